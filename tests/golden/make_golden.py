@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Run in the build container only (needs /root/reference, which never travels
+to the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's `models.cdan` / `models.cbam` on CPU, loads the
+deterministic parameter sets of `oracle.params`, pushes seeded inputs through
+the reference modules and stores inputs + expected outputs as small .npz
+files.  Only data is written: no reference source text is copied.
+
+Files written
+  state_dict_spec.json    names/shapes/dtypes of CDAN().state_dict() (236 entries)
+  params_checksum.json    checksum of oracle.params.make_state_dict(42)
+  e2e_eval_*.npz          whole-network eval outputs + stage taps
+  op_*.npz                per-op vectors (ConvBlock, DenseBlock, CBAM, ConvTranspose2d,
+                          bilinear x2 + add, maxpool)
+  train_step_32.npz       batch-stat BN forward, charbonnier loss, selected gradients,
+                          updated running statistics (dropout disabled)
+"""
+import json
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from models.cbam import CBAM  # noqa: E402  (reference)
+from models.cdan import CDAN, ConvBlock, DenseBlock  # noqa: E402  (reference)
+
+from oracle import params as P  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def np32(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def module_spec(m):
+    return OrderedDict((k, tuple(v.shape)) for k, v in m.state_dict().items())
+
+
+def load_seeded(m, seed):
+    sd = P.fill_spec(module_spec(m), seed)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    return sd
+
+
+def pack_params(sd):
+    return {"p:" + k: v.numpy() for k, v in sd.items()}
+
+
+def main():
+    # ---- checkpoint layout ------------------------------------------------------------
+    ref = CDAN()
+    ref_sd = ref.state_dict()
+    spec = P.cdan_spec()
+    assert list(spec.keys()) == list(ref_sd.keys()), "state_dict key order differs"
+    for k, shp in spec.items():
+        assert tuple(ref_sd[k].shape) == tuple(shp), (k, shp, ref_sd[k].shape)
+    with open(os.path.join(HERE, "state_dict_spec.json"), "w") as f:
+        json.dump([[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in ref_sd.items()], f, indent=0)
+
+    sd = P.make_state_dict(42)
+    with open(os.path.join(HERE, "params_checksum.json"), "w") as f:
+        json.dump({"seed": 42, "checksum": P.checksum(sd),
+                   "numel": int(sum(v.numel() for v in sd.values()))}, f)
+    ref.load_state_dict(sd, strict=True)
+    ref.eval()
+
+    # ---- whole network, eval ------------------------------------------------------------
+    def run_e2e(tag, x, keep_taps):
+        taps = {}
+        with torch.no_grad():
+            e, skips, denses = ref.encoder(x)
+            b = ref.bottleneck(e)
+            y = ref.decoder(x, b, skips, denses)
+            y2 = ref(x)
+        assert torch.equal(y, y2)
+        arrays = {"x": np32(x), "y": np32(y)}
+        if keep_taps:
+            arrays["enc"] = np32(e)
+            arrays["bott"] = np32(b)
+            for i in range(3):
+                arrays[f"skip{i}"] = np32(skips[i])
+                arrays[f"dense{i}"] = np32(denses[i])
+        save(f"e2e_eval_{tag}.npz", **arrays)
+        print(f"  {tag}: y min {y.min():.4f} max {y.max():.4f} std {y.std():.4f}")
+
+    g = torch.Generator().manual_seed(1234)
+    run_e2e("1x32x32", torch.rand(1, 3, 32, 32, generator=g), True)
+    run_e2e("1x40x56", torch.rand(1, 3, 40, 56, generator=g), True)
+    xl, _ = P.lowlight_batch(7, 2, 64, 64)
+    run_e2e("2x64x64_lowlight", xl, False)
+    # BASELINE configs[0] shape: 4 x 3 x 64 x 64 (noise-like input: clean + N(0, sigma))
+    xn, cl = P.lowlight_batch(11, 4, 64, 64)
+    xn = (cl + 0.1 * torch.randn(cl.shape, generator=g)).clamp(0, 1)
+    run_e2e("4x64x64_noise", xn, False)
+
+    # ---- per-op vectors -----------------------------------------------------------------
+    with torch.no_grad():
+        for cin, cout, h, w in ((16, 32, 16, 16), (3, 16, 12, 20), (32, 64, 8, 8)):
+            m = ConvBlock(cin, cout)
+            p = load_seeded(m, 100 + cin)
+            x = torch.randn(2, cin, h, w, generator=g)
+            y = m(x)
+            save(f"op_convblock_{cin}_{cout}.npz", x=np32(x), y=np32(y),
+                 y_pool=np32(F.max_pool2d(y, 2, 2)), **pack_params(p))
+
+        for cin, cout, h, w in ((16, 16, 16, 16), (32, 32, 8, 12), (3, 3, 16, 16)):
+            m = DenseBlock(cin, cout, 16, 4)
+            p = load_seeded(m, 200 + cin)
+            x = torch.randn(2, cin, h, w, generator=g)
+            save(f"op_denseblock_{cin}.npz", x=np32(x), y=np32(m(x)), **pack_params(p))
+
+        for c in (32, 64, 256):
+            m = CBAM(c)
+            p = load_seeded(m, 300 + c)
+            x = torch.randn(2, c, 8, 12, generator=g).relu() + 0.1 * torch.randn(2, c, 8, 12, generator=g)
+            cg = m.ChannelGate(x)
+            save(f"op_cbam_{c}.npz", x=np32(x), y_channel=np32(cg), y=np32(m(x)), **pack_params(p))
+
+        for cin, cout in ((32, 16), (64, 3)):
+            m = nn.ConvTranspose2d(cin, cout, kernel_size=3, stride=1, padding=1)
+            p = load_seeded(m, 400 + cin)
+            x = torch.randn(2, cin, 8, 12, generator=g)
+            save(f"op_convtranspose_{cin}_{cout}.npz", x=np32(x), y=np32(m(x)), **pack_params(p))
+
+        lo = torch.randn(2, 16, 6, 10, generator=g)
+        skip = torch.randn(2, 16, 12, 20, generator=g)
+        up = F.interpolate(lo, scale_factor=2, mode="bilinear", align_corners=False)
+        save("op_up2_add.npz", lo=np32(lo), skip=np32(skip), y=np32(torch.add(up, skip)))
+
+    # ---- one training step (batch-stat BN, dropout off) ----------------------------------------
+    ref.load_state_dict(sd, strict=True)
+    ref.train()
+    for mod in ref.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.eval()
+    xt, tt = P.lowlight_batch(21, 2, 32, 32)
+    y = ref(xt)
+    loss = torch.sqrt((y - tt) ** 2 + 1e-6).mean()  # charbonnier, utils/loss_factory.py:160-167
+    loss.backward()
+    named = dict(ref.named_parameters())
+    grads = {}
+    for k in ("encoder.conv1.conv.weight", "encoder.conv1.bn.weight", "encoder.dense1.layers.1.2.weight",
+              "encoder.dense2.transition_layer.2.weight", "bottleneck.ChannelGate.mlp.1.weight",
+              "bottleneck.SpatialGate.spatial.conv.weight", "decoder.conv1.bias", "decoder.conv3.weight",
+              "decoder.bn4.bias", "decoder.cbam2.ChannelGate.mlp.3.bias",
+              "decoder.final_dense.layers.3.2.weight", "decoder.final_dense.transition_layer.2.weight"):
+        grads["g:" + k] = np32(named[k].grad)
+    norms = {k: float(v.grad.double().norm()) for k, v in named.items()}
+    stats = {}
+    new_sd = ref.state_dict()
+    for k in ("encoder.conv1.bn.running_mean", "encoder.conv1.bn.running_var",
+              "decoder.cbam3.SpatialGate.spatial.bn.running_mean",
+              "decoder.cbam3.SpatialGate.spatial.bn.running_var",
+              "decoder.final_dense.layers.2.0.running_var"):
+        stats["s:" + k] = np32(new_sd[k])
+    save("train_step_32.npz", x=np32(xt), t=np32(tt), y=np32(y), loss=np.float64(loss.item()),
+         grad_norms=np.array(json.dumps(norms)), **grads, **stats)
+
+
+if __name__ == "__main__":
+    main()
