@@ -1,0 +1,206 @@
+/*
+ * mdie.h -- C ABI of libmdie_hip.so: the MI355X (gfx950) engine for the CDAN/CBAM
+ * restoration path of danielluca00/Multi-Degradation-Image-Enhancement.
+ *
+ * The reference has no native interface of its own (it is pure PyTorch); its
+ * extension point is the JSON-named class factory utils/parser.py:42-73, which
+ * instantiates models.cdan.CDAN (config/low_light.json:10-15) and calls
+ * nn.Module.forward (models/model.py:160,252,342).  This header is the boundary a
+ * binding for that path talks to: plain pointers, sizes and small POD structs, no
+ * C++ or torch types.  Every entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - All device tensors are NHWC ("channels last"), element type `dtype`
+ *     (MDIE_F32 or MDIE_BF16), pixel stride given in ELEMENTS.  Channel counts
+ *     of internal tensors are multiples of 16; the 3-channel tensors of the path
+ *     (input x, decoder.conv4 output, final output) are stored with 16 channels,
+ *     channels 3..15 zero.
+ *   - Entry points are asynchronous on `stream` (a hipStream_t passed as void*),
+ *     never allocate, never synchronise; the caller owns every buffer.
+ *   - Return 0 on success, a negative MDIE_E* code on error;
+ *     mdie_last_error() returns a thread-local message.
+ *   - Accumulation is always fp32.  MDIE_F32 uses the exact-f32 MFMA
+ *     (v_mfma_f32_16x16x4_f32), MDIE_BF16 the bf16 MFMA (v_mfma_f32_16x16x32_bf16).
+ */
+#ifndef MDIE_H
+#define MDIE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDIE_ABI_VERSION 1
+
+enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
+enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
+enum {
+  MDIE_OK = 0,
+  MDIE_EINVAL = -1,   /* bad argument / unsupported shape */
+  MDIE_ELAUNCH = -2,  /* HIP launch error */
+  MDIE_ENOSPC = -3,   /* workspace too small */
+  MDIE_ENOENT = -4    /* missing checkpoint entry */
+};
+
+#define MDIE_MAX_SEG 5
+
+/* One channel segment of a concatenated NHWC view (a DenseBlock's `torch.cat(features)`,
+ * models/cdan.py:35,38, is never materialised: each growth layer writes its own segment). */
+typedef struct {
+  const void* ptr;  /* first element of pixel (0,0,0) */
+  int channels;     /* multiple of 16 */
+  int stride;       /* elements between consecutive pixels */
+} mdie_seg;
+
+/* ---------------------------------------------------------------------------------
+ * Fused convolution:  out = pool2x2?( act( conv_k(pre(in)) * post_scale + post_shift ) + residual? )
+ *   pre(x) = relu(x * pre_scale + pre_shift) when pre_scale != NULL (pre-activation
+ *            BN -> ReLU of a dense layer, models/cdan.py:41-53; zero padding is applied
+ *            AFTER pre(), as nn.Conv2d pads the activated tensor)
+ *   conv_k = 3x3 / pad 1 / stride 1 or 1x1, weights packed by mdie_pack_conv_weight
+ *   post   = conv bias + eval-mode BatchNorm folded to scale/shift
+ *            (ConvBlock, models/cdan.py:15-19; decoder ConvTranspose2d+BN+ReLU, :127-129)
+ *   pool   = nn.MaxPool2d(2,2) (models/cdan.py:67,75,82,89) fused into the epilogue
+ * ConvTranspose2d(k3,s1,p1) is the same kernel with flipped/transposed weights
+ * (mdie_pack_conv_weight(..., transposed=1)).
+ * --------------------------------------------------------------------------------- */
+typedef struct {
+  int dtype;
+  int B, H, W;             /* input extent; output is H x W, or H/2 x W/2 with pool */
+  int ksize;               /* 3 or 1 */
+  int nseg;
+  mdie_seg in[MDIE_MAX_SEG];
+  int cin;                 /* sum of segment channels */
+  int cout;                /* stored output channels, multiple of 16 */
+  const float* pre_scale;  /* [cin] or NULL */
+  const float* pre_shift;  /* [cin] or NULL */
+  const void* weight;      /* packed, element type = dtype */
+  const float* post_scale; /* [cout] */
+  const float* post_shift; /* [cout] */
+  int act;
+  int pool;
+  const void* residual;    /* NHWC at output resolution, or NULL */
+  int res_stride;
+  void* out;
+  int out_stride;
+} mdie_conv_desc;
+
+int mdie_conv_fwd(const mdie_conv_desc* d, void* stream);
+
+/* Host-side packing of one convolution weight (fp32, PyTorch layout) into the layout
+ * mdie_conv_fwd reads: [cin_chunk][tap][cout_pad][KC] with KC = 16 (f32) / 32 (bf16)
+ * channels = 64 bytes per row, zero padded.
+ *   transposed = 0: w is [cout][cin][k][k]   (nn.Conv2d)
+ *   transposed = 1: w is [cin][cout][k][k]   (nn.ConvTranspose2d, models/cdan.py:103-115);
+ *                   the spatial flip is applied here.
+ * cin_off / cin_pad place the `cin` real channels inside a wider stored input:
+ * real channel c reads stored channel c + (c >= split ? gap : 0)  (the 3-channel base of
+ * decoder.final_dense is stored in 16 channels: split = 3, gap = 13). */
+size_t mdie_conv_weight_bytes(int dtype, int ksize, int cin_stored, int cout_stored);
+int mdie_pack_conv_weight(int dtype, int ksize, int transposed, const float* w, int cout, int cin,
+                          int cout_stored, int cin_stored, int split, int gap, void* dst);
+
+/* ---------------------------------------------------------------------------------
+ * CBAM (models/cbam.py:84-95) as four passes over an NHWC tensor x[B,H,W,C]:
+ *   1. mdie_cbam_pool      per-(image, channel) sum and max over H*W  (cbam.py:41,44)
+ *   2. mdie_cbam_gate      att = MLP(avg) + MLP(max); gate = sigmoid(att)   (cbam.py:30-35,42-59)
+ *   3. mdie_cbam_chanpool  y = x*gate; map = (max_c y, mean_c y)            (cbam.py:59,68-70)
+ *   4. mdie_cbam_spatial   s = sigmoid(BN(conv7x7(map))); out = x*gate*s [* mul]
+ *                          (cbam.py:72-82; `out *= denses[k]`, models/cdan.py:133,141,149)
+ * --------------------------------------------------------------------------------- */
+typedef struct {
+  int dtype;
+  int B, H, W, C;
+  const void* x;       int x_stride;
+  const float* w1;     /* [C/16][C]   ChannelGate.mlp.1.weight */
+  const float* b1;     /* [C/16] */
+  const float* w2;     /* [C][C/16]   ChannelGate.mlp.3.weight */
+  const float* b2;     /* [C] */
+  const float* w7;     /* [2][7][7]   SpatialGate.spatial.conv.weight (max plane first) */
+  const float* bn;     /* device [2]: eval-mode BN(1) folded to (scale, shift) */
+  const void* mul;     int mul_stride;  /* optional elementwise multiplicand, or NULL */
+  void* out;           int out_stride;
+  void* workspace;     size_t workspace_bytes; /* >= mdie_cbam_workspace_bytes */
+} mdie_cbam_desc;
+
+size_t mdie_cbam_workspace_bytes(int B, int H, int W, int C);
+int mdie_cbam_fwd(const mdie_cbam_desc* d, void* stream);
+/* the same pipeline stopped after pass 2 + channel scaling only (for stage-wise parity tests) */
+int mdie_cbam_channel_only_fwd(const mdie_cbam_desc* d, void* stream);
+
+/* out[B,2H,2W,C] = bilinear_x2(lo[B,H,W,C]) + skip  (F.interpolate(scale_factor=2, 'bilinear',
+ * align_corners=False) + torch.add, models/cdan.py:137-138,145-146,153-154) */
+int mdie_upsample2x_add(int dtype, int B, int H, int W, int C, const void* lo, int lo_stride,
+                        const void* skip, int skip_stride, void* out, int out_stride, void* stream);
+
+/* Boundary layout changes: fp32 NCHW [B,3,H,W] <-> NHWC with 16 stored channels. */
+int mdie_nchw3_to_nhwc16(int dtype, int B, int H, int W, const float* x_nchw, void* out, void* stream);
+int mdie_nhwc16_to_nchw3(int dtype, int B, int H, int W, const void* in, float* y_nchw, void* stream);
+/* Generic converters used by the per-op tests: fp32 NCHW [B,C,H,W] <-> NHWC dtype, C % 16 == 0 */
+int mdie_nchw_to_nhwc(int dtype, int B, int C, int H, int W, const float* x_nchw, void* out, void* stream);
+int mdie_nhwc_to_nchw(int dtype, int B, int C, int H, int W, const void* in, float* y_nchw, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Whole network: CDAN.forward (models/cdan.py:171-176) in eval mode
+ * (network.eval(), models/model.py:232: running-stat BatchNorm, dropout = identity).
+ *
+ *   blob   = mdie_cdan_pack_params(...)  host side, once per checkpoint
+ *   y      = mdie_cdan_forward(blob_dev, x, ...)  one call enqueues every kernel
+ * --------------------------------------------------------------------------------- */
+typedef struct {
+  const char* name;   /* state_dict key, e.g. "encoder.conv1.conv.weight" */
+  const float* data;  /* host pointer, fp32, PyTorch layout (int64 counters may be omitted) */
+  int64_t numel;
+} mdie_tensor;
+
+size_t mdie_cdan_param_bytes(int dtype);
+/* Packs the reference checkpoint (the 236-entry state_dict written by models/base.py:52-55)
+ * into one relocatable blob: packed conv weights, folded BN scale/shift vectors, CBAM MLPs. */
+int mdie_cdan_pack_params(int dtype, const mdie_tensor* tensors, int n, void* blob_host, size_t blob_bytes);
+
+size_t mdie_cdan_workspace_bytes(int dtype, int B, int H, int W);
+
+/* names of intermediate tensors mdie_cdan_forward can expose for stage-wise parity
+ * (NHWC in workspace; the host copies them out through mdie_nhwc_to_nchw) */
+typedef struct {
+  const void* ptr; int channels; int stride; int H, W;
+} mdie_tap;
+enum { MDIE_TAP_SKIP0 = 0, MDIE_TAP_SKIP1, MDIE_TAP_SKIP2, MDIE_TAP_DENSE0, MDIE_TAP_DENSE1,
+       MDIE_TAP_DENSE2, MDIE_TAP_ENC, MDIE_TAP_BOTT, MDIE_TAP_DEC1, MDIE_TAP_DEC2, MDIE_TAP_DEC3,
+       MDIE_TAP_DEC4, MDIE_TAP_COUNT };
+
+/* x, y: fp32 NCHW [B,3,H,W] device pointers; H, W multiples of 8.
+ * taps (optional, host array of MDIE_TAP_COUNT) is filled with workspace views.
+ * launch_ms (optional, host array of capacity max_launches) turns on the instrumented mode:
+ * a hipEvent pair around every kernel launch, synchronised at the end (NOT capturable);
+ * n_launches receives the count, launch_kind[i] an MDIE_K* id. */
+typedef struct {
+  int dtype;
+  int B, H, W;
+  const void* params;      /* device copy of the packed blob */
+  const float* x;
+  float* y;
+  void* workspace;  size_t workspace_bytes;
+  mdie_tap* taps;
+  float* launch_ms; int* launch_kind; int max_launches; int* n_launches;
+} mdie_cdan_fwd_desc;
+
+enum { MDIE_K_LAYOUT = 0, MDIE_K_CONV3 = 1, MDIE_K_CONV1 = 2, MDIE_K_CBAM_POOL = 3, MDIE_K_CBAM_GATE = 4,
+       MDIE_K_CBAM_CHANPOOL = 5, MDIE_K_CBAM_SPATIAL = 6, MDIE_K_UPSAMPLE = 7, MDIE_K_COUNT = 8 };
+
+int mdie_cdan_forward(const mdie_cdan_fwd_desc* d, void* stream);
+
+/* algorithmic work of one forward: FLOPs (2*MAC of every conv/linear)
+ * and fused-schedule activation bytes for element size `esize` */
+double mdie_cdan_flops(int B, int H, int W);
+double mdie_cdan_algorithmic_bytes(int B, int H, int W, int esize);
+
+const char* mdie_last_error(void);
+int mdie_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDIE_H */

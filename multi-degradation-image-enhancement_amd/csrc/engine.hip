@@ -1,0 +1,484 @@
+// Whole-network plan: CDAN.forward (models/cdan.py:171-176) in eval mode as one host call that
+// enqueues every kernel on the caller's stream (capturable into a hipGraph: no allocation, no
+// synchronisation), plus the host-side packing of the reference checkpoint into the parameter blob.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.hpp"
+
+namespace mdie {
+
+// ---- error plumbing -------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+LaunchTimer*& current_timer() {
+  static thread_local LaunchTimer* t = nullptr;
+  return t;
+}
+
+// ---- architecture table -----------------------------------------------------------------------------------
+// Everything below is derived from the layer widths of models/cdan.py:58-65,103-119.
+constexpr float BN_EPS = 1e-5f;
+constexpr int GROWTH = 16, NLAYERS = 4;
+
+struct ConvSpec {
+  std::string w_key, b_key, bn_pre, bn_post;
+  int ks, transposed;
+  int cin, cout;        // real channels
+  int cin_st, cout_st;  // stored channels (multiples of 16)
+  int split, gap;       // real channel c >= split is stored at c + gap
+};
+struct CbamSpec {
+  std::string prefix;
+  int C;
+};
+
+static int st16(int c) { return (c + 15) / 16 * 16; }
+
+enum { CV_E1 = 0, CV_E2, CV_E3, CV_E4, CV_DENSE0 = 4 /* 4 blocks x 5 */, CV_D1 = 24, CV_D2, CV_D3, CV_D4, CV_COUNT };
+enum { CB_BOTT = 0, CB_1, CB_2, CB_3, CB_COUNT };
+
+struct Arch {
+  std::vector<ConvSpec> conv;
+  std::vector<CbamSpec> cbam;
+  Arch() {
+    conv.resize(CV_COUNT);
+    const int enc[5] = {3, 64, 128, 256, 512};
+    for (int i = 0; i < 4; ++i) {
+      const std::string p = "encoder.conv" + std::to_string(i + 1);
+      conv[CV_E1 + i] = {p + ".conv.weight", p + ".conv.bias", "", p + ".bn", 3, 0, enc[i], enc[i + 1], st16(enc[i]), st16(enc[i + 1]), enc[i], 0};
+    }
+    const char* dn[4] = {"encoder.dense1", "encoder.dense2", "encoder.dense3", "decoder.final_dense"};
+    const int dc[4] = {64, 128, 256, 3};
+    for (int b = 0; b < 4; ++b) {
+      const int c0 = dc[b], c0s = st16(c0), gap = c0s - c0;
+      for (int l = 0; l <= NLAYERS; ++l) {
+        const bool tr = l == NLAYERS;
+        const std::string p = std::string(dn[b]) + (tr ? ".transition_layer" : ".layers." + std::to_string(l));
+        const int cin = c0 + GROWTH * l, cout = tr ? c0 : GROWTH;
+        conv[CV_DENSE0 + b * 5 + l] = {p + ".2.weight", p + ".2.bias", p + ".0", "", tr ? 1 : 3, 0, cin, cout, c0s + GROWTH * l, st16(cout), c0, gap};
+      }
+    }
+    const int dec[5] = {512, 256, 128, 64, 3};
+    for (int i = 0; i < 4; ++i) {
+      const std::string p = "decoder.conv" + std::to_string(i + 1);
+      conv[CV_D1 + i] = {p + ".weight", p + ".bias", "", "decoder.bn" + std::to_string(i + 1), 3, 1, dec[i], dec[i + 1], st16(dec[i]), st16(dec[i + 1]), dec[i], 0};
+    }
+    cbam = {{"bottleneck", 512}, {"decoder.cbam1", 256}, {"decoder.cbam2", 128}, {"decoder.cbam3", 64}};
+  }
+};
+static const Arch& arch() {
+  static const Arch a;
+  return a;
+}
+
+// ---- parameter blob layout ----------------------------------------------------------------------------------
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct ConvBlob { size_t w, post_scale, post_shift, pre_scale, pre_shift; };
+struct CbamBlob { size_t w1, b1, w2, b2, w7, bn; };
+struct BlobLayout {
+  ConvBlob conv[CV_COUNT];
+  CbamBlob cbam[CB_COUNT];
+  size_t total;
+};
+
+static size_t conv_weight_bytes(int dtype, int ks, int cin_st, int cout_st) {
+  const int kc = dtype == MDIE_F32 ? 16 : 32;
+  return (size_t)cdiv(cin_st, kc) * ks * ks * cout_st * 64;
+}
+
+static BlobLayout blob_layout(int dtype) {
+  BlobLayout L{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+  const Arch& A = arch();
+  for (int i = 0; i < CV_COUNT; ++i) {
+    const ConvSpec& s = A.conv[i];
+    L.conv[i].w = take(conv_weight_bytes(dtype, s.ks, s.cin_st, s.cout_st));
+    L.conv[i].post_scale = take(s.cout_st * sizeof(float));
+    L.conv[i].post_shift = take(s.cout_st * sizeof(float));
+    L.conv[i].pre_scale = take(s.cin_st * sizeof(float));
+    L.conv[i].pre_shift = take(s.cin_st * sizeof(float));
+  }
+  for (int i = 0; i < CB_COUNT; ++i) {
+    const int C = A.cbam[i].C, Hd = C / 16;
+    L.cbam[i].w1 = take((size_t)Hd * C * sizeof(float));
+    L.cbam[i].b1 = take(Hd * sizeof(float));
+    L.cbam[i].w2 = take((size_t)C * Hd * sizeof(float));
+    L.cbam[i].b2 = take(C * sizeof(float));
+    L.cbam[i].w7 = take(98 * sizeof(float));
+    L.cbam[i].bn = take(2 * sizeof(float));
+  }
+  L.total = off;
+  return L;
+}
+
+// ---- host-side packing ----------------------------------------------------------------------------------------
+static uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+static int pack_conv_weight(int dtype, int ks, int transposed, const float* w, int cout, int cin, int cout_st, int cin_st, int split,
+                            int gap, void* dst) {
+  const int kc = dtype == MDIE_F32 ? 16 : 32;
+  const int ntap = ks * ks;
+  const size_t esz = dtype_size(dtype);
+  memset(dst, 0, conv_weight_bytes(dtype, ks, cin_st, cout_st));
+  for (int o = 0; o < cout; ++o)
+    for (int c = 0; c < cin; ++c) {
+      const int cs = c + (c >= split ? gap : 0);
+      const int chunk = cs / kc, k = cs % kc;
+      for (int kh = 0; kh < ks; ++kh)
+        for (int kw = 0; kw < ks; ++kw) {
+          // ConvTranspose2d(k3,s1,p1) == Conv2d with W'[o][c][kh][kw] = W[c][o][k-1-kh][k-1-kw]
+          const float v = transposed ? w[(((size_t)c * cout + o) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)]
+                                     : w[(((size_t)o * cin + c) * ks + kh) * ks + kw];
+          const size_t idx = (((size_t)chunk * ntap + kh * ks + kw) * cout_st + o) * kc + k;
+          if (esz == 4) reinterpret_cast<float*>(dst)[idx] = v;
+          else reinterpret_cast<uint16_t*>(dst)[idx] = f32_to_bf16_rne(v);
+        }
+    }
+  return MDIE_OK;
+}
+
+struct TensorMap {
+  std::unordered_map<std::string, const mdie_tensor*> m;
+  const float* get(const std::string& k, int64_t numel) const {
+    auto it = m.find(k);
+    if (it == m.end() || !it->second->data) { set_error("mdie_cdan_pack_params: checkpoint entry '%s' missing", k.c_str()); return nullptr; }
+    if (it->second->numel != numel) {
+      set_error("mdie_cdan_pack_params: '%s' has %lld elements, expected %lld", k.c_str(), (long long)it->second->numel, (long long)numel);
+      return nullptr;
+    }
+    return it->second->data;
+  }
+};
+
+// eval-mode BatchNorm as y = x * s + t  (models/cdan.py:12; running statistics, eps 1e-5)
+static bool bn_fold(const TensorMap& T, const std::string& p, int c, std::vector<float>& s, std::vector<float>& t) {
+  const float *g = T.get(p + ".weight", c), *b = T.get(p + ".bias", c), *m = T.get(p + ".running_mean", c), *v = T.get(p + ".running_var", c);
+  if (!g || !b || !m || !v) return false;
+  s.resize(c); t.resize(c);
+  for (int i = 0; i < c; ++i) {
+    const double inv = 1.0 / sqrt((double)v[i] + (double)BN_EPS);
+    s[i] = (float)(g[i] * inv);
+    t[i] = (float)(b[i] - m[i] * g[i] * inv);
+  }
+  return true;
+}
+
+// ---- workspace plan ---------------------------------------------------------------------------------------------------
+struct Buf { size_t off; int C; };  // NHWC, stride == C
+struct Plan {
+  Buf x16, o[3], g[3][4], d[3], e, bott, t1, u1, t2lo, t2, u2, t3lo, t3, u3, t4lo, t4, fg[4], out16;
+  size_t cbam_ws, cbam_ws_bytes;
+  size_t total;
+};
+
+static Plan make_plan(int dtype, int B, int H, int W) {
+  Plan P{};
+  size_t off = 0;
+  const size_t esz = dtype_size(dtype);
+  auto take = [&](int C, int h, int w) { Buf b{off, C}; off += align256((size_t)B * h * w * C * esz); return b; };
+  const int h1 = H / 2, w1 = W / 2, h2 = H / 4, w2 = W / 4, h3 = H / 8, w3 = W / 8;
+  const int hs[3] = {h1, h2, h3}, ws[3] = {w1, w2, w3}, cs[3] = {64, 128, 256};
+  P.x16 = take(16, H, W);
+  for (int i = 0; i < 3; ++i) {
+    P.o[i] = take(cs[i], hs[i], ws[i]);
+    for (int l = 0; l < 4; ++l) P.g[i][l] = take(16, hs[i], ws[i]);
+    P.d[i] = take(cs[i], hs[i], ws[i]);
+  }
+  P.e = take(512, h3, w3);
+  P.bott = take(512, h3, w3);
+  P.t1 = take(256, h3, w3); P.u1 = take(256, h3, w3);
+  P.t2lo = take(128, h3, w3); P.t2 = take(128, h2, w2); P.u2 = take(128, h2, w2);
+  P.t3lo = take(64, h2, w2); P.t3 = take(64, h1, w1); P.u3 = take(64, h1, w1);
+  P.t4lo = take(16, h1, w1); P.t4 = take(16, H, W);
+  for (int l = 0; l < 4; ++l) P.fg[l] = take(16, H, W);
+  P.out16 = take(16, H, W);
+  size_t cb = 0;
+  const int ch[4] = {512, 256, 128, 64}, chh[4] = {h3, h3, h2, h1}, cww[4] = {w3, w3, w2, w1};
+  for (int i = 0; i < 4; ++i) { size_t b = mdie_cbam_workspace_bytes(B, chh[i], cww[i], ch[i]); cb = b > cb ? b : cb; }
+  P.cbam_ws = off; P.cbam_ws_bytes = cb; off += align256(cb);
+  P.total = off;
+  return P;
+}
+
+}  // namespace mdie
+
+using namespace mdie;
+
+extern "C" const char* mdie_last_error(void) { return g_err; }
+extern "C" int mdie_abi_version(void) { return MDIE_ABI_VERSION; }
+
+extern "C" size_t mdie_conv_weight_bytes(int dtype, int ksize, int cin_stored, int cout_stored) {
+  return conv_weight_bytes(dtype, ksize, cin_stored, cout_stored);
+}
+
+extern "C" int mdie_pack_conv_weight(int dtype, int ksize, int transposed, const float* w, int cout, int cin, int cout_stored,
+                                     int cin_stored, int split, int gap, void* dst) {
+  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_pack_conv_weight: bad dtype %d", dtype);
+  MDIE_REQUIRE(ksize == 1 || ksize == 3, "mdie_pack_conv_weight: ksize %d", ksize);
+  MDIE_REQUIRE(w && dst && cout > 0 && cin > 0, "mdie_pack_conv_weight: null/empty");
+  MDIE_REQUIRE(cout_stored >= cout && cout_stored % 16 == 0, "mdie_pack_conv_weight: cout_stored %d", cout_stored);
+  MDIE_REQUIRE(cin_stored % 16 == 0 && cin_stored >= cin + (split < cin ? gap : 0) && gap >= 0 && split >= 0,
+               "mdie_pack_conv_weight: cin_stored %d too small for cin %d split %d gap %d", cin_stored, cin, split, gap);
+  return pack_conv_weight(dtype, ksize, transposed, w, cout, cin, cout_stored, cin_stored, split, gap, dst);
+}
+
+extern "C" size_t mdie_cdan_param_bytes(int dtype) {
+  if (dtype != MDIE_F32 && dtype != MDIE_BF16) return 0;
+  return blob_layout(dtype).total;
+}
+
+extern "C" int mdie_cdan_pack_params(int dtype, const mdie_tensor* tensors, int n, void* blob_host, size_t blob_bytes) {
+  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_cdan_pack_params: bad dtype %d", dtype);
+  MDIE_REQUIRE(tensors && n > 0 && blob_host, "mdie_cdan_pack_params: null argument");
+  const BlobLayout L = blob_layout(dtype);
+  if (blob_bytes < L.total) { set_error("mdie_cdan_pack_params: blob %zu < %zu bytes", blob_bytes, L.total); return MDIE_ENOSPC; }
+  TensorMap T;
+  for (int i = 0; i < n; ++i)
+    if (tensors[i].name) T.m[tensors[i].name] = &tensors[i];
+  char* blob = reinterpret_cast<char*>(blob_host);
+  memset(blob, 0, L.total);
+  const Arch& A = arch();
+  for (int i = 0; i < CV_COUNT; ++i) {
+    const ConvSpec& s = A.conv[i];
+    const float* w = T.get(s.w_key, (int64_t)s.cin * s.cout * s.ks * s.ks);
+    const float* b = T.get(s.b_key, s.cout);
+    if (!w || !b) return MDIE_ENOENT;
+    pack_conv_weight(dtype, s.ks, s.transposed, w, s.cout, s.cin, s.cout_st, s.cin_st, s.split, s.gap, blob + L.conv[i].w);
+    float* ps = reinterpret_cast<float*>(blob + L.conv[i].post_scale);
+    float* pt = reinterpret_cast<float*>(blob + L.conv[i].post_shift);
+    if (!s.bn_post.empty()) {
+      std::vector<float> sc, sh;
+      if (!bn_fold(T, s.bn_post, s.cout, sc, sh)) return MDIE_ENOENT;
+      for (int c = 0; c < s.cout; ++c) { ps[c] = sc[c]; pt[c] = (float)((double)b[c] * sc[c] + sh[c]); }
+    } else {
+      for (int c = 0; c < s.cout; ++c) { ps[c] = 1.0f; pt[c] = b[c]; }
+    }
+    if (!s.bn_pre.empty()) {
+      std::vector<float> sc, sh;
+      if (!bn_fold(T, s.bn_pre, s.cin, sc, sh)) return MDIE_ENOENT;
+      float* qs = reinterpret_cast<float*>(blob + L.conv[i].pre_scale);
+      float* qt = reinterpret_cast<float*>(blob + L.conv[i].pre_shift);
+      for (int c = 0; c < s.cin; ++c) {
+        const int cs = c + (c >= s.split ? s.gap : 0);
+        qs[cs] = sc[c]; qt[cs] = sh[c];
+      }
+    }
+  }
+  for (int i = 0; i < CB_COUNT; ++i) {
+    const std::string& p = A.cbam[i].prefix;
+    const int C = A.cbam[i].C, Hd = C / 16;
+    const float* w1 = T.get(p + ".ChannelGate.mlp.1.weight", (int64_t)Hd * C);
+    const float* b1 = T.get(p + ".ChannelGate.mlp.1.bias", Hd);
+    const float* w2 = T.get(p + ".ChannelGate.mlp.3.weight", (int64_t)C * Hd);
+    const float* b2 = T.get(p + ".ChannelGate.mlp.3.bias", C);
+    const float* w7 = T.get(p + ".SpatialGate.spatial.conv.weight", 98);
+    std::vector<float> sc, sh;
+    if (!w1 || !b1 || !w2 || !b2 || !w7 || !bn_fold(T, p + ".SpatialGate.spatial.bn", 1, sc, sh)) return MDIE_ENOENT;
+    memcpy(blob + L.cbam[i].w1, w1, (size_t)Hd * C * 4);
+    memcpy(blob + L.cbam[i].b1, b1, Hd * 4);
+    memcpy(blob + L.cbam[i].w2, w2, (size_t)C * Hd * 4);
+    memcpy(blob + L.cbam[i].b2, b2, C * 4);
+    memcpy(blob + L.cbam[i].w7, w7, 98 * 4);
+    float bn[2] = {sc[0], sh[0]};
+    memcpy(blob + L.cbam[i].bn, bn, 8);
+  }
+  return MDIE_OK;
+}
+
+extern "C" size_t mdie_cdan_workspace_bytes(int dtype, int B, int H, int W) {
+  if ((dtype != MDIE_F32 && dtype != MDIE_BF16) || B <= 0 || H <= 0 || W <= 0 || H % 8 || W % 8) return 0;
+  return make_plan(dtype, B, H, W).total;
+}
+
+extern "C" double mdie_cdan_flops(int B, int H, int W) {
+  // 2*MAC over the 35 conv / 16 linear applications (hook-traced law of SURVEY.md section 6)
+  return (double)B * (252837.375 * (double)H * (double)W + 174080.0);
+}
+
+extern "C" double mdie_cdan_algorithmic_bytes(int B, int H, int W, int esize) {
+  // Fused-schedule model of SURVEY.md 8(d): each conv reads its input and writes its output once
+  // (BN/ReLU/bias/sigmoid/maxpool free, torch.cat free); a CBAM reads its tensor twice, writes it
+  // once, reads the multiplicand and round-trips the 2-channel map; upsample+add reads low-res and
+  // skip and writes the sum.  Weights (3.53 M elements) are counted once per batch.
+  const double P = (double)H * W;
+  double el = 0;
+  auto conv = [&](double cin, double cout, double pin, double pout) { el += cin * pin + cout * pout; };
+  auto dense = [&](double c, double p, double cout) {
+    for (int i = 0; i < 4; ++i) el += (c + 16 * i) * p + 16 * p;
+    el += (c + 64) * p + cout * p;
+  };
+  auto cbam = [&](double c, double p, bool mul) { el += 3 * c * p + (mul ? c * p : 0) + 4 * p; };
+  auto up = [&](double c, double plo) { el += c * plo + 8 * c * plo; };
+  conv(3, 64, P, P / 4); dense(64, P / 4, 64);
+  conv(64, 128, P / 4, P / 16); dense(128, P / 16, 128);
+  conv(128, 256, P / 16, P / 64); dense(256, P / 64, 256);
+  conv(256, 512, P / 64, P / 64);
+  cbam(512, P / 64, false);
+  conv(512, 256, P / 64, P / 64); el += 256 * P / 64; cbam(256, P / 64, true);
+  conv(256, 128, P / 64, P / 64); up(128, P / 64); cbam(128, P / 16, true);
+  conv(128, 64, P / 16, P / 16); up(64, P / 16); cbam(64, P / 4, true);
+  conv(64, 3, P / 4, P / 4); up(3, P / 4);
+  dense(3, P, 3);
+  const double weights = 3585663.0 - 2.0 * 0;  // parameters, read once per batch
+  return ((double)B * el + weights) * esize;
+}
+
+// ---- the forward plan ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct Ctx {
+  int dtype, B;
+  const char* params;
+  char* ws;
+  BlobLayout L;
+  hipStream_t stream;
+  size_t esz;
+};
+
+static mdie_seg seg(const Ctx& c, const Buf& b) { return mdie_seg{c.ws + b.off, b.C, b.C}; }
+
+static int run_conv(const Ctx& c, int id, int H, int W, std::initializer_list<Buf> in, const Buf& out, int act, int pool,
+                    const Buf* residual) {
+  const ConvSpec& s = arch().conv[id];
+  mdie_conv_desc d{};
+  d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.ksize = s.ks;
+  d.nseg = 0; d.cin = 0;
+  for (const Buf& b : in) { d.in[d.nseg++] = seg(c, b); d.cin += b.C; }
+  d.cout = s.cout_st;
+  if (d.cin != s.cin_st) { set_error("plan: conv %d fed %d channels, expects %d", id, d.cin, s.cin_st); return MDIE_EINVAL; }
+  if (!s.bn_pre.empty()) {
+    d.pre_scale = reinterpret_cast<const float*>(c.params + c.L.conv[id].pre_scale);
+    d.pre_shift = reinterpret_cast<const float*>(c.params + c.L.conv[id].pre_shift);
+  }
+  d.weight = c.params + c.L.conv[id].w;
+  d.post_scale = reinterpret_cast<const float*>(c.params + c.L.conv[id].post_scale);
+  d.post_shift = reinterpret_cast<const float*>(c.params + c.L.conv[id].post_shift);
+  d.act = act; d.pool = pool;
+  if (residual) { d.residual = c.ws + residual->off; d.res_stride = residual->C; }
+  d.out = c.ws + out.off; d.out_stride = out.C;
+  return mdie_conv_fwd(&d, c.stream);
+}
+
+static int run_dense(const Ctx& c, int block, int H, int W, const Buf& base, const Buf* g, const Buf& out, int act) {
+  const int id0 = CV_DENSE0 + block * 5;
+  int e;
+  if ((e = run_conv(c, id0 + 0, H, W, {base}, g[0], MDIE_ACT_NONE, 0, nullptr))) return e;
+  if ((e = run_conv(c, id0 + 1, H, W, {base, g[0]}, g[1], MDIE_ACT_NONE, 0, nullptr))) return e;
+  if ((e = run_conv(c, id0 + 2, H, W, {base, g[0], g[1]}, g[2], MDIE_ACT_NONE, 0, nullptr))) return e;
+  if ((e = run_conv(c, id0 + 3, H, W, {base, g[0], g[1], g[2]}, g[3], MDIE_ACT_NONE, 0, nullptr))) return e;
+  return run_conv(c, id0 + 4, H, W, {base, g[0], g[1], g[2], g[3]}, out, act, 0, nullptr);
+}
+
+static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, const Buf& x, const Buf* mul, const Buf& out) {
+  const CbamBlob& o = c.L.cbam[id];
+  mdie_cbam_desc d{};
+  d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.C = arch().cbam[id].C;
+  d.x = c.ws + x.off; d.x_stride = x.C;
+  d.w1 = reinterpret_cast<const float*>(c.params + o.w1); d.b1 = reinterpret_cast<const float*>(c.params + o.b1);
+  d.w2 = reinterpret_cast<const float*>(c.params + o.w2); d.b2 = reinterpret_cast<const float*>(c.params + o.b2);
+  d.w7 = reinterpret_cast<const float*>(c.params + o.w7);
+  d.bn = reinterpret_cast<const float*>(c.params + o.bn);
+  if (mul) { d.mul = c.ws + mul->off; d.mul_stride = mul->C; }
+  d.out = c.ws + out.off; d.out_stride = out.C;
+  d.workspace = c.ws + P.cbam_ws; d.workspace_bytes = P.cbam_ws_bytes;
+  return mdie_cbam_fwd(&d, c.stream);
+}
+
+static int run_up(const Ctx& c, int H, int W, const Buf& lo, const Buf& skip, const Buf& out) {
+  return mdie_upsample2x_add(c.dtype, c.B, H, W, lo.C, c.ws + lo.off, lo.C, c.ws + skip.off, skip.C, c.ws + out.off, out.C, c.stream);
+}
+
+static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
+  const int B = d->B, H = d->H, W = d->W;
+  const Plan P = make_plan(d->dtype, B, H, W);
+  if (d->workspace_bytes < P.total) { set_error("mdie_cdan_forward: workspace %zu < %zu bytes", d->workspace_bytes, P.total); return MDIE_ENOSPC; }
+  Ctx c{d->dtype, B, reinterpret_cast<const char*>(d->params), reinterpret_cast<char*>(d->workspace), blob_layout(d->dtype), stream,
+        dtype_size(d->dtype)};
+  const int h1 = H / 2, w1 = W / 2, h2 = H / 4, w2 = W / 4, h3 = H / 8, w3 = W / 8;
+  int e;
+#define RUN(call) do { if ((e = (call))) return e; } while (0)
+  RUN(mdie_nchw3_to_nhwc16(d->dtype, B, H, W, d->x, c.ws + P.x16.off, stream));
+  // Encoder.forward, models/cdan.py:70-98 (dropout = identity in eval)
+  RUN(run_conv(c, CV_E1, H, W, {P.x16}, P.o[0], MDIE_ACT_RELU, 1, nullptr));
+  RUN(run_dense(c, 0, h1, w1, P.o[0], P.g[0], P.d[0], MDIE_ACT_NONE));
+  RUN(run_conv(c, CV_E2, h1, w1, {P.o[0]}, P.o[1], MDIE_ACT_RELU, 1, nullptr));
+  RUN(run_dense(c, 1, h2, w2, P.o[1], P.g[1], P.d[1], MDIE_ACT_NONE));
+  RUN(run_conv(c, CV_E3, h2, w2, {P.o[1]}, P.o[2], MDIE_ACT_RELU, 1, nullptr));
+  RUN(run_dense(c, 2, h3, w3, P.o[2], P.g[2], P.d[2], MDIE_ACT_NONE));
+  RUN(run_conv(c, CV_E4, h3, w3, {P.o[2]}, P.e, MDIE_ACT_RELU, 0, nullptr));
+  // bottleneck, models/cdan.py:173
+  RUN(run_cbam_stage(c, P, CB_BOTT, h3, w3, P.e, nullptr, P.bott));
+  // Decoder.forward, models/cdan.py:126-159
+  RUN(run_conv(c, CV_D1, h3, w3, {P.bott}, P.t1, MDIE_ACT_RELU, 0, &P.o[2]));      // convT+BN+ReLU, + skip2
+  RUN(run_cbam_stage(c, P, CB_1, h3, w3, P.t1, &P.d[2], P.u1));                     // cbam1, *= dense3
+  RUN(run_conv(c, CV_D2, h3, w3, {P.u1}, P.t2lo, MDIE_ACT_RELU, 0, nullptr));
+  RUN(run_up(c, h3, w3, P.t2lo, P.o[1], P.t2));                                     // bilinear x2 + skip1
+  RUN(run_cbam_stage(c, P, CB_2, h2, w2, P.t2, &P.d[1], P.u2));
+  RUN(run_conv(c, CV_D3, h2, w2, {P.u2}, P.t3lo, MDIE_ACT_RELU, 0, nullptr));
+  RUN(run_up(c, h2, w2, P.t3lo, P.o[0], P.t3));
+  RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3));
+  RUN(run_conv(c, CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
+  RUN(run_up(c, h1, w1, P.t4lo, P.x16, P.t4));                                      // bilinear x2 + x
+  RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID));                // final_dense + sigmoid
+  RUN(mdie_nhwc16_to_nchw3(d->dtype, B, H, W, c.ws + P.out16.off, d->y, stream));
+#undef RUN
+  if (d->taps) {
+    auto tap = [&](int id, const Buf& b, int h, int w) { d->taps[id] = mdie_tap{c.ws + b.off, b.C, b.C, h, w}; };
+    tap(MDIE_TAP_SKIP0, P.o[0], h1, w1); tap(MDIE_TAP_SKIP1, P.o[1], h2, w2); tap(MDIE_TAP_SKIP2, P.o[2], h3, w3);
+    tap(MDIE_TAP_DENSE0, P.d[0], h1, w1); tap(MDIE_TAP_DENSE1, P.d[1], h2, w2); tap(MDIE_TAP_DENSE2, P.d[2], h3, w3);
+    tap(MDIE_TAP_ENC, P.e, h3, w3); tap(MDIE_TAP_BOTT, P.bott, h3, w3);
+    tap(MDIE_TAP_DEC1, P.u1, h3, w3); tap(MDIE_TAP_DEC2, P.u2, h2, w2); tap(MDIE_TAP_DEC3, P.u3, h1, w1);
+    tap(MDIE_TAP_DEC4, P.t4, H, W);
+  }
+  return MDIE_OK;
+}
+
+}  // namespace
+
+extern "C" int mdie_cdan_forward(const mdie_cdan_fwd_desc* d, void* stream) {
+  MDIE_REQUIRE(d != nullptr, "mdie_cdan_forward: null descriptor");
+  MDIE_REQUIRE(d->dtype == MDIE_F32 || d->dtype == MDIE_BF16, "mdie_cdan_forward: bad dtype %d", d->dtype);
+  MDIE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "mdie_cdan_forward: empty batch %dx%dx%d", d->B, d->H, d->W);
+  MDIE_REQUIRE(d->H % 8 == 0 && d->W % 8 == 0,
+               "mdie_cdan_forward: H, W must be multiples of 8 (three 2x2 pools + three x2 upsamples with skip adds), got %dx%d", d->H, d->W);
+  MDIE_REQUIRE(d->params && d->x && d->y && d->workspace, "mdie_cdan_forward: null pointer");
+  MDIE_REQUIRE((((uintptr_t)d->params | (uintptr_t)d->workspace) & 255) == 0, "mdie_cdan_forward: params/workspace must be 256-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (!d->launch_ms) return forward_impl(d, s);
+
+  // instrumented mode: one event pair per launch (not capturable; synchronises at the end)
+  MDIE_REQUIRE(d->launch_kind && d->n_launches && d->max_launches > 0, "mdie_cdan_forward: instrumentation buffers missing");
+  LaunchTimer t;
+  t.stream = s; t.cap = d->max_launches; t.kind = d->launch_kind;
+  std::vector<hipEvent_t> ev(2 * (size_t)t.cap);
+  for (auto& x : ev) (void)hipEventCreate(&x);
+  t.ev = ev.data();
+  current_timer() = &t;
+  const int rc = forward_impl(d, s);
+  current_timer() = nullptr;
+  (void)hipStreamSynchronize(s);
+  for (int i = 0; i < t.n; ++i) (void)hipEventElapsedTime(&d->launch_ms[i], ev[2 * i], ev[2 * i + 1]);
+  *d->n_launches = t.n;
+  for (auto& x : ev) (void)hipEventDestroy(x);
+  return rc;
+}

@@ -1,0 +1,155 @@
+// Bandwidth-bound glue of the decoder and the NCHW<->NHWC boundary.
+//   upsample2x_add : F.interpolate(scale_factor=2, 'bilinear', align_corners=False) + torch.add
+//                    (models/cdan.py:137-138,145-146,153-154) in one pass
+//   layout kernels : fp32 NCHW (the nn.Module boundary) <-> internal NHWC
+#include "common.hpp"
+
+namespace mdie {
+
+constexpr int RS_THREADS = 256;
+
+// half-pixel source index exactly as ATen computes it: src = max(0, (dst + 0.5) * 0.5 - 0.5)
+__device__ __forceinline__ void src_index(int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
+  float src = ((float)dst + 0.5f) * 0.5f - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void upsample2x_add_kernel(int B, int H, int W, int C, const char* lo, int lo_stride,
+                                                                    const char* skip, int skip_stride, char* out, int out_stride) {
+  constexpr int VEC = Traits<T>::VEC;
+  const int CV = C / VEC;
+  const int Ho = 2 * H, Wo = 2 * W;
+  const size_t total = (size_t)B * Ho * Wo * CV;
+  for (size_t u = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * RS_THREADS) {
+    const int v = (int)(u % CV);
+    size_t p = u / CV;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int img = (int)(p / Ho);
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    src_index(oy, H, y0, y1, hy0, hy1);
+    src_index(ox, W, x0, x1, wx0, wx1);
+    const char* base = lo + (size_t)img * H * W * lo_stride * sizeof(T) + (size_t)v * 16;
+    auto at = [&](int y, int x) { return *reinterpret_cast<const uint4*>(base + ((size_t)y * W + x) * lo_stride * sizeof(T)); };
+    float a00[VEC], a01[VEC], a10[VEC], a11[VEC], sk[VEC], r[VEC];
+    Vec16<T>::unpack(at(y0, x0), a00);
+    Vec16<T>::unpack(at(y0, x1), a01);
+    Vec16<T>::unpack(at(y1, x0), a10);
+    Vec16<T>::unpack(at(y1, x1), a11);
+    const size_t op = ((size_t)img * Ho + oy) * Wo + ox;
+    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(skip + op * skip_stride * sizeof(T) + (size_t)v * 16), sk);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+      r[i] = hy0 * (wx0 * a00[i] + wx1 * a01[i]) + hy1 * (wx0 * a10[i] + wx1 * a11[i]) + sk[i];
+    *reinterpret_cast<uint4*>(out + op * out_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(r);
+  }
+}
+
+// fp32 NCHW [B,Creal,H,W] -> NHWC [B,H,W,Cst] (channels >= Creal zero filled)
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void nchw_to_nhwc_kernel(int B, int Creal, int Cst, int H, int W, const float* x, T* out) {
+  const size_t total = (size_t)B * H * W * Cst;
+  const size_t HW = (size_t)H * W;
+  for (size_t u = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * RS_THREADS) {
+    const int c = (int)(u % Cst);
+    const size_t p = u / Cst;
+    const size_t img = p / HW, hw = p % HW;
+    const float v = c < Creal ? x[(img * Creal + c) * HW + hw] : 0.f;
+    st(out + u, v);
+  }
+}
+
+// NHWC [B,H,W,Cst] -> fp32 NCHW [B,Creal,H,W]
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void nhwc_to_nchw_kernel(int B, int Creal, int Cst, int H, int W, const T* in, float* y) {
+  const size_t HW = (size_t)H * W;
+  const size_t total = (size_t)B * Creal * HW;
+  for (size_t u = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * RS_THREADS) {
+    const size_t hw = u % HW;
+    const size_t t = u / HW;
+    const int c = (int)(t % Creal);
+    const size_t img = t / Creal;
+    y[u] = ld(in + (img * HW + hw) * Cst + c);
+  }
+}
+
+static int grid_for(size_t total) {
+  size_t g = (total + RS_THREADS - 1) / RS_THREADS;
+  const size_t cap = 256 * 16;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+template <typename T>
+static int to_nhwc(int B, int Creal, int Cst, int H, int W, const float* x, void* out, hipStream_t s) {
+  TimedLaunch tl(MDIE_K_LAYOUT);
+  hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for((size_t)B * H * W * Cst)), dim3(RS_THREADS), 0, s, B, Creal, Cst, H, W, x,
+                     reinterpret_cast<T*>(out));
+  MDIE_LAUNCH_CHECK("nchw_to_nhwc");
+  return MDIE_OK;
+}
+template <typename T>
+static int to_nchw(int B, int Creal, int Cst, int H, int W, const void* in, float* y, hipStream_t s) {
+  TimedLaunch tl(MDIE_K_LAYOUT);
+  hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid_for((size_t)B * H * W * Creal)), dim3(RS_THREADS), 0, s, B, Creal, Cst, H, W,
+                     reinterpret_cast<const T*>(in), y);
+  MDIE_LAUNCH_CHECK("nhwc_to_nchw");
+  return MDIE_OK;
+}
+
+static int check_layout(const char* who, int dtype, int B, int C, int H, int W, const void* a, const void* b) {
+  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "%s: bad dtype %d", who, dtype);
+  MDIE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "%s: empty extent", who);
+  MDIE_REQUIRE(a && b, "%s: null pointer", who);
+  return MDIE_OK;
+}
+
+}  // namespace mdie
+
+using namespace mdie;
+
+extern "C" int mdie_upsample2x_add(int dtype, int B, int H, int W, int C, const void* lo, int lo_stride, const void* skip,
+                                   int skip_stride, void* out, int out_stride, void* stream) {
+  if (int e = check_layout("mdie_upsample2x_add", dtype, B, C, H, W, lo, out)) return e;
+  MDIE_REQUIRE(skip != nullptr, "mdie_upsample2x_add: null skip");
+  MDIE_REQUIRE(C % 16 == 0 && lo_stride % 16 == 0 && skip_stride % 16 == 0 && out_stride % 16 == 0,
+               "mdie_upsample2x_add: channels/strides must be multiples of 16");
+  MDIE_REQUIRE((((uintptr_t)lo | (uintptr_t)skip | (uintptr_t)out) & 15) == 0, "mdie_upsample2x_add: alignment");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t total = (size_t)B * 4 * H * W * (C / (dtype == MDIE_F32 ? 4 : 8));
+  TimedLaunch tl(MDIE_K_UPSAMPLE);
+  if (dtype == MDIE_F32)
+    hipLaunchKernelGGL((upsample2x_add_kernel<float>), dim3(grid_for(total)), dim3(RS_THREADS), 0, s, B, H, W, C, (const char*)lo, lo_stride,
+                       (const char*)skip, skip_stride, (char*)out, out_stride);
+  else
+    hipLaunchKernelGGL((upsample2x_add_kernel<mdie::bf16>), dim3(grid_for(total)), dim3(RS_THREADS), 0, s, B, H, W, C, (const char*)lo,
+                       lo_stride, (const char*)skip, skip_stride, (char*)out, out_stride);
+  MDIE_LAUNCH_CHECK("mdie_upsample2x_add");
+  return MDIE_OK;
+}
+
+extern "C" int mdie_nchw_to_nhwc(int dtype, int B, int C, int H, int W, const float* x, void* out, void* stream) {
+  if (int e = check_layout("mdie_nchw_to_nhwc", dtype, B, C, H, W, x, out)) return e;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dtype == MDIE_F32 ? to_nhwc<float>(B, C, C, H, W, x, out, s) : to_nhwc<mdie::bf16>(B, C, C, H, W, x, out, s);
+}
+extern "C" int mdie_nhwc_to_nchw(int dtype, int B, int C, int H, int W, const void* in, float* y, void* stream) {
+  if (int e = check_layout("mdie_nhwc_to_nchw", dtype, B, C, H, W, in, y)) return e;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dtype == MDIE_F32 ? to_nchw<float>(B, C, C, H, W, in, y, s) : to_nchw<mdie::bf16>(B, C, C, H, W, in, y, s);
+}
+extern "C" int mdie_nchw3_to_nhwc16(int dtype, int B, int H, int W, const float* x, void* out, void* stream) {
+  if (int e = check_layout("mdie_nchw3_to_nhwc16", dtype, B, 3, H, W, x, out)) return e;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dtype == MDIE_F32 ? to_nhwc<float>(B, 3, 16, H, W, x, out, s) : to_nhwc<mdie::bf16>(B, 3, 16, H, W, x, out, s);
+}
+extern "C" int mdie_nhwc16_to_nchw3(int dtype, int B, int H, int W, const void* in, float* y, void* stream) {
+  if (int e = check_layout("mdie_nhwc16_to_nchw3", dtype, B, 3, H, W, in, y)) return e;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dtype == MDIE_F32 ? to_nchw<float>(B, 3, 16, H, W, in, y, s) : to_nchw<mdie::bf16>(B, 3, 16, H, W, in, y, s);
+}

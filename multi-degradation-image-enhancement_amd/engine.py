@@ -1,0 +1,200 @@
+"""Host side of the HIP engine: checkpoint packing, workspace ownership, launches.
+
+PyTorch is used here only for device memory and streams; every numeric
+operation of the path runs in libmdie_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+DTYPES = {"fp32": L.F32, "f32": L.F32, "float32": L.F32, "bf16": L.BF16, "bfloat16": L.BF16}
+TORCH_DTYPE = {L.F32: torch.float32, L.BF16: torch.bfloat16}
+
+
+def dtype_id(name):
+    try:
+        return DTYPES[str(name).lower()]
+    except KeyError:
+        raise ValueError(f"unknown precision {name!r}; use 'fp32' or 'bf16'") from None
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _require_gpu(x, what):
+    if not x.is_cuda:
+        raise L.MdieError(f"{what}: tensor is on {x.device}; this path runs on the MI355X only (no CPU fallback)")
+
+
+def pack_checkpoint(state_dict, dtype):
+    """state_dict (any device, the reference's 236 keys) -> packed parameter blob (CPU uint8 tensor)."""
+    nbytes = L.lib.mdie_cdan_param_bytes(dtype)
+    blob = torch.zeros(nbytes, dtype=torch.uint8)
+    keep, entries = [], []
+    for name, value in state_dict.items():
+        if not torch.is_tensor(value) or not value.dtype.is_floating_point:
+            continue  # num_batches_tracked counters are not needed in eval
+        a = np.ascontiguousarray(value.detach().to("cpu", torch.float32).numpy())
+        keep.append(a)
+        entries.append(L.Tensor(name.encode(), a.ctypes.data, a.size))
+    arr = (L.Tensor * len(entries))(*entries)
+    L.check(L.lib.mdie_cdan_pack_params(dtype, arr, len(entries), blob.data_ptr(), nbytes), "mdie_cdan_pack_params")
+    return blob
+
+
+class CdanEngine:
+    """Eval-mode CDAN forward on one GPU.  One instance per (device, precision)."""
+
+    def __init__(self, device, precision="fp32"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.MdieError(f"CdanEngine needs a GPU device, got {self.device} (no CPU fallback)")
+        self.dtype = dtype_id(precision)
+        self.params = None
+        self._ws = None
+        self._ws_key = None
+
+    def load(self, state_dict):
+        self.params = pack_checkpoint(state_dict, self.dtype).to(self.device)
+        return self
+
+    def _workspace(self, B, H, W):
+        key = (B, H, W)
+        if self._ws_key != key:
+            n = L.lib.mdie_cdan_workspace_bytes(self.dtype, B, H, W)
+            if n == 0:
+                raise L.MdieError(f"unsupported input extent {B}x3x{H}x{W}: H and W must be multiples of 8")
+            self._ws = None  # release before re-allocating
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws_key = key
+        return self._ws
+
+    def forward(self, x, out=None, want_taps=False, profile=False):
+        """x: float32 NCHW [B,3,H,W] on this engine's GPU -> float32 NCHW [B,3,H,W]."""
+        if self.params is None:
+            raise L.MdieError("CdanEngine.forward before load(state_dict)")
+        _require_gpu(x, "CdanEngine.forward")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise L.MdieError(f"expected input [B,3,H,W], got {tuple(x.shape)}")
+        x = x.to(torch.float32).contiguous()
+        B, _, H, W = x.shape
+        ws = self._workspace(B, H, W)
+        y = out if out is not None else torch.empty_like(x)
+        d = L.CdanFwdDesc()
+        d.dtype, d.B, d.H, d.W = self.dtype, B, H, W
+        d.params, d.x, d.y = self.params.data_ptr(), x.data_ptr(), y.data_ptr()
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        taps = (L.Tap * len(L.TAP_NAMES))() if want_taps else None
+        if taps is not None:
+            d.taps = taps
+        if profile:
+            cap = 256
+            ms, kind, n = (C.c_float * cap)(), (C.c_int * cap)(), C.c_int(0)
+            d.launch_ms, d.launch_kind, d.max_launches, d.n_launches = ms, kind, cap, C.pointer(n)
+        with torch.cuda.device(self.device):
+            L.check(L.lib.mdie_cdan_forward(C.byref(d), _stream_ptr(self.device)), "mdie_cdan_forward")
+        extras = {}
+        if taps is not None:
+            extras["taps"] = {name: self._read_tap(taps[i], B) for i, name in enumerate(L.TAP_NAMES)}
+        if profile:
+            extras["launches"] = [(L.KERNEL_KINDS[kind[i]], float(ms[i])) for i in range(n.value)]
+        return (y, extras) if extras else y
+
+    def _read_tap(self, tap, B):
+        out = torch.empty(B, tap.channels, tap.H, tap.W, dtype=torch.float32, device=self.device)
+        L.check(L.lib.mdie_nhwc_to_nchw(self.dtype, B, tap.channels, tap.H, tap.W, C.c_void_p(tap.ptr), out.data_ptr(),
+                                        _stream_ptr(self.device)), "mdie_nhwc_to_nchw")
+        return out
+
+
+# ---- thin per-op wrappers (used by the parity tests; same entry points the plan calls) -----------------------------
+def to_nhwc(x, dtype):
+    _require_gpu(x, "to_nhwc")
+    B, Cc, H, W = x.shape
+    out = torch.empty(B, H, W, Cc, dtype=TORCH_DTYPE[dtype], device=x.device)
+    L.check(L.lib.mdie_nchw_to_nhwc(dtype, B, Cc, H, W, x.contiguous().data_ptr(), out.data_ptr(), _stream_ptr(x.device)),
+            "mdie_nchw_to_nhwc")
+    return out
+
+
+def to_nchw(x_nhwc, dtype):
+    B, H, W, Cc = x_nhwc.shape
+    out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x_nhwc.device)
+    L.check(L.lib.mdie_nhwc_to_nchw(dtype, B, Cc, H, W, x_nhwc.data_ptr(), out.data_ptr(), _stream_ptr(x_nhwc.device)),
+            "mdie_nhwc_to_nchw")
+    return out
+
+
+def pack_conv_weight(w, dtype, transposed=False, cout_stored=None, cin_stored=None, split=None, gap=0):
+    w = np.ascontiguousarray(w.detach().cpu().float().numpy())
+    ks = w.shape[2]
+    cout, cin = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    cout_stored = cout_stored or (cout + 15) // 16 * 16
+    cin_stored = cin_stored or (cin + 15) // 16 * 16
+    split = cin if split is None else split
+    n = L.lib.mdie_conv_weight_bytes(dtype, ks, cin_stored, cout_stored)
+    dst = torch.zeros(n, dtype=torch.uint8)
+    L.check(L.lib.mdie_pack_conv_weight(dtype, ks, int(transposed), w.ctypes.data, cout, cin, cout_stored, cin_stored,
+                                        split, gap, dst.data_ptr()), "mdie_pack_conv_weight")
+    return dst
+
+
+def conv_fwd(segments, weight_packed, post_scale, post_shift, *, dtype, ksize, cout, act=L.ACT_NONE, pool=False,
+             pre_scale=None, pre_shift=None, residual=None, out=None, out_view=None):
+    """segments: list of NHWC tensors [B,H,W,Ci] (Ci % 16 == 0).  Returns NHWC [B,Ho,Wo,cout]."""
+    x0 = segments[0]
+    B, H, W, _ = x0.shape
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    if out is None:
+        out = torch.empty(B, Ho, Wo, cout, dtype=TORCH_DTYPE[dtype], device=x0.device)
+    d = L.ConvDesc()
+    d.dtype, d.B, d.H, d.W, d.ksize = dtype, B, H, W, ksize
+    d.nseg = len(segments)
+    cin = 0
+    for i, s in enumerate(segments):
+        d.inp[i] = L.Seg(s.data_ptr(), s.shape[3], s.stride(2))
+        cin += s.shape[3]
+    d.cin, d.cout = cin, cout
+    d.pre_scale, d.pre_shift = _ptr(pre_scale), _ptr(pre_shift)
+    d.weight, d.post_scale, d.post_shift = _ptr(weight_packed), _ptr(post_scale), _ptr(post_shift)
+    d.act, d.pool = act, int(pool)
+    d.residual = _ptr(residual)
+    d.res_stride = residual.stride(2) if residual is not None else 0
+    target = out_view if out_view is not None else out
+    d.out, d.out_stride = target.data_ptr(), target.stride(2)
+    L.check(L.lib.mdie_conv_fwd(C.byref(d), _stream_ptr(x0.device)), "mdie_conv_fwd")
+    return out
+
+
+def cbam_fwd(x, w1, b1, w2, b2, w7, bn, *, dtype, mul=None, channel_only=False):
+    B, H, W, Cc = x.shape
+    out = torch.empty_like(x)
+    n = L.lib.mdie_cbam_workspace_bytes(B, H, W, Cc)
+    ws = torch.empty(n, dtype=torch.uint8, device=x.device)
+    d = L.CbamDesc()
+    d.dtype, d.B, d.H, d.W, d.C = dtype, B, H, W, Cc
+    d.x, d.x_stride = x.data_ptr(), x.stride(2)
+    d.w1, d.b1, d.w2, d.b2, d.w7, d.bn = (t.data_ptr() for t in (w1, b1, w2, b2, w7, bn))
+    d.mul = _ptr(mul)
+    d.mul_stride = mul.stride(2) if mul is not None else 0
+    d.out, d.out_stride = out.data_ptr(), out.stride(2)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), n
+    fn = L.lib.mdie_cbam_channel_only_fwd if channel_only else L.lib.mdie_cbam_fwd
+    L.check(fn(C.byref(d), _stream_ptr(x.device)), "mdie_cbam_fwd")
+    return out
+
+
+def upsample2x_add(lo, skip, *, dtype):
+    B, H, W, Cc = lo.shape
+    out = torch.empty_like(skip)
+    L.check(L.lib.mdie_upsample2x_add(dtype, B, H, W, Cc, lo.data_ptr(), lo.stride(2), skip.data_ptr(), skip.stride(2),
+                                      out.data_ptr(), out.stride(2), _stream_ptr(lo.device)), "mdie_upsample2x_add")
+    return out

@@ -1,0 +1,112 @@
+"""ctypes binding of libmdie_hip.so (the C ABI declared in include/mdie.h).
+
+There is deliberately no fallback: if the shared library is missing or does not
+export the ABI version this file was written for, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdie_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+MAX_SEG = 5
+ABI_VERSION = 1
+
+TAP_NAMES = ("skip0", "skip1", "skip2", "dense0", "dense1", "dense2", "enc", "bott", "dec1", "dec2", "dec3", "dec4")
+KERNEL_KINDS = ("layout", "conv3x3", "conv1x1", "cbam_pool", "cbam_gate", "cbam_chanpool", "cbam_spatial", "upsample_add")
+
+
+class MdieError(RuntimeError):
+    pass
+
+
+class Seg(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("channels", C.c_int), ("stride", C.c_int)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("ksize", C.c_int),
+                ("nseg", C.c_int), ("inp", Seg * MAX_SEG), ("cin", C.c_int), ("cout", C.c_int),
+                ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("weight", C.c_void_p),
+                ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int), ("pool", C.c_int),
+                ("residual", C.c_void_p), ("res_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int)]
+
+
+class CbamDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
+                ("x", C.c_void_p), ("x_stride", C.c_int),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("w7", C.c_void_p), ("bn", C.c_void_p),
+                ("mul", C.c_void_p), ("mul_stride", C.c_int),
+                ("out", C.c_void_p), ("out_stride", C.c_int),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+class Tap(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("channels", C.c_int), ("stride", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+
+
+class CdanFwdDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("params", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("taps", C.POINTER(Tap)),
+                ("launch_ms", C.POINTER(C.c_float)), ("launch_kind", C.POINTER(C.c_int)),
+                ("max_launches", C.c_int), ("n_launches", C.POINTER(C.c_int))]
+
+
+# name -> (restype, argtypes); must list every function include/mdie.h declares
+SIGNATURES = {
+    "mdie_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "mdie_conv_weight_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mdie_pack_conv_weight": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_void_p]),
+    "mdie_cbam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mdie_cbam_fwd": (C.c_int, [C.POINTER(CbamDesc), C.c_void_p]),
+    "mdie_cbam_channel_only_fwd": (C.c_int, [C.POINTER(CbamDesc), C.c_void_p]),
+    "mdie_upsample2x_add": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mdie_nchw3_to_nhwc16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdie_nhwc16_to_nchw3": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdie_nchw_to_nhwc": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdie_nhwc_to_nchw": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdie_cdan_param_bytes": (C.c_size_t, [C.c_int]),
+    "mdie_cdan_pack_params": (C.c_int, [C.c_int, C.POINTER(Tensor), C.c_int, C.c_void_p, C.c_size_t]),
+    "mdie_cdan_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mdie_cdan_forward": (C.c_int, [C.POINTER(CdanFwdDesc), C.c_void_p]),
+    "mdie_cdan_flops": (C.c_double, [C.c_int, C.c_int, C.c_int]),
+    "mdie_cdan_algorithmic_bytes": (C.c_double, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mdie_last_error": (C.c_char_p, []),
+    "mdie_abi_version": (C.c_int, []),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP engine has not been built. Run "
+            "`make -C multi-degradation-image-enhancement_amd/csrc` (or __graft_entry__.build()). "
+            "There is no CPU fallback for this path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.mdie_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} exports ABI {got}, binding expects {ABI_VERSION}: rebuild the library")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MdieError(f"{what} failed ({rc}): {lib.mdie_last_error().decode()}")

@@ -1,0 +1,139 @@
+"""`nn.Module` front ends that keep the reference's construction and call signatures
+(`CDAN()`, `CBAM(gate_channels, ...)`, `forward(x)`) and its checkpoint
+keys, while the arithmetic runs in libmdie_hip.so.
+
+The modules hold parameters only.  Parameter containers are generated from the
+layout table in `arch.py`, so `state_dict()` / `load_state_dict()` interoperate with
+checkpoints written by the reference (`torch.save(network.state_dict())`,
+/root/reference/models/base.py:52-55) in both directions.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from . import arch
+from . import engine as E
+from . import lib as L
+
+
+class _Node(nn.Module):
+    """Bare container: a named position in the checkpoint key tree."""
+
+
+def _attach(root, spec):
+    fan_in = 1
+    for name, (shape, kind) in spec.items():
+        *path, leaf = name.split(".")
+        node = root
+        for part in path:
+            if part not in node._modules:
+                node.add_module(part, _Node())
+            node = node._modules[part]
+        if kind == "counter":
+            node.register_buffer(leaf, torch.tensor(0, dtype=torch.long))
+        elif kind == "buffer":
+            node.register_buffer(leaf, torch.ones(shape) if leaf == "running_var" else torch.zeros(shape))
+        else:
+            is_norm = (name.rsplit(".", 1)[0] + ".running_mean") in spec
+            t = torch.empty(shape)
+            if is_norm:
+                t.fill_(1.0 if leaf == "weight" else 0.0)
+            else:
+                # torch's default for Conv2d / ConvTranspose2d / Linear: U(-1/sqrt(fan_in), +1/sqrt(fan_in))
+                # with fan_in = size(1) * receptive field, for weight and bias alike
+                if leaf == "weight":
+                    fan_in = shape[1] * (shape[2] * shape[3] if len(shape) == 4 else 1)
+                bound = 1.0 / math.sqrt(fan_in)
+                t.uniform_(-bound, bound)
+            node.register_parameter(leaf, nn.Parameter(t))
+
+
+def _fingerprint(module):
+    v = 0
+    for t in module.parameters():
+        v += t._version
+    for t in module.buffers():
+        v += t._version
+    return v
+
+
+class CDAN(nn.Module):
+    """Drop-in for `models.cdan.CDAN` (/root/reference/models/cdan.py:164-176).
+
+    `precision` ("fp32" default, "bf16") can also be set through the environment
+    variable MDIE_PRECISION so that the reference's config files stay unchanged.
+    """
+
+    def __init__(self, precision=None):
+        super().__init__()
+        _attach(self, arch.cdan_param_spec())
+        self.precision = precision or os.environ.get("MDIE_PRECISION", "fp32")
+        self._engines = {}
+        self._packed = {}
+
+    def _engine(self, device):
+        key = (str(device), self.precision)
+        eng = self._engines.get(key)
+        fp = (_fingerprint(self), id(next(self.parameters())))
+        if eng is None:
+            eng = self._engines[key] = E.CdanEngine(device, self.precision)
+            self._packed[key] = None
+        if self._packed[key] != fp:
+            eng.load(self.state_dict())
+            self._packed[key] = fp
+        return eng
+
+    def forward(self, x):
+        if self.training or torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x.requires_grad:
+            pass
+        if self.training:
+            raise NotImplementedError(
+                "CDAN.forward in training mode: the MI355X engine currently implements the eval path "
+                "(network.eval(), models/model.py:232); call .eval() first")
+        if not x.is_cuda:
+            raise L.MdieError(f"CDAN.forward: input is on {x.device}; this engine runs on the GPU only (no CPU fallback)")
+        return self._engine(x.device).forward(x)
+
+    def forward_with_taps(self, x):
+        y, extras = self._engine(x.device).forward(x, want_taps=True)
+        return y, extras["taps"]
+
+
+class CBAM(nn.Module):
+    """Drop-in for `models.cbam.CBAM` (/root/reference/models/cbam.py:84-95), eval mode."""
+
+    def __init__(self, gate_channels, reduction_ratio=16, pool_types=("avg", "max"), no_spatial=False, precision=None):
+        super().__init__()
+        if reduction_ratio != arch.REDUCTION or tuple(pool_types) != ("avg", "max"):
+            raise NotImplementedError("the HIP CBAM implements reduction_ratio=16 with pool_types ['avg','max'] "
+                                      "(the only configuration the CDAN path instantiates, cdan.py:104-112,168)")
+        spec = arch.cbam_param_spec(gate_channels)
+        if no_spatial:
+            spec = type(spec)((k, v) for k, v in spec.items() if k.startswith("ChannelGate"))
+        _attach(self, spec)
+        self.gate_channels, self.no_spatial = gate_channels, no_spatial
+        self.precision = precision or os.environ.get("MDIE_PRECISION", "fp32")
+
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError("CBAM.forward in training mode is not built yet; call .eval()")
+        if not x.is_cuda:
+            raise L.MdieError(f"CBAM.forward: input is on {x.device}; GPU only (no CPU fallback)")
+        dt = E.dtype_id(self.precision)
+        sd = self.state_dict()
+        dev = x.device
+        f = lambda k: sd[k].to(dev, torch.float32).contiguous()
+        if self.no_spatial:
+            w7 = torch.zeros(98, device=dev)
+            bn = torch.tensor([1.0, 0.0], device=dev)
+        else:
+            w7 = f("SpatialGate.spatial.conv.weight").reshape(-1)
+            p = "SpatialGate.spatial.bn."
+            s = f(p + "weight") / torch.sqrt(f(p + "running_var") + 1e-5)
+            bn = torch.cat((s, f(p + "bias") - f(p + "running_mean") * s))
+        y = E.cbam_fwd(E.to_nhwc(x.float(), dt), f("ChannelGate.mlp.1.weight"), f("ChannelGate.mlp.1.bias"),
+                       f("ChannelGate.mlp.3.weight"), f("ChannelGate.mlp.3.bias"), w7, bn, dtype=dt,
+                       channel_only=self.no_spatial)
+        return E.to_nchw(y, dt)
