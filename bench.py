@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the CDAN forward (config/low_light.json network) at
+256x256, bf16 storage / fp32 accumulate, batch 32 per GPU, inputs resident in HBM.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one forward pass of the hot path over one synthetic batch.  Inference shards by
+batch with no data-path collective, so N ranks run N independent batches
+("weak" scaling); the only communication is the timing barrier / max-over-ranks.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      algorithmic HBM bytes of the forward / measured kernel time vs 8 TB/s
+  cpu_baseline  the CPU oracle (port of the reference path) timed on this host's cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3}
+
+
+def kind_model(B, H, W, esz):
+    """Split of the fused-schedule algorithmic model per kernel kind:
+    kind -> (bytes, flops).  Sums to mdie_cdan_algorithmic_bytes / mdie_cdan_flops."""
+    P = float(H * W)
+    by = {k: [0.0, 0.0] for k in ("conv3x3", "conv1x1", "cbam", "upsample_add", "layout")}
+
+    def conv(kind, cin, cout, pin, pout, k):
+        by[kind][0] += (cin * pin + cout * pout) * esz
+        by[kind][1] += 2.0 * cin * cout * k * k * pin
+
+    def dense(c, p):
+        for i in range(4):
+            conv("conv3x3", c + 16 * i, 16, p, p, 3)
+        conv("conv1x1", c + 64, c, p, p, 1)
+
+    def cbam(c, p, mul):
+        by["cbam"][0] += (3 * c * p + (c * p if mul else 0) + 4 * p) * esz
+        by["cbam"][1] += 4.0 * 2 * c * (c // 16)  # two MLP layers on two pooled vectors (+ 7x7: 2*98*p)
+        by["cbam"][1] += 2.0 * 98 * p
+
+    def up(c, plo):
+        by["upsample_add"][0] += 9 * c * plo * esz
+
+    conv("conv3x3", 3, 64, P, P / 4, 3); dense(64, P / 4)
+    conv("conv3x3", 64, 128, P / 4, P / 16, 3); dense(128, P / 16)
+    conv("conv3x3", 128, 256, P / 16, P / 64, 3); dense(256, P / 64)
+    conv("conv3x3", 256, 512, P / 64, P / 64, 3)
+    cbam(512, P / 64, False)
+    conv("conv3x3", 512, 256, P / 64, P / 64, 3); by["conv3x3"][0] += 256 * P / 64 * esz; cbam(256, P / 64, True)
+    conv("conv3x3", 256, 128, P / 64, P / 64, 3); up(128, P / 64); cbam(128, P / 16, True)
+    conv("conv3x3", 128, 64, P / 16, P / 16, 3); up(64, P / 16); cbam(64, P / 4, True)
+    conv("conv3x3", 64, 3, P / 4, P / 4, 3); up(3, P / 4)
+    dense(3, P)
+    return {k: (v[0] * B, v[1] * B) for k, v in by.items()}
+
+
+def cpu_baseline(sd, x_cpu, seconds_budget=20.0):
+    """The oracle (a port of the reference's PyTorch CPU path) on this host's cores."""
+    from oracle import cdan_oracle as O
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # a one-GPU box owns a 16-core share of its host; more threads than that only oversubscribe
+    cores = int(os.environ.get("MDIE_CPU_THREADS", min(avail, 16)))
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ref = O.cdan_forward(sd, x_cpu)          # warm-up (also the parity reference)
+        warm = time.perf_counter() - t0
+        reps = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            O.cdan_forward(sd, x_cpu)
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return ref, {"value": round(x_cpu.shape[0] / med, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+                 "sample": f"{reps} timed fp32 forwards of {x_cpu.shape[0]}x3x{x_cpu.shape[2]}x{x_cpu.shape[3]} "
+                           f"(same synthetic low-light images, first {x_cpu.shape[0]} of the GPU batch), median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="enqueue launches eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mdie_amd import lib as L
+    from models.cdan import CDAN
+    from oracle import params as P  # synthetic-input recipe + seeded checkpoint (test infrastructure)
+
+    B, S = args.batch, args.size
+    sd = P.make_state_dict(42)
+    net = CDAN(precision=args.precision)
+    net.load_state_dict(sd, strict=True)
+    net = net.eval().to(dev)
+    x_cpu, clean_cpu = P.lowlight_batch(1000 + rank, B, S, S)
+    x = x_cpu.to(dev)
+    y = torch.empty_like(x)
+    eng = net._engine(dev)
+
+    def step():
+        eng.forward(x, out=y)
+
+    graph = None
+    with torch.no_grad():
+        step()
+        torch.cuda.synchronize(dev)
+        if not args.no_graph:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+        run = graph.replay if graph is not None else step
+
+        for _ in range(args.warmup):
+            run()
+
+        def fence():
+            torch.cuda.synchronize(dev)
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # ---- roofline: per-launch HIP events on the launch stream (instrumented mode, eager) ------------------
+        prof = {}
+        if rank == 0:
+            reps = 5
+            for _ in range(reps):
+                _, extras = eng.forward(x, out=y, profile=True)
+                for kind, ms in extras["launches"]:
+                    k = "cbam" if kind.startswith("cbam") else kind
+                    prof.setdefault(k, [0, 0.0])
+                    prof[k][0] += 1
+                    prof[k][1] += ms
+            for k in prof:
+                prof[k] = (prof[k][0] // reps, prof[k][1] / reps)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    esz = 2 if args.precision == "bf16" else 4
+    alg_bytes = L.lib.mdie_cdan_algorithmic_bytes(B, S, S, esz)
+    flops = L.lib.mdie_cdan_flops(B, S, S)
+    model = kind_model(B, S, S, esz)
+    kernel_ms = sum(v[1] for v in prof.values())
+    per_kernel = {}
+    for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+        b, f = model.get(k, (0.0, 0.0))
+        per_kernel[k] = {"launches": n, "ms": round(ms, 4), "alg_GB": round(b / 1e9, 4), "GBps": round(b / ms / 1e6, 1) if ms else None,
+                         "TFLOPs": round(f / ms / 1e9, 1) if ms and f else None}
+    dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+                "kernel": "cdan_forward (all launches of one step)", "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_step": alg_bytes, "flops_per_step": flops,
+                "mfma_frac": round(flops / (kernel_ms * 1e-3) / 1e12 / MFMA_PEAK_TF[args.precision], 4) if kernel_ms else None,
+                "dominant_kernel": dom, "per_kernel": per_kernel}
+
+    out = {"metric": "images/sec @256x256 bf16 (low_light CDAN)", "value": round(value, 2), "unit": "images/sec",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+           "config": {"workload": f"config/low_light.json CDAN forward (eval), {S}x{S}, batch {B}/GPU, {args.precision} storage + fp32 accumulate, "
+                                  f"seeded random-init weights, synthetic low-light images resident in HBM",
+                      "global_batch": B * world, "parallelism": f"batch-parallel x{world}, no collective",
+                      "launch": "eager" if graph is None else "hipGraph replay"},
+           "roofline": roofline}
+
+    if not args.no_cpu:
+        nb = min(args.cpu_batch, B)
+        ref, cb = cpu_baseline(sd, x_cpu[:nb])
+        yc = y[:nb].float().cpu()
+        err = ((yc - ref).abs().max() / ref.abs().max()).item()
+        from oracle.cdan_oracle import psnr
+        cb["parity"] = {"max_abs_err_over_max": round(err, 6), "psnr_gpu_vs_cpu_db": round(psnr(yc, ref), 2),
+                        "psnr_gpu_vs_clean_db": round(psnr(yc, clean_cpu[:nb]), 2),
+                        "psnr_cpu_vs_clean_db": round(psnr(ref, clean_cpu[:nb]), 2)}
+        out["cpu_baseline"] = cb
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
