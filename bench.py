@@ -88,6 +88,20 @@ def cpu_baseline(sd, x_cpu, seconds_budget=20.0):
                            f"(same synthetic low-light images, first {x_cpu.shape[0]} of the GPU batch), median"}
 
 
+def max_over_ranks(elapsed, dist, device):
+    """Whole-job time of a step loop = the slowest rank's (the contract's max over ranks)."""
+    if dist is None:
+        return elapsed
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def rank_inputs(P, rank, B, S):
+    """Every rank owns its own batch (weak scaling, no data-path collective)."""
+    return P.lowlight_batch(1000 + rank, B, S, S)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,7 +139,7 @@ def main():
     net = CDAN(precision=args.precision)
     net.load_state_dict(sd, strict=True)
     net = net.eval().to(dev)
-    x_cpu, clean_cpu = P.lowlight_batch(1000 + rank, B, S, S)
+    x_cpu, clean_cpu = rank_inputs(P, rank, B, S)
     x = x_cpu.to(dev)
     y = torch.empty_like(x)
     eng = net._engine(dev)
@@ -163,10 +177,7 @@ def main():
             run()
         fence()
         elapsed = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed, dist, dev)
 
         # ---- roofline: per-launch HIP events on the launch stream (instrumented mode, eager) ------------------
         prof = {}

@@ -1,0 +1,136 @@
+"""CPU-side checks of the C ABI: the library loads without a GPU, exports every function
+include/mdie.h declares, validates arguments before touching the device, and its host-side
+packers produce the documented layouts."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import mdie_amd.engine as E
+import mdie_amd.lib as L
+from oracle import params as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    text = open(os.path.join(ROOT, "include", "mdie.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(mdie_[a-z0-9_]+)\s*\(", text))
+    assert declared, "no declarations parsed"
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    raw = C.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert L.lib.mdie_abi_version() == L.ABI_VERSION
+
+
+def bf16_bits(a):
+    u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_pack_conv_weight_layout(dtype, transposed):
+    rng = np.random.default_rng(0)
+    cout, cin, ks = 19, 35, 3          # final_dense-like: 3 + 2*16 real input channels, base stored in 16
+    split, gap = 3, 13
+    cin_st, cout_st = 48, 32
+    w = rng.standard_normal((cin, cout, ks, ks) if transposed else (cout, cin, ks, ks)).astype(np.float32)
+    packed = E.pack_conv_weight(torch.from_numpy(w), dtype, transposed=transposed, cout_stored=cout_st,
+                                cin_stored=cin_st, split=split, gap=gap)
+    kc = 16 if dtype == L.F32 else 32
+    nchunk = -(-cin_st // kc)
+    assert packed.numel() == nchunk * 9 * cout_st * 64 == L.lib.mdie_conv_weight_bytes(dtype, ks, cin_st, cout_st)
+    expect = np.zeros((nchunk, 9, cout_st, kc), np.float32)
+    for o in range(cout):
+        for c in range(cin):
+            cs = c + (gap if c >= split else 0)
+            for kh in range(3):
+                for kw in range(3):
+                    v = w[c, o, 2 - kh, 2 - kw] if transposed else w[o, c, kh, kw]
+                    expect[cs // kc, kh * 3 + kw, o, cs % kc] = v
+    if dtype == L.F32:
+        got = packed.numpy().view(np.float32).reshape(expect.shape)
+        assert np.array_equal(got, expect)
+    else:
+        got = packed.numpy().view(np.uint16).reshape(expect.shape)
+        assert np.array_equal(got, bf16_bits(expect))
+
+
+def test_pack_params_roundtrip_and_errors():
+    sd = P.make_state_dict(42)
+    for dt in (L.F32, L.BF16):
+        blob = E.pack_checkpoint(sd, dt)
+        assert blob.numel() == L.lib.mdie_cdan_param_bytes(dt)
+        assert torch.equal(blob, E.pack_checkpoint(sd, dt))
+    broken = dict(sd)
+    del broken["decoder.cbam2.ChannelGate.mlp.3.bias"]
+    with pytest.raises(L.MdieError, match="decoder.cbam2.ChannelGate.mlp.3.bias"):
+        E.pack_checkpoint(broken, L.F32)
+    wrong = dict(sd)
+    wrong["encoder.conv2.conv.weight"] = torch.zeros(128, 64, 3, 2)
+    with pytest.raises(L.MdieError, match="encoder.conv2.conv.weight"):
+        E.pack_checkpoint(wrong, L.BF16)
+
+
+def test_folded_batchnorm_in_blob():
+    """encoder.conv1 is the first blob entry: packed weight, then post_scale, post_shift."""
+    sd = P.make_state_dict(42)
+    blob = E.pack_checkpoint(sd, L.F32).numpy()
+    wbytes = L.lib.mdie_conv_weight_bytes(L.F32, 3, 16, 64)
+    scale = blob[wbytes:wbytes + 256].view(np.float32)
+    shift = blob[wbytes + 256:wbytes + 512].view(np.float32)
+    g, b = sd["encoder.conv1.bn.weight"].double(), sd["encoder.conv1.bn.bias"].double()
+    m, v = sd["encoder.conv1.bn.running_mean"].double(), sd["encoder.conv1.bn.running_var"].double()
+    s = g / torch.sqrt(v + 1e-5)
+    t = (sd["encoder.conv1.conv.bias"].double() - m) * s + b
+    assert np.allclose(scale, s.numpy(), rtol=1e-6)
+    assert np.allclose(shift, t.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_sizes_and_work_model():
+    assert L.lib.mdie_cdan_workspace_bytes(L.BF16, 1, 36, 32) == 0          # H not a multiple of 8
+    assert L.lib.mdie_cdan_workspace_bytes(L.BF16, 0, 32, 32) == 0
+    a = L.lib.mdie_cdan_workspace_bytes(L.BF16, 2, 64, 64)
+    b = L.lib.mdie_cdan_workspace_bytes(L.F32, 2, 64, 64)
+    assert 0 < a < b
+    # SURVEY.md section 6/8d constants
+    assert L.lib.mdie_cdan_flops(1, 256, 256) == pytest.approx(16570124288.0)
+    act = L.lib.mdie_cdan_algorithmic_bytes(1, 256, 256, 2) - 2 * 3585663
+    assert act / 2 == pytest.approx(52.39e6, rel=1e-3)
+
+
+def test_argument_validation_needs_no_gpu():
+    d = L.CdanFwdDesc()
+    d.dtype, d.B, d.H, d.W = L.BF16, 1, 36, 32
+    assert L.lib.mdie_cdan_forward(C.byref(d), None) == -1
+    assert b"multiples of 8" in L.lib.mdie_last_error()
+    c = L.ConvDesc()
+    c.dtype, c.B, c.H, c.W, c.ksize, c.nseg = 7, 1, 8, 8, 3, 1
+    assert L.lib.mdie_conv_fwd(C.byref(c), None) == -1
+    assert b"dtype" in L.lib.mdie_last_error()
+    assert L.lib.mdie_upsample2x_add(L.F32, 1, 4, 4, 12, 16, 16, 16, 16, 16, 16, None) == -1
+    k = L.CbamDesc()
+    k.dtype, k.B, k.H, k.W, k.C = L.F32, 1, 4, 4, 48
+    assert L.lib.mdie_cbam_fwd(C.byref(k), None) == -1
+    assert b"power of two" in L.lib.mdie_last_error()
+
+
+def test_module_front_end_contract():
+    from models.cbam import CBAM
+    from models.cdan import CDAN
+    m = CDAN()
+    assert len(m.state_dict()) == 236
+    assert sum(p.numel() for p in m.parameters()) == 3585663
+    m.load_state_dict(P.make_state_dict(7), strict=True)
+    with pytest.raises(L.MdieError, match="no CPU fallback"):
+        m.eval()(torch.rand(1, 3, 32, 32))
+    c = CBAM(64)
+    assert list(c.state_dict())[0] == "ChannelGate.mlp.1.weight"
+    with pytest.raises(NotImplementedError):
+        CBAM(64, reduction_ratio=8)

@@ -1,0 +1,41 @@
+"""world_size-2 rehearsal (gloo, CPU) of bench.py's multi-rank logic: ranks own different
+batches (no data-path collective) and the reported time is the max over ranks."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from oracle import params as P
+    t = bench.max_over_ranks(1.0 + rank, dist, "cpu")
+    x, _ = bench.rank_inputs(P, rank, 2, 16)
+    sums = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(sums, x.double().sum().reshape(1))
+    q.put((rank, t, [float(s) for s in sums]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_timing_and_sharding():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, t, sums in res:
+        assert t == 2.0                      # max over ranks, identical on every rank
+        assert sums[0] != sums[1]            # ranks hold different batches
