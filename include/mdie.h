@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 1
+#define MDIE_ABI_VERSION 2
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -130,6 +130,35 @@ int mdie_cbam_fwd(const mdie_cbam_desc* d, void* stream);
 /* the same pipeline stopped after pass 2 + channel scaling only (for stage-wise parity tests) */
 int mdie_cbam_channel_only_fwd(const mdie_cbam_desc* d, void* stream);
 
+/* One named fp32 tensor of a checkpoint (host memory). */
+typedef struct {
+  const char* name;   /* state_dict key, e.g. "encoder.conv1.conv.weight" */
+  const float* data;  /* host pointer, fp32, PyTorch layout (int64 counters may be omitted) */
+  int64_t numel;
+} mdie_tensor;
+
+/* ---------------------------------------------------------------------------------
+ * Fused decoder tail:  y = sigmoid( DenseBlock(3,3,16,4)( bilinear_x2(lo) + x ) )
+ * = F.interpolate + torch.add (models/cdan.py:153-154), decoder.final_dense (:119,156;
+ * layer recipes :41-53) and nn.Sigmoid (:157) in one kernel; the four growth maps stay in LDS.
+ *   lo : NHWC [B,H/2,W/2,lo_stride] (channels 0..2 used), or NULL for a plain DenseBlock(3,..)
+ *   x,y: fp32 NCHW [B,3,H,W]
+ *   params: device copy of mdie_tail_pack_params(prefix = the DenseBlock's state_dict prefix,
+ *           e.g. "decoder.final_dense"; "" for a bare block)
+ * --------------------------------------------------------------------------------- */
+typedef struct {
+  int dtype;
+  int B, H, W;
+  const void* lo;  int lo_stride;
+  const float* x;
+  float* y;
+  const void* params;
+} mdie_tail_desc;
+
+size_t mdie_tail_param_bytes(int dtype);
+int mdie_tail_pack_params(int dtype, const mdie_tensor* tensors, int n, const char* prefix, void* dst, size_t dst_bytes);
+int mdie_tail_fwd(const mdie_tail_desc* d, void* stream);
+
 /* out[B,2H,2W,C] = bilinear_x2(lo[B,H,W,C]) + skip  (F.interpolate(scale_factor=2, 'bilinear',
  * align_corners=False) + torch.add, models/cdan.py:137-138,145-146,153-154) */
 int mdie_upsample2x_add(int dtype, int B, int H, int W, int C, const void* lo, int lo_stride,
@@ -149,12 +178,6 @@ int mdie_nhwc_to_nchw(int dtype, int B, int C, int H, int W, const void* in, flo
  *   blob   = mdie_cdan_pack_params(...)  host side, once per checkpoint
  *   y      = mdie_cdan_forward(blob_dev, x, ...)  one call enqueues every kernel
  * --------------------------------------------------------------------------------- */
-typedef struct {
-  const char* name;   /* state_dict key, e.g. "encoder.conv1.conv.weight" */
-  const float* data;  /* host pointer, fp32, PyTorch layout (int64 counters may be omitted) */
-  int64_t numel;
-} mdie_tensor;
-
 size_t mdie_cdan_param_bytes(int dtype);
 /* Packs the reference checkpoint (the 236-entry state_dict written by models/base.py:52-55)
  * into one relocatable blob: packed conv weights, folded BN scale/shift vectors, CBAM MLPs. */
@@ -184,11 +207,14 @@ typedef struct {
   float* y;
   void* workspace;  size_t workspace_bytes;
   mdie_tap* taps;
+  int flags;                /* MDIE_FWD_* bits */
   float* launch_ms; int* launch_kind; int max_launches; int* n_launches;
 } mdie_cdan_fwd_desc;
 
+enum { MDIE_FWD_UNFUSED_TAIL = 1 /* run upsample + final_dense + sigmoid as separate launches */ };
+
 enum { MDIE_K_LAYOUT = 0, MDIE_K_CONV3 = 1, MDIE_K_CONV1 = 2, MDIE_K_CBAM_POOL = 3, MDIE_K_CBAM_GATE = 4,
-       MDIE_K_CBAM_CHANPOOL = 5, MDIE_K_CBAM_SPATIAL = 6, MDIE_K_UPSAMPLE = 7, MDIE_K_COUNT = 8 };
+       MDIE_K_CBAM_CHANPOOL = 5, MDIE_K_CBAM_SPATIAL = 6, MDIE_K_UPSAMPLE = 7, MDIE_K_TAIL = 8, MDIE_K_COUNT = 9 };
 
 int mdie_cdan_forward(const mdie_cdan_fwd_desc* d, void* stream);
 

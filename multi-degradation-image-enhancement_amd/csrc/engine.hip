@@ -91,6 +91,7 @@ struct CbamBlob { size_t w1, b1, w2, b2, w7, bn; };
 struct BlobLayout {
   ConvBlob conv[CV_COUNT];
   CbamBlob cbam[CB_COUNT];
+  size_t tail;   // mdie_tail_pack_params("decoder.final_dense")
   size_t total;
 };
 
@@ -121,6 +122,7 @@ static BlobLayout blob_layout(int dtype) {
     L.cbam[i].w7 = take(98 * sizeof(float));
     L.cbam[i].bn = take(2 * sizeof(float));
   }
+  L.tail = take(mdie_tail_param_bytes(dtype));
   L.total = off;
   return L;
 }
@@ -302,7 +304,7 @@ extern "C" int mdie_cdan_pack_params(int dtype, const mdie_tensor* tensors, int 
     float bn[2] = {sc[0], sh[0]};
     memcpy(blob + L.cbam[i].bn, bn, 8);
   }
-  return MDIE_OK;
+  return mdie_tail_pack_params(dtype, tensors, n, "decoder.final_dense", blob + L.tail, mdie_tail_param_bytes(dtype));
 }
 
 extern "C" size_t mdie_cdan_workspace_bytes(int dtype, int B, int H, int W) {
@@ -438,9 +440,17 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   RUN(run_up(c, h2, w2, P.t3lo, P.o[0], P.t3));
   RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3));
   RUN(run_conv(c, CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
-  RUN(run_up(c, h1, w1, P.t4lo, P.x16, P.t4));                                      // bilinear x2 + x
-  RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID));                // final_dense + sigmoid
-  RUN(mdie_nhwc16_to_nchw3(d->dtype, B, H, W, c.ws + P.out16.off, d->y, stream));
+  if (d->flags & MDIE_FWD_UNFUSED_TAIL) {
+    RUN(run_up(c, h1, w1, P.t4lo, P.x16, P.t4));                                    // bilinear x2 + x
+    RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID));              // final_dense + sigmoid
+    RUN(mdie_nhwc16_to_nchw3(d->dtype, B, H, W, c.ws + P.out16.off, d->y, stream));
+  } else {
+    mdie_tail_desc t{};
+    t.dtype = d->dtype; t.B = B; t.H = H; t.W = W;
+    t.lo = c.ws + P.t4lo.off; t.lo_stride = P.t4lo.C;
+    t.x = d->x; t.y = d->y; t.params = c.params + c.L.tail;
+    RUN(mdie_tail_fwd(&t, stream));                                                 // all of the above, one launch
+  }
 #undef RUN
   if (d->taps) {
     auto tap = [&](int id, const Buf& b, int h, int w) { d->taps[id] = mdie_tap{c.ws + b.off, b.C, b.C, h, w}; };
@@ -449,6 +459,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     tap(MDIE_TAP_ENC, P.e, h3, w3); tap(MDIE_TAP_BOTT, P.bott, h3, w3);
     tap(MDIE_TAP_DEC1, P.u1, h3, w3); tap(MDIE_TAP_DEC2, P.u2, h2, w2); tap(MDIE_TAP_DEC3, P.u3, h1, w1);
     tap(MDIE_TAP_DEC4, P.t4, H, W);
+    if (!(d->flags & MDIE_FWD_UNFUSED_TAIL)) d->taps[MDIE_TAP_DEC4].ptr = nullptr;  // never materialised when fused
   }
   return MDIE_OK;
 }

@@ -77,7 +77,7 @@ class CdanEngine:
             self._ws_key = key
         return self._ws
 
-    def forward(self, x, out=None, want_taps=False, profile=False):
+    def forward(self, x, out=None, want_taps=False, profile=False, unfused_tail=False):
         """x: float32 NCHW [B,3,H,W] on this engine's GPU -> float32 NCHW [B,3,H,W]."""
         if self.params is None:
             raise L.MdieError("CdanEngine.forward before load(state_dict)")
@@ -92,6 +92,7 @@ class CdanEngine:
         d.dtype, d.B, d.H, d.W = self.dtype, B, H, W
         d.params, d.x, d.y = self.params.data_ptr(), x.data_ptr(), y.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        d.flags = L.FWD_UNFUSED_TAIL if unfused_tail else 0
         taps = (L.Tap * len(L.TAP_NAMES))() if want_taps else None
         if taps is not None:
             d.taps = taps
@@ -103,7 +104,7 @@ class CdanEngine:
             L.check(L.lib.mdie_cdan_forward(C.byref(d), _stream_ptr(self.device)), "mdie_cdan_forward")
         extras = {}
         if taps is not None:
-            extras["taps"] = {name: self._read_tap(taps[i], B) for i, name in enumerate(L.TAP_NAMES)}
+            extras["taps"] = {name: self._read_tap(taps[i], B) for i, name in enumerate(L.TAP_NAMES) if taps[i].ptr}
         if profile:
             extras["launches"] = [(L.KERNEL_KINDS[kind[i]], float(ms[i])) for i in range(n.value)]
         return (y, extras) if extras else y
@@ -198,3 +199,38 @@ def upsample2x_add(lo, skip, *, dtype):
     L.check(L.lib.mdie_upsample2x_add(dtype, B, H, W, Cc, lo.data_ptr(), lo.stride(2), skip.data_ptr(), skip.stride(2),
                                       out.data_ptr(), out.stride(2), _stream_ptr(lo.device)), "mdie_upsample2x_add")
     return out
+
+
+def _tensor_array(state_dict):
+    keep, entries = [], []
+    for name, value in state_dict.items():
+        if not torch.is_tensor(value) or not value.dtype.is_floating_point:
+            continue
+        a = np.ascontiguousarray(value.detach().to("cpu", torch.float32).numpy())
+        keep.append(a)
+        entries.append(L.Tensor(name.encode(), a.ctypes.data, a.size))
+    return (L.Tensor * len(entries))(*entries), len(entries), keep
+
+
+def pack_tail(state_dict, dtype, prefix=""):
+    """DenseBlock(3,3,16,4) checkpoint entries under `prefix` -> packed blob for mdie_tail_fwd (CPU uint8)."""
+    n = L.lib.mdie_tail_param_bytes(dtype)
+    blob = torch.zeros(n, dtype=torch.uint8)
+    arr, cnt, keep = _tensor_array(state_dict)
+    L.check(L.lib.mdie_tail_pack_params(dtype, arr, cnt, prefix.encode(), blob.data_ptr(), n), "mdie_tail_pack_params")
+    return blob
+
+
+def tail_fwd(x, params, *, dtype, lo=None):
+    """x: fp32 NCHW [B,3,H,W]; lo: NHWC [B,H/2,W/2,C>=3] or None; -> sigmoid(DenseBlock(up2(lo)+x)) fp32 NCHW."""
+    _require_gpu(x, "tail_fwd")
+    x = x.contiguous()
+    B, _, H, W = x.shape
+    y = torch.empty_like(x)
+    d = L.TailDesc()
+    d.dtype, d.B, d.H, d.W = dtype, B, H, W
+    d.lo = _ptr(lo)
+    d.lo_stride = lo.stride(2) if lo is not None else 0
+    d.x, d.y, d.params = x.data_ptr(), y.data_ptr(), params.data_ptr()
+    L.check(L.lib.mdie_tail_fwd(C.byref(d), _stream_ptr(x.device)), "mdie_tail_fwd")
+    return y

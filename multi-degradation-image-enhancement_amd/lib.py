@@ -12,10 +12,11 @@ LIB_PATH = os.path.join(_HERE, "libmdie_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 1
+ABI_VERSION = 2
+FWD_UNFUSED_TAIL = 1
 
 TAP_NAMES = ("skip0", "skip1", "skip2", "dense0", "dense1", "dense2", "enc", "bott", "dec1", "dec2", "dec3", "dec4")
-KERNEL_KINDS = ("layout", "conv3x3", "conv1x1", "cbam_pool", "cbam_gate", "cbam_chanpool", "cbam_spatial", "upsample_add")
+KERNEL_KINDS = ("layout", "conv3x3", "conv1x1", "cbam_pool", "cbam_gate", "cbam_chanpool", "cbam_spatial", "upsample_add", "tail")
 
 
 class MdieError(RuntimeError):
@@ -48,6 +49,12 @@ class Tensor(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
 
 
+class TailDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("lo", C.c_void_p), ("lo_stride", C.c_int), ("x", C.c_void_p), ("y", C.c_void_p),
+                ("params", C.c_void_p)]
+
+
 class Tap(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("channels", C.c_int), ("stride", C.c_int), ("H", C.c_int), ("W", C.c_int)]
 
@@ -56,7 +63,7 @@ class CdanFwdDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("params", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("taps", C.POINTER(Tap)),
+                ("taps", C.POINTER(Tap)), ("flags", C.c_int),
                 ("launch_ms", C.POINTER(C.c_float)), ("launch_kind", C.POINTER(C.c_int)),
                 ("max_launches", C.c_int), ("n_launches", C.POINTER(C.c_int))]
 
@@ -70,6 +77,9 @@ SIGNATURES = {
     "mdie_cbam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mdie_cbam_fwd": (C.c_int, [C.POINTER(CbamDesc), C.c_void_p]),
     "mdie_cbam_channel_only_fwd": (C.c_int, [C.POINTER(CbamDesc), C.c_void_p]),
+    "mdie_tail_param_bytes": (C.c_size_t, [C.c_int]),
+    "mdie_tail_pack_params": (C.c_int, [C.c_int, C.POINTER(Tensor), C.c_int, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "mdie_tail_fwd": (C.c_int, [C.POINTER(TailDesc), C.c_void_p]),
     "mdie_upsample2x_add": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mdie_nchw3_to_nhwc16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
