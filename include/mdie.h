@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 2
+#define MDIE_ABI_VERSION 3
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -90,8 +90,9 @@ typedef struct {
 int mdie_conv_fwd(const mdie_conv_desc* d, void* stream);
 
 /* Host-side packing of one convolution weight (fp32, PyTorch layout) into the layout
- * mdie_conv_fwd reads: [cin_chunk][tap][cout_pad][KC] with KC = 16 (f32) / 32 (bf16)
- * channels = 64 bytes per row, zero padded.
+ * mdie_conv_fwd reads: [cin_chunk][q][tap][cout_pad][16 bytes], where a chunk is 64 bytes of
+ * input channels (KC = 16 f32 / 32 bf16) and q = 0..3 selects its 16-byte quarter -- exactly the
+ * planar LDS image of one K chunk (plane q = the `lane>>4` K group of an MFMA operand); zero padded.
  *   transposed = 0: w is [cout][cin][k][k]   (nn.Conv2d)
  *   transposed = 1: w is [cin][cout][k][k]   (nn.ConvTranspose2d, models/cdan.py:103-115);
  *                   the spatial flip is applied here.
@@ -101,6 +102,29 @@ int mdie_conv_fwd(const mdie_conv_desc* d, void* stream);
 size_t mdie_conv_weight_bytes(int dtype, int ksize, int cin_stored, int cout_stored);
 int mdie_pack_conv_weight(int dtype, int ksize, int transposed, const float* w, int cout, int cin,
                           int cout_stored, int cin_stored, int split, int gap, void* dst);
+
+/* First layer, straight from the network input: out = pool2x2?(act(conv3x3(x) * post_scale + post_shift))
+ * with x fp32 NCHW [B,3,H,W] (encoder.conv1 + maxpool, models/cdan.py:58,74-75).  K = 27 is im2col'ed
+ * into one 32-deep MFMA step; weights packed by mdie_pack_conv_first_weight:
+ * [step][cout_stored][64 bytes], element k = tap*3 + c (k < 27), steps = 1 (bf16) / 2 (f32). */
+typedef struct {
+  int dtype;
+  int B, H, W;
+  const float* x;
+  const void* weight;
+  const float* post_scale;
+  const float* post_shift;
+  int cout;                /* stored output channels, multiple of 16 */
+  int act;
+  int pool;
+  void* out;
+  int out_stride;
+} mdie_conv_first_desc;
+
+int mdie_conv_first_fwd(const mdie_conv_first_desc* d, void* stream);
+size_t mdie_conv_first_weight_bytes(int dtype, int cout_stored);
+/* w: [cout][3][3][3] fp32 (nn.Conv2d) */
+int mdie_pack_conv_first_weight(int dtype, const float* w, int cout, int cout_stored, void* dst);
 
 /* ---------------------------------------------------------------------------------
  * CBAM (models/cbam.py:84-95) as four passes over an NHWC tensor x[B,H,W,C]:
@@ -211,7 +235,7 @@ typedef struct {
   float* launch_ms; int* launch_kind; int max_launches; int* n_launches;
 } mdie_cdan_fwd_desc;
 
-enum { MDIE_FWD_UNFUSED_TAIL = 1 /* run upsample + final_dense + sigmoid as separate launches */ };
+enum { MDIE_FWD_FUSED_TAIL = 1 /* run upsample + final_dense + sigmoid as ONE launch (mdie_tail_fwd) instead of 7 */ };
 
 enum { MDIE_K_LAYOUT = 0, MDIE_K_CONV3 = 1, MDIE_K_CONV1 = 2, MDIE_K_CBAM_POOL = 3, MDIE_K_CBAM_GATE = 4,
        MDIE_K_CBAM_CHANPOOL = 5, MDIE_K_CBAM_SPATIAL = 6, MDIE_K_UPSAMPLE = 7, MDIE_K_TAIL = 8, MDIE_K_COUNT = 9 };

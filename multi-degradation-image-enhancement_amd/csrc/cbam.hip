@@ -11,7 +11,8 @@
 namespace mdie {
 
 constexpr int CB_THREADS = 256;
-constexpr int POOL_SLAB = 128;  // pixels per pool block
+constexpr int POOL_MIN_SLAB = 128;  // pixels per pool block (at least)
+constexpr int POOL_MAX_SLABS = 16; // partials per image the gate kernel has to fold
 
 struct CbamArgs {
   int B, H, W, C;
@@ -23,7 +24,7 @@ struct CbamArgs {
   float* partial;  // [B][nslab][2][C]
   float* gate;     // [B][C]
   float* map;      // [B][H][W][2]  (max, mean)
-  int nslab;
+  int nslab, slab;  // pool blocks per image, pixels per block
   int spatial;     // 0: channel gate only
 };
 
@@ -39,8 +40,8 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_pool_kernel(const CbamArgs a)
   const int tid = threadIdx.x;
   const int slab = blockIdx.x, img = blockIdx.y;
   const int npix = a.H * a.W;
-  const int p_begin = slab * POOL_SLAB;
-  const int p_end = min(npix, p_begin + POOL_SLAB);
+  const int p_begin = slab * a.slab;
+  const int p_end = min(npix, p_begin + a.slab);
   const int v = tid % CV, r = tid / CV;
   float s[VEC], m[VEC];
 #pragma unroll
@@ -65,13 +66,17 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_pool_kernel(const CbamArgs a)
 }
 
 // ---- pass 2 ----------------------------------------------------------------------------------------
+// One block per image.  The hidden layer is split over (unit j, part q): 256/Hd parts per unit, each
+// part a contiguous run of C/parts channels for BOTH pooled vectors, so all weight loads of the block
+// are issued at once (a per-output loop serialises 2*Hd cold-miss round trips: 42 us at C=512).
 __global__ __launch_bounds__(CB_THREADS) void cbam_gate_kernel(const CbamArgs a) {
   extern __shared__ __attribute__((aligned(16))) char dyn[];
   float* avg = reinterpret_cast<float*>(dyn);  // [C]
   float* mx = avg + a.C;                       // [C]
-  float* hid = mx + a.C;                       // [2][Hd]
+  float* part = mx + a.C;                      // [2][CB_THREADS]
+  float* hid = part + 2 * CB_THREADS;          // [Hd]  (h_avg + h_max)
   const int Hd = a.C / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int img = blockIdx.x;
   const float inv = 1.0f / (float)(a.H * a.W);
   for (int c = tid; c < a.C; c += CB_THREADS) {
@@ -85,20 +90,33 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_gate_kernel(const CbamArgs a)
     mx[c] = m;
   }
   __syncthreads();
-  // hidden = relu(W1 v + b1) for v in {avg, max}: one wave per output, lanes stride over C
-  for (int o = wave; o < 2 * Hd; o += CB_THREADS / 64) {
-    const int j = o % Hd;
-    const float* v = o < Hd ? avg : mx;
-    float s = 0.f;
-    for (int c = lane; c < a.C; c += 64) s = fmaf(a.w1[(size_t)j * a.C + c], v[c], s);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
-    if (lane == 0) hid[o] = fmaxf(s + a.b1[j], 0.f);
+  const int parts = CB_THREADS / Hd;           // 8 (C=512) .. 256 (C=16)
+  const int run = a.C / parts > 0 ? a.C / parts : 1;  // channels per part
+  {
+    const int j = tid / parts, q = tid - j * parts;
+    float sa = 0.f, sm = 0.f;
+    if (j < Hd) {
+      const int c0 = q * run;
+      if (c0 < a.C) {
+        const float* w = a.w1 + (size_t)j * a.C + c0;
+        for (int i = 0; i < run; ++i) { const float wv = w[i]; sa = fmaf(wv, avg[c0 + i], sa); sm = fmaf(wv, mx[c0 + i], sm); }
+      }
+    }
+    part[tid] = sa;
+    part[CB_THREADS + tid] = sm;
+  }
+  __syncthreads();
+  if (tid < Hd) {
+    float sa = 0.f, sm = 0.f;
+    for (int q = 0; q < parts; ++q) { sa += part[tid * parts + q]; sm += part[CB_THREADS + tid * parts + q]; }
+    const float b = a.b1[tid];
+    hid[tid] = fmaxf(sa + b, 0.f) + fmaxf(sm + b, 0.f);
   }
   __syncthreads();
   for (int c = tid; c < a.C; c += CB_THREADS) {
     float s = 2.0f * a.b2[c];  // the MLP (bias included) is applied to both pooled vectors
-    for (int j = 0; j < Hd; ++j) s = fmaf(a.w2[(size_t)c * Hd + j], hid[j] + hid[Hd + j], s);
+    const float* w = a.w2 + (size_t)c * Hd;
+    for (int j = 0; j < Hd; ++j) s = fmaf(w[j], hid[j], s);
     a.gate[(size_t)img * a.C + c] = sigmoidf(s);
   }
 }
@@ -136,10 +154,10 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_chanpool_kernel(const CbamArg
 }
 
 // ---- pass 4 ----------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int TS>
 __global__ __launch_bounds__(CB_THREADS) void cbam_spatial_kernel(const CbamArgs a) {
   constexpr int VEC = Traits<T>::VEC;
-  constexpr int TS = 16, PW = TS + 6;
+  constexpr int PW = TS + 6;
   extern __shared__ __attribute__((aligned(16))) char dyn[];
   float* gate = reinterpret_cast<float*>(dyn);     // [C]
   float* patch = gate + a.C;                       // [2][PW][PW]
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_spatial_kernel(const CbamArgs
     if (tid < 98) w7[tid] = a.w7[tid];
   }
   __syncthreads();
-  {
+  if (tid < TS * TS) {
     float s = 1.0f;
     if (a.spatial) {
       const int py = tid / TS, px = tid % TS;
@@ -206,7 +224,7 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_spatial_kernel(const CbamArgs
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static int nslab_for(int H, int W) { return cdiv(H * W, POOL_SLAB); }
+static int nslab_for(int H, int W) { const int n = cdiv(H * W, POOL_MIN_SLAB); return n < POOL_MAX_SLABS ? n : POOL_MAX_SLABS; }
 
 template <typename T>
 static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
@@ -219,6 +237,7 @@ static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
   a.mul = reinterpret_cast<const char*>(d->mul); a.mul_stride = d->mul_stride;
   a.out = reinterpret_cast<char*>(d->out); a.out_stride = d->out_stride;
   a.nslab = nslab_for(d->H, d->W);
+  a.slab = cdiv(d->H * d->W, a.nslab);
   a.spatial = spatial ? 1 : 0;
   char* ws = reinterpret_cast<char*>(d->workspace);
   a.partial = reinterpret_cast<float*>(ws);
@@ -236,7 +255,7 @@ static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
     MDIE_LAUNCH_CHECK("cbam_pool");
   }
   {
-    const size_t lds = (size_t)(2 * d->C + 2 * (d->C / 16)) * sizeof(float);
+    const size_t lds = (size_t)(2 * d->C + 2 * CB_THREADS + d->C / 16) * sizeof(float);
     TimedLaunch tl(MDIE_K_CBAM_GATE);
     hipLaunchKernelGGL(cbam_gate_kernel, dim3(d->B), dim3(CB_THREADS), lds, stream, a);
     MDIE_LAUNCH_CHECK("cbam_gate");
@@ -255,9 +274,12 @@ static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
   }
   {
     const size_t lds = (size_t)(d->C + 2 * 22 * 22 + 256 + 100) * sizeof(float);
-    const int tiles = cdiv(d->W, 16) * cdiv(d->H, 16);
+    // 1 KiB-per-pixel tensors (C >= 256) sit at 32x32 in this network: 16x16 tiles would give 128 blocks
+    const int ts = d->C >= 256 ? 8 : 16;
+    const int tiles = cdiv(d->W, ts) * cdiv(d->H, ts);
     TimedLaunch tl(MDIE_K_CBAM_SPATIAL);
-    hipLaunchKernelGGL((cbam_spatial_kernel<T>), dim3(tiles, d->B), dim3(CB_THREADS), lds, stream, a);
+    if (ts == 8) hipLaunchKernelGGL((cbam_spatial_kernel<T, 8>), dim3(tiles, d->B), dim3(CB_THREADS), lds, stream, a);
+    else hipLaunchKernelGGL((cbam_spatial_kernel<T, 16>), dim3(tiles, d->B), dim3(CB_THREADS), lds, stream, a);
     MDIE_LAUNCH_CHECK("cbam_spatial");
   }
   return MDIE_OK;

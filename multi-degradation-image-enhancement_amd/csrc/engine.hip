@@ -100,6 +100,8 @@ static size_t conv_weight_bytes(int dtype, int ks, int cin_st, int cout_st) {
   return (size_t)cdiv(cin_st, kc) * ks * ks * cout_st * 64;
 }
 
+static size_t first_weight_bytes(int dtype, int cout_st) { return (size_t)(dtype == MDIE_F32 ? 2 : 1) * cout_st * 64; }
+
 static BlobLayout blob_layout(int dtype) {
   BlobLayout L{};
   size_t off = 0;
@@ -107,7 +109,7 @@ static BlobLayout blob_layout(int dtype) {
   const Arch& A = arch();
   for (int i = 0; i < CV_COUNT; ++i) {
     const ConvSpec& s = A.conv[i];
-    L.conv[i].w = take(conv_weight_bytes(dtype, s.ks, s.cin_st, s.cout_st));
+    L.conv[i].w = take(i == CV_E1 ? first_weight_bytes(dtype, s.cout_st) : conv_weight_bytes(dtype, s.ks, s.cin_st, s.cout_st));
     L.conv[i].post_scale = take(s.cout_st * sizeof(float));
     L.conv[i].post_shift = take(s.cout_st * sizeof(float));
     L.conv[i].pre_scale = take(s.cin_st * sizeof(float));
@@ -151,12 +153,26 @@ static int pack_conv_weight(int dtype, int ks, int transposed, const float* w, i
           // ConvTranspose2d(k3,s1,p1) == Conv2d with W'[o][c][kh][kw] = W[c][o][k-1-kh][k-1-kw]
           const float v = transposed ? w[(((size_t)c * cout + o) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)]
                                      : w[(((size_t)o * cin + c) * ks + kh) * ks + kw];
-          const size_t idx = (((size_t)chunk * ntap + kh * ks + kw) * cout_st + o) * kc + k;
+          const int vec = kc / 4, q = k / vec, i = k % vec;  // 16-byte quarter q of the chunk, element i in it
+          const size_t idx = ((((size_t)chunk * 4 + q) * ntap + kh * ks + kw) * cout_st + o) * vec + i;
           if (esz == 4) reinterpret_cast<float*>(dst)[idx] = v;
           else reinterpret_cast<uint16_t*>(dst)[idx] = f32_to_bf16_rne(v);
         }
     }
   return MDIE_OK;
+}
+
+
+// encoder.conv1 weight [cout][3][3][3] -> [step][cout_st][64 B] with k = tap*3 + c
+static void pack_first_weight(int dtype, const float* w, int cout, int cout_st, void* dst) {
+  memset(dst, 0, first_weight_bytes(dtype, cout_st));
+  for (int o = 0; o < cout; ++o)
+    for (int k = 0; k < 27; ++k) {
+      const int tap = k / 3, c = k % 3;
+      const float v = w[((size_t)o * 3 + c) * 9 + tap];
+      if (dtype == MDIE_F32) reinterpret_cast<float*>(dst)[((size_t)(k / 16) * cout_st + o) * 16 + k % 16] = v;
+      else reinterpret_cast<uint16_t*>(dst)[(size_t)o * 32 + k] = f32_to_bf16_rne(v);
+    }
 }
 
 struct TensorMap {
@@ -244,6 +260,18 @@ extern "C" int mdie_pack_conv_weight(int dtype, int ksize, int transposed, const
   return pack_conv_weight(dtype, ksize, transposed, w, cout, cin, cout_stored, cin_stored, split, gap, dst);
 }
 
+extern "C" size_t mdie_conv_first_weight_bytes(int dtype, int cout_stored) {
+  if ((dtype != MDIE_F32 && dtype != MDIE_BF16) || cout_stored <= 0) return 0;
+  return first_weight_bytes(dtype, cout_stored);
+}
+
+extern "C" int mdie_pack_conv_first_weight(int dtype, const float* w, int cout, int cout_stored, void* dst) {
+  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_pack_conv_first_weight: bad dtype %d", dtype);
+  MDIE_REQUIRE(w && dst && cout > 0 && cout_stored >= cout && cout_stored % 16 == 0, "mdie_pack_conv_first_weight: bad argument");
+  pack_first_weight(dtype, w, cout, cout_stored, dst);
+  return MDIE_OK;
+}
+
 extern "C" size_t mdie_cdan_param_bytes(int dtype) {
   if (dtype != MDIE_F32 && dtype != MDIE_BF16) return 0;
   return blob_layout(dtype).total;
@@ -265,7 +293,8 @@ extern "C" int mdie_cdan_pack_params(int dtype, const mdie_tensor* tensors, int 
     const float* w = T.get(s.w_key, (int64_t)s.cin * s.cout * s.ks * s.ks);
     const float* b = T.get(s.b_key, s.cout);
     if (!w || !b) return MDIE_ENOENT;
-    pack_conv_weight(dtype, s.ks, s.transposed, w, s.cout, s.cin, s.cout_st, s.cin_st, s.split, s.gap, blob + L.conv[i].w);
+    if (i == CV_E1) pack_first_weight(dtype, w, s.cout, s.cout_st, blob + L.conv[i].w);
+    else pack_conv_weight(dtype, s.ks, s.transposed, w, s.cout, s.cin, s.cout_st, s.cin_st, s.split, s.gap, blob + L.conv[i].w);
     float* ps = reinterpret_cast<float*>(blob + L.conv[i].post_scale);
     float* pt = reinterpret_cast<float*>(blob + L.conv[i].post_shift);
     if (!s.bn_post.empty()) {
@@ -419,9 +448,17 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   const int h1 = H / 2, w1 = W / 2, h2 = H / 4, w2 = W / 4, h3 = H / 8, w3 = W / 8;
   int e;
 #define RUN(call) do { if ((e = (call))) return e; } while (0)
-  RUN(mdie_nchw3_to_nhwc16(d->dtype, B, H, W, d->x, c.ws + P.x16.off, stream));
   // Encoder.forward, models/cdan.py:70-98 (dropout = identity in eval)
-  RUN(run_conv(c, CV_E1, H, W, {P.x16}, P.o[0], MDIE_ACT_RELU, 1, nullptr));
+  {
+    mdie_conv_first_desc f{};  // encoder.conv1 + BN + ReLU + maxpool straight from the fp32 NCHW input
+    f.dtype = d->dtype; f.B = B; f.H = H; f.W = W; f.x = d->x;
+    f.weight = c.params + c.L.conv[CV_E1].w;
+    f.post_scale = reinterpret_cast<const float*>(c.params + c.L.conv[CV_E1].post_scale);
+    f.post_shift = reinterpret_cast<const float*>(c.params + c.L.conv[CV_E1].post_shift);
+    f.cout = 64; f.act = MDIE_ACT_RELU; f.pool = 1;
+    f.out = c.ws + P.o[0].off; f.out_stride = P.o[0].C;
+    RUN(mdie_conv_first_fwd(&f, stream));
+  }
   RUN(run_dense(c, 0, h1, w1, P.o[0], P.g[0], P.d[0], MDIE_ACT_NONE));
   RUN(run_conv(c, CV_E2, h1, w1, {P.o[0]}, P.o[1], MDIE_ACT_RELU, 1, nullptr));
   RUN(run_dense(c, 1, h2, w2, P.o[1], P.g[1], P.d[1], MDIE_ACT_NONE));
@@ -440,7 +477,8 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   RUN(run_up(c, h2, w2, P.t3lo, P.o[0], P.t3));
   RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3));
   RUN(run_conv(c, CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
-  if (d->flags & MDIE_FWD_UNFUSED_TAIL) {
+  if (!(d->flags & MDIE_FWD_FUSED_TAIL)) {
+    RUN(mdie_nchw3_to_nhwc16(d->dtype, B, H, W, d->x, c.ws + P.x16.off, stream));  // x as the last skip, NHWC
     RUN(run_up(c, h1, w1, P.t4lo, P.x16, P.t4));                                    // bilinear x2 + x
     RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID));              // final_dense + sigmoid
     RUN(mdie_nhwc16_to_nchw3(d->dtype, B, H, W, c.ws + P.out16.off, d->y, stream));
@@ -459,7 +497,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     tap(MDIE_TAP_ENC, P.e, h3, w3); tap(MDIE_TAP_BOTT, P.bott, h3, w3);
     tap(MDIE_TAP_DEC1, P.u1, h3, w3); tap(MDIE_TAP_DEC2, P.u2, h2, w2); tap(MDIE_TAP_DEC3, P.u3, h1, w1);
     tap(MDIE_TAP_DEC4, P.t4, H, W);
-    if (!(d->flags & MDIE_FWD_UNFUSED_TAIL)) d->taps[MDIE_TAP_DEC4].ptr = nullptr;  // never materialised when fused
+    if (d->flags & MDIE_FWD_FUSED_TAIL) d->taps[MDIE_TAP_DEC4].ptr = nullptr;  // never materialised when fused
   }
   return MDIE_OK;
 }

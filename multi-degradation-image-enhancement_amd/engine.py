@@ -77,7 +77,7 @@ class CdanEngine:
             self._ws_key = key
         return self._ws
 
-    def forward(self, x, out=None, want_taps=False, profile=False, unfused_tail=False):
+    def forward(self, x, out=None, want_taps=False, profile=False, fused_tail=False):
         """x: float32 NCHW [B,3,H,W] on this engine's GPU -> float32 NCHW [B,3,H,W]."""
         if self.params is None:
             raise L.MdieError("CdanEngine.forward before load(state_dict)")
@@ -92,7 +92,7 @@ class CdanEngine:
         d.dtype, d.B, d.H, d.W = self.dtype, B, H, W
         d.params, d.x, d.y = self.params.data_ptr(), x.data_ptr(), y.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-        d.flags = L.FWD_UNFUSED_TAIL if unfused_tail else 0
+        d.flags = L.FWD_FUSED_TAIL if fused_tail else 0
         taps = (L.Tap * len(L.TAP_NAMES))() if want_taps else None
         if taps is not None:
             d.taps = taps
@@ -172,6 +172,28 @@ def conv_fwd(segments, weight_packed, post_scale, post_shift, *, dtype, ksize, c
     target = out_view if out_view is not None else out
     d.out, d.out_stride = target.data_ptr(), target.stride(2)
     L.check(L.lib.mdie_conv_fwd(C.byref(d), _stream_ptr(x0.device)), "mdie_conv_fwd")
+    return out
+
+
+def conv_first_fwd(x_nchw, w, post_scale, post_shift, *, dtype, act=L.ACT_NONE, pool=False):
+    """x_nchw: fp32 [B,3,H,W]; w: nn.Conv2d weight [cout,3,3,3].  Returns NHWC [B,Ho,Wo,cout_stored]."""
+    _require_gpu(x_nchw, "conv_first_fwd")
+    x_nchw = x_nchw.contiguous()
+    B, _, H, W = x_nchw.shape
+    cout = w.shape[0]
+    cst = (cout + 15) // 16 * 16
+    wn = np.ascontiguousarray(w.detach().cpu().float().numpy())
+    packed = torch.zeros(L.lib.mdie_conv_first_weight_bytes(dtype, cst), dtype=torch.uint8)
+    L.check(L.lib.mdie_pack_conv_first_weight(dtype, wn.ctypes.data, cout, cst, packed.data_ptr()), "mdie_pack_conv_first_weight")
+    packed = packed.to(x_nchw.device)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    out = torch.empty(B, Ho, Wo, cst, dtype=TORCH_DTYPE[dtype], device=x_nchw.device)
+    d = L.ConvFirstDesc()
+    d.dtype, d.B, d.H, d.W, d.x = dtype, B, H, W, x_nchw.data_ptr()
+    d.weight, d.post_scale, d.post_shift = packed.data_ptr(), post_scale.data_ptr(), post_shift.data_ptr()
+    d.cout, d.act, d.pool = cst, act, int(pool)
+    d.out, d.out_stride = out.data_ptr(), cst
+    L.check(L.lib.mdie_conv_first_fwd(C.byref(d), _stream_ptr(x_nchw.device)), "mdie_conv_first_fwd")
     return out
 
 

@@ -12,8 +12,8 @@ LIB_PATH = os.path.join(_HERE, "libmdie_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 2
-FWD_UNFUSED_TAIL = 1
+ABI_VERSION = 3
+FWD_FUSED_TAIL = 1
 
 TAP_NAMES = ("skip0", "skip1", "skip2", "dense0", "dense1", "dense2", "enc", "bott", "dec1", "dec2", "dec3", "dec4")
 KERNEL_KINDS = ("layout", "conv3x3", "conv1x1", "cbam_pool", "cbam_gate", "cbam_chanpool", "cbam_spatial", "upsample_add", "tail")
@@ -33,6 +33,12 @@ class ConvDesc(C.Structure):
                 ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("weight", C.c_void_p),
                 ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int), ("pool", C.c_int),
                 ("residual", C.c_void_p), ("res_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int)]
+
+
+class ConvFirstDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("x", C.c_void_p),
+                ("weight", C.c_void_p), ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("cout", C.c_int),
+                ("act", C.c_int), ("pool", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int)]
 
 
 class CbamDesc(C.Structure):
@@ -74,6 +80,9 @@ SIGNATURES = {
     "mdie_conv_weight_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mdie_pack_conv_weight": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p]),
+    "mdie_conv_first_fwd": (C.c_int, [C.POINTER(ConvFirstDesc), C.c_void_p]),
+    "mdie_conv_first_weight_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mdie_pack_conv_first_weight": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mdie_cbam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mdie_cbam_fwd": (C.c_int, [C.POINTER(CbamDesc), C.c_void_p]),
     "mdie_cbam_channel_only_fwd": (C.c_int, [C.POINTER(CbamDesc), C.c_void_p]),

@@ -46,14 +46,16 @@ def test_pack_conv_weight_layout(dtype, transposed):
     kc = 16 if dtype == L.F32 else 32
     nchunk = -(-cin_st // kc)
     assert packed.numel() == nchunk * 9 * cout_st * 64 == L.lib.mdie_conv_weight_bytes(dtype, ks, cin_st, cout_st)
-    expect = np.zeros((nchunk, 9, cout_st, kc), np.float32)
+    vec = kc // 4
+    expect = np.zeros((nchunk, 4, 9, cout_st, vec), np.float32)
     for o in range(cout):
         for c in range(cin):
             cs = c + (gap if c >= split else 0)
             for kh in range(3):
                 for kw in range(3):
                     v = w[c, o, 2 - kh, 2 - kw] if transposed else w[o, c, kh, kw]
-                    expect[cs // kc, kh * 3 + kw, o, cs % kc] = v
+                    k = cs % kc
+                    expect[cs // kc, k // vec, kh * 3 + kw, o, k % vec] = v
     if dtype == L.F32:
         got = packed.numpy().view(np.float32).reshape(expect.shape)
         assert np.array_equal(got, expect)
@@ -82,7 +84,7 @@ def test_folded_batchnorm_in_blob():
     """encoder.conv1 is the first blob entry: packed weight, then post_scale, post_shift."""
     sd = P.make_state_dict(42)
     blob = E.pack_checkpoint(sd, L.F32).numpy()
-    wbytes = L.lib.mdie_conv_weight_bytes(L.F32, 3, 16, 64)
+    wbytes = L.lib.mdie_conv_first_weight_bytes(L.F32, 64)
     scale = blob[wbytes:wbytes + 256].view(np.float32)
     shift = blob[wbytes + 256:wbytes + 512].view(np.float32)
     g, b = sd["encoder.conv1.bn.weight"].double(), sd["encoder.conv1.bn.bias"].double()
@@ -134,3 +136,20 @@ def test_module_front_end_contract():
     assert list(c.state_dict())[0] == "ChannelGate.mlp.1.weight"
     with pytest.raises(NotImplementedError):
         CBAM(64, reduction_ratio=8)
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_pack_first_layer_weight(dtype):
+    rng = np.random.default_rng(1)
+    w = rng.standard_normal((64, 3, 3, 3)).astype(np.float32)
+    n = L.lib.mdie_conv_first_weight_bytes(dtype, 64)
+    dst = torch.zeros(n, dtype=torch.uint8)
+    L.check(L.lib.mdie_pack_conv_first_weight(dtype, w.ctypes.data, 64, 64, dst.data_ptr()), "pack")
+    im2col = np.zeros((64, 32), np.float32)
+    for k in range(27):
+        im2col[:, k] = w[:, k % 3, (k // 3) // 3, (k // 3) % 3]
+    if dtype == L.F32:
+        got = dst.numpy().view(np.float32).reshape(2, 64, 16)
+        assert np.array_equal(np.concatenate((got[0], got[1]), axis=1), im2col)
+    else:
+        assert np.array_equal(dst.numpy().view(np.uint16).reshape(64, 32), bf16_bits(im2col))

@@ -202,6 +202,19 @@ def test_conv_block(E, L, golden_dir, cin, cout, precision):
         assert err <= tol_for(precision), f"pool={pool}: {err:.3e}"
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_first_layer_kernel(E, L, golden_dir, precision):
+    """ConvBlock(3,16) through the im2col first-layer kernel (fp32 NCHW in, NHWC out)."""
+    g, p = _golden(golden_dir, "op_convblock_3_16.npz")
+    dt = _dt(E, precision)
+    s, t = bn_fold(p, "bn")
+    for pool, key in ((False, "y"), (True, "y_pool")):
+        y = E.conv_first_fwd(g["x"].cuda(), p["conv.weight"], s.cuda(), (p["conv.bias"] * s + t).cuda(), dtype=dt,
+                             act=L.ACT_RELU, pool=pool)
+        err = rel_to_max(E.to_nchw(y, dt), g[key])
+        assert err <= tol_for(precision), f"pool={pool}: {err:.3e}"
+
+
 def _dense_block(E, L, p, x_nchw, cin, dt):
     c0 = (cin + 15) // 16 * 16
     gap = c0 - cin
@@ -315,8 +328,8 @@ def test_fused_tail_equals_unfused_chain(E, net, precision, shape):
     net.precision = precision
     eng = net._engine(x.device)
     with torch.no_grad():
-        fused = eng.forward(x)
-        chain = eng.forward(x, unfused_tail=True)
+        fused = eng.forward(x, fused_tail=True)
+        chain = eng.forward(x)
     err = rel_to_max(fused, chain)
     # bf16: the fused kernel keeps the base in fp32 and rounds growth maps to bf16 in LDS like the
     # unfused chain does in HBM; both agree far inside the bf16 tolerance
