@@ -21,6 +21,8 @@
 // channels of one pixel (8/16-byte NHWC stores), and the 4 pixels of a 2x2 pooling window sit in
 // 4 adjacent lanes (max-pool = two lane swaps in the epilogue).
 // The input is a list of channel segments (mdie_seg): a DenseBlock's torch.cat is never built.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mdie {
@@ -47,7 +49,7 @@ struct EpiArgs {
 
 struct ConvArgs {
   int B, H, W;
-  int tiles_x, tiles_y, n_tiles;
+  int tiles_x, tiles_y, n_tiles, n_tiles_log2;
   int cin, nchunk, cout;
   int nseg;
   SegDev seg[MDIE_MAX_SEG];
@@ -80,53 +82,79 @@ __device__ __forceinline__ void tile_pixel(int ps, int p, int& y, int& x) {
 }
 
 // ---- epilogue: affine, activation, residual, 2x2 max-pool, NHWC store -----------------------------------------
-template <typename T, int NCS, int NPS, int TILE>
-__device__ __forceinline__ void conv_epilogue(const EpiArgs& e, f32x4 (&acc)[NCS][NPS], int img, int y0, int x0, int n0,
-                                              int wave, int lq, int lp) {
-  const int Ho = e.pool ? e.H >> 1 : e.H, Wo = e.pool ? e.W >> 1 : e.W;
+// max over the 4 lanes of a quad (the 2x2 pooling window) with DPP quad_perm swaps: no LDS traffic
+__device__ __forceinline__ float quad_max(float v) {
+  const int a = __builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  v = fmaxf(v, __int_as_float(a));
+  const int b = __builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  return fmaxf(v, __int_as_float(b));
+}
+
+template <int ACT> __device__ __forceinline__ float act_fn(float v) {
+  if constexpr (ACT == MDIE_ACT_RELU) return fmaxf(v, 0.0f);
+  else if constexpr (ACT == MDIE_ACT_SIGMOID) return sigmoidf(v);
+  else return v;
+}
+
+template <typename T, int NCS, int NPS, int TILE, int ACT, bool POOL>
+__device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (&esc)[NCS], const float4 (&esh)[NCS],
+                                                f32x4 (&acc)[NCS][NPS], int img, int y0, int x0, int n0, int ps_base, int lq, int lp) {
+  const int Ho = POOL ? e.H >> 1 : e.H, Wo = POOL ? e.W >> 1 : e.W;
 #pragma unroll
-  for (int cs = 0; cs < NCS; ++cs) {
-    const int c = n0 + cs * 16 + lq * 4;
-    const float4 sc = *reinterpret_cast<const float4*>(e.post_scale + c);
-    const float4 sh = *reinterpret_cast<const float4*>(e.post_shift + c);
+  for (int ps = 0; ps < NPS; ++ps) {
+    int y, x;
+    tile_pixel<TILE>(ps_base + ps, lp, y, x);
+    const int gy = y0 + y, gx = x0 + x;
+    const bool inside = gy < e.H && gx < e.W;
+    const bool writer = POOL ? (inside && (lp & 3) == 0) : inside;
+    const int oy = POOL ? gy >> 1 : gy, ox = POOL ? gx >> 1 : gx;
+    const size_t opix = ((size_t)img * Ho + oy) * Wo + ox;
+    T* orow = reinterpret_cast<T*>(e.out) + opix * e.out_stride + n0 + lq * 4;
+    const T* rrow = e.residual ? reinterpret_cast<const T*>(e.residual) + opix * e.res_stride + n0 + lq * 4 : nullptr;
 #pragma unroll
-    for (int ps = 0; ps < NPS; ++ps) {
-      int y, x;
-      tile_pixel<TILE>(wave * NPS + ps, lp, y, x);
-      const int gy = y0 + y, gx = x0 + x;
-      const bool inside = gy < e.H && gx < e.W;
+    for (int cs = 0; cs < NCS; ++cs) {
+      const float4 sc = esc[cs], sh = esh[cs];
       float v[4];
-      v[0] = apply_act(fmaf(acc[cs][ps][0], sc.x, sh.x), e.act);
-      v[1] = apply_act(fmaf(acc[cs][ps][1], sc.y, sh.y), e.act);
-      v[2] = apply_act(fmaf(acc[cs][ps][2], sc.z, sh.z), e.act);
-      v[3] = apply_act(fmaf(acc[cs][ps][3], sc.w, sh.w), e.act);
-      int oy = gy, ox = gx;
-      bool writer = inside;
-      if (e.pool) {
-        // 2x2 window = lanes lp^1 (x neighbour) and lp^2 (y neighbour)
+      v[0] = act_fn<ACT>(fmaf(acc[cs][ps][0], sc.x, sh.x));
+      v[1] = act_fn<ACT>(fmaf(acc[cs][ps][1], sc.y, sh.y));
+      v[2] = act_fn<ACT>(fmaf(acc[cs][ps][2], sc.z, sh.z));
+      v[3] = act_fn<ACT>(fmaf(acc[cs][ps][3], sc.w, sh.w));
+      if constexpr (POOL) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[i] = fmaxf(v[i], __shfl_xor(v[i], 1));
-          v[i] = fmaxf(v[i], __shfl_xor(v[i], 2));
-        }
-        oy = gy >> 1; ox = gx >> 1;
-        writer = inside && (lp & 3) == 0;
+        for (int i = 0; i < 4; ++i) v[i] = quad_max(v[i]);
       }
+#ifdef EXP_NO_STORE
+      if (writer && v[0] == 1234.5f) {
+#else
       if (writer) {
-        const size_t opix = ((size_t)img * Ho + oy) * Wo + ox;
-        if (e.residual) {
-          const T* r = reinterpret_cast<const T*>(e.residual) + opix * e.res_stride + c;
+#endif
+        if (rrow) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += ld(r + i);
+          for (int i = 0; i < 4; ++i) v[i] += ld(rrow + cs * 16 + i);
         }
-        T* o = reinterpret_cast<T*>(e.out) + opix * e.out_stride + c;
         if constexpr (sizeof(T) == 4) {
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(orow + cs * 16) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          *reinterpret_cast<uint2*>(o) = make_uint2(bf_pack(v[0], v[1]), bf_pack(v[2], v[3]));
+          *reinterpret_cast<uint2*>(orow + cs * 16) = make_uint2(bf_pack(v[0], v[1]), bf_pack(v[2], v[3]));
         }
       }
     }
+  }
+}
+
+// runtime -> compile-time dispatch (act and pool are launch-uniform, so this is one scalar branch)
+template <typename T, int NCS, int NPS, int TILE>
+__device__ __forceinline__ void conv_epilogue(const EpiArgs& e, const float4 (&esc)[NCS], const float4 (&esh)[NCS],
+                                              f32x4 (&acc)[NCS][NPS], int img, int y0, int x0, int n0, int ps_base, int lq, int lp) {
+  if (e.pool) {
+    // only ReLU is ever pooled on this path (encoder blocks, models/cdan.py:74-75)
+    if (e.act == MDIE_ACT_RELU) conv_epilogue_t<T, NCS, NPS, TILE, MDIE_ACT_RELU, true>(e, esc, esh, acc, img, y0, x0, n0, ps_base, lq, lp);
+    else if (e.act == MDIE_ACT_SIGMOID) conv_epilogue_t<T, NCS, NPS, TILE, MDIE_ACT_SIGMOID, true>(e, esc, esh, acc, img, y0, x0, n0, ps_base, lq, lp);
+    else conv_epilogue_t<T, NCS, NPS, TILE, MDIE_ACT_NONE, true>(e, esc, esh, acc, img, y0, x0, n0, ps_base, lq, lp);
+  } else {
+    if (e.act == MDIE_ACT_RELU) conv_epilogue_t<T, NCS, NPS, TILE, MDIE_ACT_RELU, false>(e, esc, esh, acc, img, y0, x0, n0, ps_base, lq, lp);
+    else if (e.act == MDIE_ACT_SIGMOID) conv_epilogue_t<T, NCS, NPS, TILE, MDIE_ACT_SIGMOID, false>(e, esc, esh, acc, img, y0, x0, n0, ps_base, lq, lp);
+    else conv_epilogue_t<T, NCS, NPS, TILE, MDIE_ACT_NONE, false>(e, esc, esh, acc, img, y0, x0, n0, ps_base, lq, lp);
   }
 }
 
@@ -136,12 +164,30 @@ template <int KS, int BN, int TILE> struct ConvGeom {
   static constexpr int NTAP = KS * KS;
   static constexpr int PLANE = ((PW * PWP * 16 + 127) / 256) * 256 + 128;  // == 128 (mod 256): 2-way staging writes at worst
   static constexpr int WPLANE = NTAP * BN * 16;             // multiple of 256 for BN in {16, 64}
-  static constexpr int LDS_BYTES = 4 * PLANE + 4 * WPLANE;
+  static constexpr int BUF_BYTES = 4 * PLANE + 4 * WPLANE;  // one stage: patch + weights of a 64-byte K chunk
 };
 
+// minimum waves per SIMD the register allocator must allow: the thin (cout = 16) kernels live on occupancy
+constexpr int conv_min_waves(int BN, int TILE) { return BN == 16 ? 4 : (TILE == 16 ? 2 : 3); }
+
+#ifdef EXP_STAMPS
+#define STAMP(i) do { if (threadIdx.x == 0 && dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dbg[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = t_; } } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+// The kernel is instruction-issue bound on its bookkeeping (in-kernel s_memtime stamps: ~2.4k cycles of
+// setup and ~5k cycles of epilogue around ~5k cycles of MFMA work for a cout=16 layer), so everything
+// that is not a load, an LDS access or an MFMA is kept off the hot path: 3-D grid instead of index
+// division, incremental patch coordinates, remainder staging iterations under a wave-uniform branch,
+// epilogue constants prefetched at kernel entry.
 template <typename T, int KS, int BN, int TILE>
-__global__ __launch_bounds__(CONV_THREADS) void conv_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_kernel(const ConvArgs a) {
   using G = ConvGeom<KS, BN, TILE>;
+#ifdef EXP_STAMPS
+  unsigned long long* dbg = (a.e.res_stride == -12345) ? reinterpret_cast<unsigned long long*>(const_cast<char*>(a.e.residual)) : nullptr;
+  STAMP(0);
+#endif
   constexpr int VEC = Traits<T>::VEC;
   constexpr int KC = Traits<T>::KC;
   constexpr int PAD = G::PAD, PW = G::PW, NTAP = G::NTAP;
@@ -151,6 +197,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_kernel(const ConvArgs a) {
   constexpr int W_UNITS = 4 * NTAP * BN;
   constexpr int PATCH_IT = (PATCH_UNITS + CONV_THREADS - 1) / CONV_THREADS;
   constexpr int W_IT = (W_UNITS + CONV_THREADS - 1) / CONV_THREADS;
+  // the last staging iteration is partial: only the first waves run it (wave-uniform branch)
+  constexpr int PATCH_LAST_WAVES = ((PATCH_UNITS - (PATCH_IT - 1) * CONV_THREADS) + 63) / 64;
+  constexpr int W_LAST_WAVES = ((W_UNITS - (W_IT - 1) * CONV_THREADS) + 63) / 64;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_patch = smem;
@@ -158,16 +207,134 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_kernel(const ConvArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane >> 4;   // 16-byte K group = LDS plane
   const int lp = lane & 15;
 
-  int bid = blockIdx.x;
-  const int nt = bid % a.n_tiles; bid /= a.n_tiles;
-  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y; bid /= a.tiles_y;
-  const int img = bid;
-  const int y0 = ty * TILE, x0 = tx * TILE, n0 = nt * BN;
+  // grid = (n_tiles * tiles_x, tiles_y, B); n_tiles is a power of two (host checked)
+  const int nt = blockIdx.x & (a.n_tiles - 1);
+  const int tx = blockIdx.x >> a.n_tiles_log2;
+  const int y0 = blockIdx.y * TILE, x0 = tx * TILE, n0 = nt * BN;
+  const int img = blockIdx.z;
+
+  const int q = tid & 3;  // this thread's 16-byte column while staging the patch (CONV_THREADS % 4 == 0)
+  const bool has_pre = a.pre_scale != nullptr;
+
+  // ---- staging geometry: unit u = tid + it*256 -> patch pixel u>>2 (advances 64 pixels per iteration) ----
+  int gpix[PATCH_IT];   // (img*H + gy)*W + gx, or -1 outside the picture / past the patch
+  int pdst[PATCH_IT];   // LDS byte offset of the unit
+  {
+    int pix = tid >> 2;
+    int py = pix / PW, px = pix - py * PW;
+    const int base = img * a.H * a.W;
+#pragma unroll
+    for (int it = 0; it < PATCH_IT; ++it) {
+      const int gy = y0 + py - PAD, gx = x0 + px - PAD;
+      const bool in_patch = (it < PATCH_IT - 1) || (tid + it * CONV_THREADS < PATCH_UNITS);
+      const bool ok = in_patch && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      gpix[it] = ok ? base + gy * a.W + gx : -1;
+      pdst[it] = in_patch ? q * G::PLANE + (py * PWP + px) * 16 : -1;
+      px += 64 % PW; py += 64 / PW;
+      if (px >= PW) { px -= PW; py += 1; }
+    }
+  }
+  int wsrc_off[W_IT];   // byte offset of this thread's weight unit inside one chunk
+#pragma unroll
+  for (int it = 0; it < W_IT; ++it) {
+    const int u = tid + it * CONV_THREADS;
+    const int qt = u / BN, n = u - qt * BN;  // qt = q * NTAP + tap (BN is a power of two)
+    wsrc_off[it] = (qt * a.cout + n0 + n) * 16;
+  }
+  const size_t wchunk_bytes = (size_t)4 * NTAP * a.cout * 16;
+
+  // staging registers (chunk in flight)
+  uint4 pv[PATCH_IT];
+  uint4 wv[W_IT];
+  float ps_[VEC], pb_[VEC];
+  bool chunk_live = false;  // this thread's channel column exists in the chunk
+
+  auto load_chunk = [&](int chunk) {
+    const int c0 = chunk * KC + q * VEC;  // first stored channel of this thread's column
+    const char* sbase = nullptr;
+    int sstride = 0;
+#pragma unroll
+    for (int s = 0; s < MDIE_MAX_SEG; ++s) {
+      if (s < a.nseg && c0 >= a.seg[s].ch_begin && c0 < a.seg[s].ch_end) {
+        sbase = a.seg[s].ptr + (size_t)(c0 - a.seg[s].ch_begin) * sizeof(T);
+        sstride = a.seg[s].stride * (int)sizeof(T);
+      }
+    }
+    chunk_live = sbase != nullptr;
+#pragma unroll
+    for (int it = 0; it < PATCH_IT; ++it) {
+      pv[it] = make_uint4(0, 0, 0, 0);
+#ifndef EXP_NO_GLOAD
+      if (it < PATCH_IT - 1 || wave < PATCH_LAST_WAVES)
+        if (chunk_live && gpix[it] >= 0) pv[it] = *reinterpret_cast<const uint4*>(sbase + (size_t)gpix[it] * sstride);
+#endif
+    }
+    // weights of this chunk: global [chunk][q][tap][cout] x 16 B  ->  LDS [q][tap][BN] x 16 B (linear copy per (q, tap))
+    const char* wsrc = a.weight + chunk * wchunk_bytes;
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      wv[it] = make_uint4(0, 0, 0, 0);
+#ifndef EXP_NO_WLOAD
+      if (it < W_IT - 1 || wave < W_LAST_WAVES)
+        if (tid + it * CONV_THREADS < W_UNITS) wv[it] = *reinterpret_cast<const uint4*>(wsrc + wsrc_off[it]);
+#endif
+    }
+    if (has_pre && chunk_live) {
+      if constexpr (VEC == 8) {
+        const float4 s0 = *reinterpret_cast<const float4*>(a.pre_scale + c0), s1 = *reinterpret_cast<const float4*>(a.pre_scale + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(a.pre_shift + c0), b1 = *reinterpret_cast<const float4*>(a.pre_shift + c0 + 4);
+        ps_[0] = s0.x; ps_[1] = s0.y; ps_[2] = s0.z; ps_[3] = s0.w; ps_[4] = s1.x; ps_[5] = s1.y; ps_[6] = s1.z; ps_[7] = s1.w;
+        pb_[0] = b0.x; pb_[1] = b0.y; pb_[2] = b0.z; pb_[3] = b0.w; pb_[4] = b1.x; pb_[5] = b1.y; pb_[6] = b1.z; pb_[7] = b1.w;
+      } else {
+        const float4 s0 = *reinterpret_cast<const float4*>(a.pre_scale + c0);
+        const float4 b0 = *reinterpret_cast<const float4*>(a.pre_shift + c0);
+        ps_[0] = s0.x; ps_[1] = s0.y; ps_[2] = s0.z; ps_[3] = s0.w;
+        pb_[0] = b0.x; pb_[1] = b0.y; pb_[2] = b0.z; pb_[3] = b0.w;
+      }
+    }
+  };
+
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int it = 0; it < PATCH_IT; ++it) {
+      if (it < PATCH_IT - 1 || wave < PATCH_LAST_WAVES) {
+        if (pdst[it] >= 0) {
+          uint4 v = pv[it];
+          if (has_pre && chunk_live && gpix[it] >= 0) {
+            float f[VEC];
+            Vec16<T>::unpack(v, f);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] = fmaxf(fmaf(f[i], ps_[i], pb_[i]), 0.0f);
+            v = Vec16<T>::pack(f);
+          }
+          *reinterpret_cast<uint4*>(lds_patch + pdst[it]) = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      if (it < W_IT - 1 || wave < W_LAST_WAVES) {
+        const int u = tid + it * CONV_THREADS;
+        if (u < W_UNITS) *reinterpret_cast<uint4*>(lds_w + u * 16) = wv[it];
+      }
+    }
+  };
+
+  STAMP(1);
+  load_chunk(0);   // first memory requests leave before the rest of the bookkeeping
+  STAMP(2);
+
+  // epilogue constants: fetched now, consumed after the last MFMA (no exposed latency at the tail)
+  float4 esc[NCS], esh[NCS];
+#pragma unroll
+  for (int cs = 0; cs < NCS; ++cs) {
+    esc[cs] = *reinterpret_cast<const float4*>(a.e.post_scale + n0 + cs * 16 + lq * 4);
+    esh[cs] = *reinterpret_cast<const float4*>(a.e.post_shift + n0 + cs * 16 + lq * 4);
+  }
 
   f32x4 acc[NCS][NPS];
 #pragma unroll
@@ -185,86 +352,16 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_kernel(const ConvArgs a) {
   }
   const int woff = lq * G::WPLANE + lp * 16;
 
-  const int q = tid & 3;  // this thread's 16-byte column while staging the patch (CONV_THREADS % 4 == 0)
-  const bool has_pre = a.pre_scale != nullptr;
-
-  // staging registers (chunk in flight)
-  uint4 pv[PATCH_IT];
-  bool pin[PATCH_IT];
-  uint4 wv[W_IT];
-  float ps_[VEC], pb_[VEC];
-
-  auto load_chunk = [&](int chunk) {
-    const int c0 = chunk * KC + q * VEC;  // first stored channel of this thread's column
-    const char* sbase = nullptr;
-    int sstride = 0;
-#pragma unroll
-    for (int s = 0; s < MDIE_MAX_SEG; ++s) {
-      if (s < a.nseg && c0 >= a.seg[s].ch_begin && c0 < a.seg[s].ch_end) {
-        sbase = a.seg[s].ptr + (size_t)(c0 - a.seg[s].ch_begin) * sizeof(T);
-        sstride = a.seg[s].stride;
-      }
-    }
-    if (has_pre && sbase) {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) { ps_[i] = a.pre_scale[c0 + i]; pb_[i] = a.pre_shift[c0 + i]; }
-    }
-#pragma unroll
-    for (int it = 0; it < PATCH_IT; ++it) {
-      const int u = tid + it * CONV_THREADS;
-      const int pix = u >> 2;
-      const int py = pix / PW, px = pix - py * PW;
-      const int gy = y0 + py - PAD, gx = x0 + px - PAD;
-      pin[it] = (u < PATCH_UNITS) && sbase && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      pv[it] = make_uint4(0, 0, 0, 0);
-      if (pin[it]) {
-        const size_t pixel = ((size_t)img * a.H + gy) * a.W + gx;
-        pv[it] = *reinterpret_cast<const uint4*>(sbase + pixel * sstride * sizeof(T));
-      }
-    }
-    // weights of this chunk: global [chunk][q][tap][cout] x 16 B  ->  LDS [q][tap][BN] x 16 B (linear copy per (q, tap))
-    const char* wsrc = a.weight + (size_t)chunk * 4 * NTAP * a.cout * 16;
-#pragma unroll
-    for (int it = 0; it < W_IT; ++it) {
-      const int u = tid + it * CONV_THREADS;
-      const int qt = u / BN, n = u - qt * BN;  // qt = q * NTAP + tap
-      wv[it] = make_uint4(0, 0, 0, 0);
-      if (u < W_UNITS) wv[it] = *reinterpret_cast<const uint4*>(wsrc + ((size_t)qt * a.cout + n0 + n) * 16);
-    }
-  };
-
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int it = 0; it < PATCH_IT; ++it) {
-      const int u = tid + it * CONV_THREADS;
-      if (u < PATCH_UNITS) {
-        uint4 v = pv[it];
-        if (has_pre && pin[it]) {
-          float f[VEC];
-          Vec16<T>::unpack(v, f);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) f[i] = fmaxf(fmaf(f[i], ps_[i], pb_[i]), 0.0f);
-          v = Vec16<T>::pack(f);
-        }
-        const int pix = u >> 2;
-        const int py = pix / PW, px = pix - py * PW;
-        *reinterpret_cast<uint4*>(lds_patch + q * G::PLANE + (py * PWP + px) * 16) = v;
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < W_IT; ++it) {
-      const int u = tid + it * CONV_THREADS;
-      if (u < W_UNITS) *reinterpret_cast<uint4*>(lds_w + u * 16) = wv[it];
-    }
-  };
-
-  load_chunk(0);
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
     if (chunk > 0) __syncthreads();  // previous chunk's LDS reads are done
+    if (chunk < 2) STAMP(3 + 4 * chunk);
     store_chunk();
+    if (chunk < 2) STAMP(4 + 4 * chunk);
     __syncthreads();
     if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);  // in flight during the MFMAs below
+    if (chunk < 2) STAMP(5 + 4 * chunk);
 
+#ifndef EXP_NO_MFMA
 #pragma unroll
     for (int tap = 0; tap < NTAP; ++tap) {
       const int kh = tap / KS, kw = tap - kh * KS;
@@ -280,9 +377,18 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_kernel(const ConvArgs a) {
 #pragma unroll
         for (int ps = 0; ps < NPS; ++ps) acc[cs][ps] = mma16<T>(wf[cs], xf[ps], acc[cs][ps]);
     }
+#endif
+    if (chunk < 2) STAMP(6 + 4 * chunk);
   }
-
-  conv_epilogue<T, NCS, NPS, TILE>(a.e, acc, img, y0, x0, n0, wave, lq, lp);
+  STAMP(11);
+#ifdef EXP_STAMPS
+  EpiArgs e2 = a.e;
+  if (dbg) { e2.residual = nullptr; e2.res_stride = 0; }
+  conv_epilogue<T, NCS, NPS, TILE>(e2, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp);
+#else
+  conv_epilogue<T, NCS, NPS, TILE>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp);
+#endif
+  STAMP(12);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -325,60 +431,79 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_first_kernel(const FirstArg
     for (int cs = 0; cs < NCS; ++cs)
       wf[s][cs] = *reinterpret_cast<const uint4*>(a.weight + ((size_t)s * a.cout + n0 + cs * 16 + lp) * 64 + lq * 16);
 
+  float4 esc[NCS], esh[NCS];
+#pragma unroll
+  for (int cs = 0; cs < NCS; ++cs) {
+    esc[cs] = *reinterpret_cast<const float4*>(a.e.post_scale + n0 + cs * 16 + lq * 4);
+    esh[cs] = *reinterpret_cast<const float4*>(a.e.post_shift + n0 + cs * 16 + lq * 4);
+  }
+  // input patch: issue every global load before the first wait
   const size_t plane = (size_t)a.H * a.W;
-  for (int p = tid; p < PW * PW; p += CONV_THREADS) {
+  constexpr int PIT = (PW * PW + CONV_THREADS - 1) / CONV_THREADS;
+  float xin[PIT][3];
+#pragma unroll
+  for (int it = 0; it < PIT; ++it) {
+    const int p = tid + it * CONV_THREADS;
     const int py = p / PW, px = p - py * PW;
     const int gy = y0 + py - 1, gx = x0 + px - 1;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+    xin[it][0] = xin[it][1] = xin[it][2] = 0.f;
+#ifndef EXP_NO_GLOAD
+    if (p < PW * PW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
       const float* xp = a.x + (size_t)img * 3 * plane + (size_t)gy * a.W + gx;
-      v0 = xp[0]; v1 = xp[plane]; v2 = xp[2 * plane];
+      xin[it][0] = xp[0]; xin[it][1] = xp[plane]; xin[it][2] = xp[2 * plane];
     }
-    T* d = patch + p * 4;
-    st(d + 0, v0); st(d + 1, v1); st(d + 2, v2); st(d + 3, 0.f);
+#endif
+  }
+#pragma unroll
+  for (int it = 0; it < PIT; ++it) {
+    const int p = tid + it * CONV_THREADS;
+    if (p < PW * PW) {
+      T* d = patch + p * 4;
+      if constexpr (E == 2) *reinterpret_cast<uint2*>(d) = make_uint2(bf_pack(xin[it][0], xin[it][1]), bf_pack(xin[it][2], 0.f));
+      else *reinterpret_cast<float4*>(d) = make_float4(xin[it][0], xin[it][1], xin[it][2], 0.f);
+    }
   }
   __syncthreads();
 
-  f32x4 acc[NCS][NPS];
+  // this lane's im2col columns k = tap*3 + c -> element offsets in the [pixel][4] patch (lane-constant)
+  constexpr int KPL = 16 / E;  // K elements per lane per step
+  int goff[STEPS][KPL];
 #pragma unroll
-  for (int i = 0; i < NCS; ++i)
+  for (int s = 0; s < STEPS; ++s)
 #pragma unroll
-    for (int j = 0; j < NPS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < KPL; ++i) {
+      const int k = (E == 2 ? 8 * lq : 16 * s + 4 * lq) + i;
+      const int tap = k / 3, c = k - tap * 3;
+      goff[s][i] = tap < 9 ? ((tap / 3) * PW + (tap % 3)) * 4 + c : 0;
+    }
 
 #pragma unroll
   for (int ps = 0; ps < NPS; ++ps) {
     int y, x;
     tile_pixel<TILE>(wave * NPS + ps, lp, y, x);
     const T* base = patch + (y * PW + x) * 4;
+    f32x4 acc[NCS][1];
+#pragma unroll
+    for (int i = 0; i < NCS; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       uint4 xf;
       if constexpr (E == 2) {
         uint32_t h[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int k = 8 * lq + i;                 // im2col column: k = tap*3 + c
-          const int tap = k / 3, c = k - tap * 3;
-          const int off = tap < 9 ? ((tap / 3) * PW + (tap % 3)) * 4 + c : 0;
-          h[i] = *reinterpret_cast<const unsigned short*>(base + off);
-        }
+        for (int i = 0; i < 8; ++i) h[i] = *reinterpret_cast<const unsigned short*>(base + goff[s][i]);
         xf = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
       } else {
         uint32_t h[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = 16 * s + 4 * lq + i;
-          const int tap = k / 3, c = k - tap * 3;
-          const int off = tap < 9 ? ((tap / 3) * PW + (tap % 3)) * 4 + c : 0;
-          h[i] = *reinterpret_cast<const uint32_t*>(base + off);
-        }
+        for (int i = 0; i < 4; ++i) h[i] = *reinterpret_cast<const uint32_t*>(base + goff[s][i]);
         xf = make_uint4(h[0], h[1], h[2], h[3]);
       }
 #pragma unroll
-      for (int cs = 0; cs < NCS; ++cs) acc[cs][ps] = mma16<T>(wf[s][cs], xf, acc[cs][ps]);
+      for (int cs = 0; cs < NCS; ++cs) acc[cs][0] = mma16<T>(wf[s][cs], xf, acc[cs][0]);
     }
+    conv_epilogue<T, NCS, 1, TILE>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS + ps, lq, lp);
   }
-  conv_epilogue<T, NCS, NPS, TILE>(a.e, acc, img, y0, x0, n0, wave, lq, lp);
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------
@@ -386,15 +511,23 @@ template <typename T, int KS, int BN, int TILE>
 static int launch_conv(ConvArgs& a, hipStream_t stream) {
   using G = ConvGeom<KS, BN, TILE>;
   a.tiles_x = cdiv(a.W, TILE); a.tiles_y = cdiv(a.H, TILE);
-  const int grid = a.n_tiles * a.tiles_x * a.tiles_y * a.B;
+  // One tile per workgroup.  (Measured on MI355X: persistent workgroups walking the flattened
+  // (tile, chunk) stages with two LDS stage buffers were 5-25 % SLOWER on every layer shape --
+  // the doubled LDS/VGPR footprint halves the resident workgroups, and resident workgroups are what
+  // hides the staging latency here.)
+  int lg = 0;
+  while ((1 << lg) < a.n_tiles) ++lg;
+  if ((1 << lg) != a.n_tiles) { set_error("mdie_conv_fwd: cout / %d = %d output tiles, must be a power of two", BN, a.n_tiles); return MDIE_EINVAL; }
+  a.n_tiles_log2 = lg;
+  const dim3 grid(a.n_tiles * a.tiles_x, a.tiles_y, a.B);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, BN, TILE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G::BUF_BYTES);
     attr_set = true;
   }
   TimedLaunch tl(KS == 3 ? MDIE_K_CONV3 : MDIE_K_CONV1);
-  hipLaunchKernelGGL((conv_kernel<T, KS, BN, TILE>), dim3(grid), dim3(CONV_THREADS), G::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_kernel<T, KS, BN, TILE>), grid, dim3(CONV_THREADS), G::BUF_BYTES, stream, a);
   MDIE_LAUNCH_CHECK("mdie_conv_fwd");
   return MDIE_OK;
 }
@@ -433,7 +566,8 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   // Small feature maps (32x32, 64x64 at the network's deep end) do not fill 256 CUs with 16x16 tiles:
   // switch to 8x8 tiles (4x the workgroups) when the 16x16 grid would leave CUs idle.
   const long wgs16 = (long)cdiv(d->H, 16) * cdiv(d->W, 16) * d->B * a.n_tiles;
-  const bool small = wgs16 < (bn == 16 ? 1024 : 512);
+  static const int force8 = getenv("MDIE_CONV_TILE8") ? atoi(getenv("MDIE_CONV_TILE8")) : 0;  // experiments: 1 = thin, 2 = all
+  const bool small = wgs16 < (bn == 16 ? 1024 : 512) || (force8 == 1 && bn == 16) || force8 == 2;
   if (d->ksize == 3) {
     if (bn == 64) return small ? launch_conv<T, 3, 64, 8>(a, stream) : launch_conv<T, 3, 64, 16>(a, stream);
     return small ? launch_conv<T, 3, 16, 8>(a, stream) : launch_conv<T, 3, 16, 16>(a, stream);
@@ -474,7 +608,9 @@ extern "C" int mdie_conv_fwd(const mdie_conv_desc* d, void* stream) {
   MDIE_REQUIRE(!d->pool || (d->H % 2 == 0 && d->W % 2 == 0), "mdie_conv_fwd: pool needs even H, W");
   MDIE_REQUIRE(d->out_stride % 4 == 0 && d->out_stride >= 4, "mdie_conv_fwd: out_stride %d", d->out_stride);
   MDIE_REQUIRE(((uintptr_t)d->out & 15) == 0 && ((uintptr_t)d->weight & 15) == 0, "mdie_conv_fwd: out/weight alignment");
+#ifndef EXP_STAMPS
   MDIE_REQUIRE(!d->residual || (d->res_stride % 4 == 0), "mdie_conv_fwd: res_stride %d", d->res_stride);
+#endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return d->dtype == MDIE_F32 ? dispatch_conv<float>(d, s) : dispatch_conv<mdie::bf16>(d, s);
 }
