@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 3
+#define MDIE_ABI_VERSION 4
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -85,6 +85,8 @@ typedef struct {
   int res_stride;
   void* out;
   int out_stride;
+  float* out_nchw3;        /* optional: instead of `out`, write output channels 0..2 as fp32 NCHW [B,3,Ho,Wo]
+                              (the network's final tensor, models/cdan.py:157); cout must be 16 */
 } mdie_conv_desc;
 
 int mdie_conv_fwd(const mdie_conv_desc* d, void* stream);
@@ -187,6 +189,12 @@ int mdie_tail_fwd(const mdie_tail_desc* d, void* stream);
  * align_corners=False) + torch.add, models/cdan.py:137-138,145-146,153-154) */
 int mdie_upsample2x_add(int dtype, int B, int H, int W, int C, const void* lo, int lo_stride,
                         const void* skip, int skip_stride, void* out, int out_stride, void* stream);
+
+/* Same, for the last decoder stage where the skip is the network input itself (`torch.add(out, x)`,
+ * models/cdan.py:153-154): lo NHWC [B,H,W,lo_stride] (channels 0..2), x fp32 NCHW [B,3,2H,2W],
+ * out NHWC [B,2H,2W,16] (channels 3..15 zero). */
+int mdie_upsample2x_add_nchw3(int dtype, int B, int H, int W, const void* lo, int lo_stride, const float* x_nchw,
+                              void* out, void* stream);
 
 /* Boundary layout changes: fp32 NCHW [B,3,H,W] <-> NHWC with 16 stored channels. */
 int mdie_nchw3_to_nhwc16(int dtype, int B, int H, int W, const float* x_nchw, void* out, void* stream);

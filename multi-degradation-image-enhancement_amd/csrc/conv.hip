@@ -45,6 +45,7 @@ struct EpiArgs {
   int res_stride;
   char* out;
   int out_stride;
+  float* nchw3;  // optional fp32 NCHW [B,3,Ho,Wo] destination for output channels 0..2
 };
 
 struct ConvArgs {
@@ -533,10 +534,11 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
 }
 
 static void fill_epi(EpiArgs& e, int H, int W, const float* sc, const float* sh, int act, int pool, const void* res, int res_stride,
-                     void* out, int out_stride) {
+                     void* out, int out_stride, float* nchw3 = nullptr) {
   e.H = H; e.W = W; e.post_scale = sc; e.post_shift = sh; e.act = act; e.pool = pool;
   e.residual = reinterpret_cast<const char*>(res); e.res_stride = res_stride;
   e.out = reinterpret_cast<char*>(out); e.out_stride = out_stride;
+  e.nchw3 = nchw3;
 }
 
 template <typename T>
@@ -560,7 +562,7 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   MDIE_REQUIRE(c == d->cin, "mdie_conv_fwd: segments hold %d channels, cin = %d", c, d->cin);
   a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift;
   a.weight = reinterpret_cast<const char*>(d->weight);
-  fill_epi(a.e, d->H, d->W, d->post_scale, d->post_shift, d->act, d->pool, d->residual, d->res_stride, d->out, d->out_stride);
+  fill_epi(a.e, d->H, d->W, d->post_scale, d->post_shift, d->act, d->pool, d->residual, d->res_stride, d->out, d->out_stride, d->out_nchw3);
   const int bn = (d->cout % 64 == 0) ? 64 : 16;
   a.n_tiles = d->cout / bn;
   // Small feature maps (32x32, 64x64 at the network's deep end) do not fill 256 CUs with 16x16 tiles:
@@ -603,10 +605,11 @@ extern "C" int mdie_conv_fwd(const mdie_conv_desc* d, void* stream) {
   MDIE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "mdie_conv_fwd: empty extent %dx%dx%d", d->B, d->H, d->W);
   MDIE_REQUIRE(d->nseg >= 1 && d->nseg <= MDIE_MAX_SEG, "mdie_conv_fwd: nseg %d", d->nseg);
   MDIE_REQUIRE(d->cout > 0 && d->cout % 16 == 0, "mdie_conv_fwd: cout %d must be a multiple of 16", d->cout);
-  MDIE_REQUIRE(d->weight && d->post_scale && d->post_shift && d->out, "mdie_conv_fwd: null pointer");
+  MDIE_REQUIRE(d->weight && d->post_scale && d->post_shift && (d->out || d->out_nchw3), "mdie_conv_fwd: null pointer");
+  MDIE_REQUIRE(!d->out_nchw3 || (d->cout == 16 && !d->residual), "mdie_conv_fwd: out_nchw3 needs cout == 16 and no residual");
   MDIE_REQUIRE((d->pre_scale == nullptr) == (d->pre_shift == nullptr), "mdie_conv_fwd: pre_scale/pre_shift mismatch");
   MDIE_REQUIRE(!d->pool || (d->H % 2 == 0 && d->W % 2 == 0), "mdie_conv_fwd: pool needs even H, W");
-  MDIE_REQUIRE(d->out_stride % 4 == 0 && d->out_stride >= 4, "mdie_conv_fwd: out_stride %d", d->out_stride);
+  MDIE_REQUIRE(d->out_nchw3 || (d->out_stride % 4 == 0 && d->out_stride >= 4), "mdie_conv_fwd: out_stride %d", d->out_stride);
   MDIE_REQUIRE(((uintptr_t)d->out & 15) == 0 && ((uintptr_t)d->weight & 15) == 0, "mdie_conv_fwd: out/weight alignment");
 #ifndef EXP_STAMPS
   MDIE_REQUIRE(!d->residual || (d->res_stride % 4 == 0), "mdie_conv_fwd: res_stride %d", d->res_stride);

@@ -389,7 +389,7 @@ struct Ctx {
 static mdie_seg seg(const Ctx& c, const Buf& b) { return mdie_seg{c.ws + b.off, b.C, b.C}; }
 
 static int run_conv(const Ctx& c, int id, int H, int W, std::initializer_list<Buf> in, const Buf& out, int act, int pool,
-                    const Buf* residual) {
+                    const Buf* residual, float* out_nchw3 = nullptr) {
   const ConvSpec& s = arch().conv[id];
   mdie_conv_desc d{};
   d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.ksize = s.ks;
@@ -407,17 +407,19 @@ static int run_conv(const Ctx& c, int id, int H, int W, std::initializer_list<Bu
   d.act = act; d.pool = pool;
   if (residual) { d.residual = c.ws + residual->off; d.res_stride = residual->C; }
   d.out = c.ws + out.off; d.out_stride = out.C;
+  d.out_nchw3 = out_nchw3;
   return mdie_conv_fwd(&d, c.stream);
 }
 
-static int run_dense(const Ctx& c, int block, int H, int W, const Buf& base, const Buf* g, const Buf& out, int act) {
+static int run_dense(const Ctx& c, int block, int H, int W, const Buf& base, const Buf* g, const Buf& out, int act,
+                     float* out_nchw3 = nullptr) {
   const int id0 = CV_DENSE0 + block * 5;
   int e;
   if ((e = run_conv(c, id0 + 0, H, W, {base}, g[0], MDIE_ACT_NONE, 0, nullptr))) return e;
   if ((e = run_conv(c, id0 + 1, H, W, {base, g[0]}, g[1], MDIE_ACT_NONE, 0, nullptr))) return e;
   if ((e = run_conv(c, id0 + 2, H, W, {base, g[0], g[1]}, g[2], MDIE_ACT_NONE, 0, nullptr))) return e;
   if ((e = run_conv(c, id0 + 3, H, W, {base, g[0], g[1], g[2]}, g[3], MDIE_ACT_NONE, 0, nullptr))) return e;
-  return run_conv(c, id0 + 4, H, W, {base, g[0], g[1], g[2], g[3]}, out, act, 0, nullptr);
+  return run_conv(c, id0 + 4, H, W, {base, g[0], g[1], g[2], g[3]}, out, act, 0, nullptr, out_nchw3);
 }
 
 static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, const Buf& x, const Buf* mul, const Buf& out) {
@@ -478,10 +480,9 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3));
   RUN(run_conv(c, CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
   if (!(d->flags & MDIE_FWD_FUSED_TAIL)) {
-    RUN(mdie_nchw3_to_nhwc16(d->dtype, B, H, W, d->x, c.ws + P.x16.off, stream));  // x as the last skip, NHWC
-    RUN(run_up(c, h1, w1, P.t4lo, P.x16, P.t4));                                    // bilinear x2 + x
-    RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID));              // final_dense + sigmoid
-    RUN(mdie_nhwc16_to_nchw3(d->dtype, B, H, W, c.ws + P.out16.off, d->y, stream));
+    // bilinear x2 + x (x read from its fp32 NCHW planes), final_dense, sigmoid written straight to NCHW
+    RUN(mdie_upsample2x_add_nchw3(d->dtype, B, h1, w1, c.ws + P.t4lo.off, P.t4lo.C, d->x, c.ws + P.t4.off, stream));
+    RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID, d->y));
   } else {
     mdie_tail_desc t{};
     t.dtype = d->dtype; t.B = B; t.H = H; t.W = W;

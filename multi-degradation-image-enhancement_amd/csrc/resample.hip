@@ -51,6 +51,37 @@ __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_kernel(int B, int H
   }
 }
 
+// last decoder stage: out[B,2H,2W,16] = bilinear_x2(lo)[:, :3] + x (fp32 NCHW), one output pixel per thread
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void upsample2x_add_nchw3_kernel(int B, int H, int W, const T* lo, int lo_stride,
+                                                                          const float* x, T* out) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const size_t plane = (size_t)Ho * Wo;
+  const size_t total = (size_t)B * plane;
+  for (size_t p = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; p < total; p += (size_t)gridDim.x * RS_THREADS) {
+    const size_t img = p / plane, hw = p - img * plane;
+    const int oy = (int)(hw / Wo), ox = (int)(hw - (size_t)oy * Wo);
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    src_index(oy, H, y0, y1, hy0, hy1);
+    src_index(ox, W, x0, x1, wx0, wx1);
+    const T* lb = lo + img * H * W * lo_stride;
+    const T *p00 = lb + ((size_t)y0 * W + x0) * lo_stride, *p01 = lb + ((size_t)y0 * W + x1) * lo_stride;
+    const T *p10 = lb + ((size_t)y1 * W + x0) * lo_stride, *p11 = lb + ((size_t)y1 * W + x1) * lo_stride;
+    const float* xp = x + img * 3 * plane + hw;
+    float f[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) f[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      f[c] = hy0 * (wx0 * ld(p00 + c) + wx1 * ld(p01 + c)) + hy1 * (wx0 * ld(p10 + c) + wx1 * ld(p11 + c)) + xp[c * plane];
+    uint4* o = reinterpret_cast<uint4*>(out + p * 16);
+    constexpr int VEC = Traits<T>::VEC;
+#pragma unroll
+    for (int v = 0; v < 16 / VEC; ++v) o[v] = Vec16<T>::pack(f + v * VEC);
+  }
+}
+
 // fp32 NCHW [B,Creal,H,W] -> NHWC [B,H,W,Cst] (channels >= Creal zero filled)
 template <typename T>
 __global__ __launch_bounds__(RS_THREADS) void nchw_to_nhwc_kernel(int B, int Creal, int Cst, int H, int W, const float* x, T* out) {
@@ -149,6 +180,23 @@ extern "C" int mdie_upsample2x_add(int dtype, int B, int H, int W, int C, const 
     hipLaunchKernelGGL((upsample2x_add_kernel<mdie::bf16>), dim3(grid_for(total)), dim3(RS_THREADS), 0, s, B, H, W, C, (const char*)lo,
                        lo_stride, (const char*)skip, skip_stride, (char*)out, out_stride);
   MDIE_LAUNCH_CHECK("mdie_upsample2x_add");
+  return MDIE_OK;
+}
+
+extern "C" int mdie_upsample2x_add_nchw3(int dtype, int B, int H, int W, const void* lo, int lo_stride, const float* x_nchw, void* out,
+                                         void* stream) {
+  if (int e = check_layout("mdie_upsample2x_add_nchw3", dtype, B, 3, H, W, lo, out)) return e;
+  MDIE_REQUIRE(x_nchw != nullptr && lo_stride >= 3, "mdie_upsample2x_add_nchw3: null x or lo_stride < 3");
+  MDIE_REQUIRE(((uintptr_t)out & 15) == 0, "mdie_upsample2x_add_nchw3: alignment");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for((size_t)B * 4 * H * W);
+  TimedLaunch tl(MDIE_K_UPSAMPLE);
+  if (dtype == MDIE_F32)
+    hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<float>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const float*)lo, lo_stride, x_nchw, (float*)out);
+  else
+    hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<mdie::bf16>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const mdie::bf16*)lo, lo_stride,
+                       x_nchw, (mdie::bf16*)out);
+  MDIE_LAUNCH_CHECK("mdie_upsample2x_add_nchw3");
   return MDIE_OK;
 }
 

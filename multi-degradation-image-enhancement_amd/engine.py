@@ -171,6 +171,7 @@ def conv_fwd(segments, weight_packed, post_scale, post_shift, *, dtype, ksize, c
     d.res_stride = residual.stride(2) if residual is not None else 0
     target = out_view if out_view is not None else out
     d.out, d.out_stride = target.data_ptr(), target.stride(2)
+    d.out_nchw3 = None
     L.check(L.lib.mdie_conv_fwd(C.byref(d), _stream_ptr(x0.device)), "mdie_conv_fwd")
     return out
 

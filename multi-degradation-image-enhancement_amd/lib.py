@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 3
+ABI_VERSION = 4
 FWD_FUSED_TAIL = 1
 
 TAP_NAMES = ("skip0", "skip1", "skip2", "dense0", "dense1", "dense2", "enc", "bott", "dec1", "dec2", "dec3", "dec4")
@@ -32,7 +32,8 @@ class ConvDesc(C.Structure):
                 ("nseg", C.c_int), ("inp", Seg * MAX_SEG), ("cin", C.c_int), ("cout", C.c_int),
                 ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("weight", C.c_void_p),
                 ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int), ("pool", C.c_int),
-                ("residual", C.c_void_p), ("res_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int)]
+                ("residual", C.c_void_p), ("res_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int),
+                ("out_nchw3", C.c_void_p)]
 
 
 class ConvFirstDesc(C.Structure):
@@ -91,6 +92,7 @@ SIGNATURES = {
     "mdie_tail_fwd": (C.c_int, [C.POINTER(TailDesc), C.c_void_p]),
     "mdie_upsample2x_add": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mdie_upsample2x_add_nchw3": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdie_nchw3_to_nhwc16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdie_nhwc16_to_nchw3": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdie_nchw_to_nhwc": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -16,7 +16,7 @@ NAMES = ["enc.conv1+pool"] + [f"dense1.l{i}" for i in range(4)] + ["dense1.tr", 
          "cbam1.pool", "cbam1.gate", "cbam1.chanpool", "cbam1.spatial*d3", "dec.conv2", "up2+skip1", "cbam2.pool",
          "cbam2.gate", "cbam2.chanpool", "cbam2.spatial*d2", "dec.conv3", "up3+skip0", "cbam3.pool", "cbam3.gate",
          "cbam3.chanpool", "cbam3.spatial*d1", "dec.conv4"]
-NAMES += (["tail(fused)"] if fused else ["x->nhwc16", "up4+x"] + [f"final.l{i}" for i in range(4)] + ["final.tr+sigmoid", "nhwc16->nchw"])
+NAMES += (["tail(fused)"] if fused else ["up4+x(nchw)"] + [f"final.l{i}" for i in range(4)] + ["final.tr+sigmoid->nchw"])
 net = CDAN(precision=prec)
 net.load_state_dict(P.make_state_dict(42), strict=True)
 net = net.eval().cuda()

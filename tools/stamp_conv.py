@@ -41,6 +41,7 @@ for name in sys.argv[1:] or list(SHAPES):
         if stamp:
             d.residual, d.res_stride = dbg.data_ptr(), -12345
         d.out, d.out_stride = out.data_ptr(), cout
+        d.out_nchw3 = None
         L.check(L.lib.mdie_conv_fwd(C.byref(d), None), "conv")
     for _ in range(3):
         run(False)
