@@ -124,6 +124,13 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = quad_max(v[i]);
       }
+      if (e.nchw3) {  // final tensor of the network: channels 0..2 straight to fp32 NCHW planes
+        if (writer && cs == 0 && lq == 0 && n0 == 0) {
+          const size_t plane = (size_t)Ho * Wo;
+          float* o = e.nchw3 + (size_t)img * 3 * plane + (size_t)oy * Wo + ox;
+          o[0] = v[0]; o[plane] = v[1]; o[2 * plane] = v[2];
+        }
+      } else
 #ifdef EXP_NO_STORE
       if (writer && v[0] == 1234.5f) {
 #else
