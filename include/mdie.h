@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 4
+#define MDIE_ABI_VERSION 5
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -226,6 +226,14 @@ enum { MDIE_TAP_SKIP0 = 0, MDIE_TAP_SKIP1, MDIE_TAP_SKIP2, MDIE_TAP_DENSE0, MDIE
        MDIE_TAP_DENSE2, MDIE_TAP_ENC, MDIE_TAP_BOTT, MDIE_TAP_DEC1, MDIE_TAP_DEC2, MDIE_TAP_DEC3,
        MDIE_TAP_DEC4, MDIE_TAP_COUNT };
 
+/* Side streams for the three encoder DenseBlocks.  dense_k depends only on the pooled block output
+ * o_k and is first consumed by the decoder (`out *= denses[k]`, models/cdan.py:133,141,149), so the
+ * plan forks it onto its own stream right after conv_k and joins before the matching decoder CBAM:
+ * the thin cout=16 launches then overlap the MFMA-heavy main chain.  Create/destroy OUTSIDE graph
+ * capture; the fork/join events are captured like any other dependency. */
+int mdie_aux_create(void** aux);
+void mdie_aux_destroy(void* aux);
+
 /* x, y: fp32 NCHW [B,3,H,W] device pointers; H, W multiples of 8.
  * taps (optional, host array of MDIE_TAP_COUNT) is filled with workspace views.
  * launch_ms (optional, host array of capacity max_launches) turns on the instrumented mode:
@@ -240,6 +248,7 @@ typedef struct {
   void* workspace;  size_t workspace_bytes;
   mdie_tap* taps;
   int flags;                /* MDIE_FWD_* bits */
+  void* aux;                /* mdie_aux_create handle or NULL (everything on `stream`) */
   float* launch_ms; int* launch_kind; int max_launches; int* n_launches;
 } mdie_cdan_fwd_desc;
 

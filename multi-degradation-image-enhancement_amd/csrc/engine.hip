@@ -377,6 +377,11 @@ extern "C" double mdie_cdan_algorithmic_bytes(int B, int H, int W, int esize) {
 // ---- the forward plan ---------------------------------------------------------------------------------------------------
 namespace {
 
+struct Aux {
+  hipStream_t side[3];
+  hipEvent_t fork[3], join[3];
+};
+
 struct Ctx {
   int dtype, B;
   const char* params;
@@ -450,6 +455,26 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   const int h1 = H / 2, w1 = W / 2, h2 = H / 4, w2 = W / 4, h3 = H / 8, w3 = W / 8;
   int e;
 #define RUN(call) do { if ((e = (call))) return e; } while (0)
+  // encoder DenseBlock k: forked onto a side stream when the caller provided aux streams
+  Aux* aux = (d->launch_ms == nullptr) ? reinterpret_cast<Aux*>(d->aux) : nullptr;  // instrumented mode stays serial
+  auto side_dense = [&](int k, int hh, int ww) -> int {
+    if (!aux) return run_dense(c, k, hh, ww, P.o[k], P.g[k], P.d[k], MDIE_ACT_NONE);
+    if (hipEventRecord(aux->fork[k], stream) != hipSuccess || hipStreamWaitEvent(aux->side[k], aux->fork[k], 0) != hipSuccess) {
+      set_error("mdie_cdan_forward: fork to side stream %d failed", k);
+      return MDIE_ELAUNCH;
+    }
+    Ctx cs = c;
+    cs.stream = aux->side[k];
+    const int rc = run_dense(cs, k, hh, ww, P.o[k], P.g[k], P.d[k], MDIE_ACT_NONE);
+    if (rc) return rc;
+    if (hipEventRecord(aux->join[k], aux->side[k]) != hipSuccess) { set_error("mdie_cdan_forward: join record %d failed", k); return MDIE_ELAUNCH; }
+    return MDIE_OK;
+  };
+  auto join_dense = [&](int k) -> int {
+    if (!aux) return MDIE_OK;
+    if (hipStreamWaitEvent(stream, aux->join[k], 0) != hipSuccess) { set_error("mdie_cdan_forward: join wait %d failed", k); return MDIE_ELAUNCH; }
+    return MDIE_OK;
+  };
   // Encoder.forward, models/cdan.py:70-98 (dropout = identity in eval)
   {
     mdie_conv_first_desc f{};  // encoder.conv1 + BN + ReLU + maxpool straight from the fp32 NCHW input
@@ -461,22 +486,25 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     f.out = c.ws + P.o[0].off; f.out_stride = P.o[0].C;
     RUN(mdie_conv_first_fwd(&f, stream));
   }
-  RUN(run_dense(c, 0, h1, w1, P.o[0], P.g[0], P.d[0], MDIE_ACT_NONE));
+  RUN(side_dense(0, h1, w1));
   RUN(run_conv(c, CV_E2, h1, w1, {P.o[0]}, P.o[1], MDIE_ACT_RELU, 1, nullptr));
-  RUN(run_dense(c, 1, h2, w2, P.o[1], P.g[1], P.d[1], MDIE_ACT_NONE));
+  RUN(side_dense(1, h2, w2));
   RUN(run_conv(c, CV_E3, h2, w2, {P.o[1]}, P.o[2], MDIE_ACT_RELU, 1, nullptr));
-  RUN(run_dense(c, 2, h3, w3, P.o[2], P.g[2], P.d[2], MDIE_ACT_NONE));
+  RUN(side_dense(2, h3, w3));
   RUN(run_conv(c, CV_E4, h3, w3, {P.o[2]}, P.e, MDIE_ACT_RELU, 0, nullptr));
   // bottleneck, models/cdan.py:173
   RUN(run_cbam_stage(c, P, CB_BOTT, h3, w3, P.e, nullptr, P.bott));
   // Decoder.forward, models/cdan.py:126-159
   RUN(run_conv(c, CV_D1, h3, w3, {P.bott}, P.t1, MDIE_ACT_RELU, 0, &P.o[2]));      // convT+BN+ReLU, + skip2
+  RUN(join_dense(2));
   RUN(run_cbam_stage(c, P, CB_1, h3, w3, P.t1, &P.d[2], P.u1));                     // cbam1, *= dense3
   RUN(run_conv(c, CV_D2, h3, w3, {P.u1}, P.t2lo, MDIE_ACT_RELU, 0, nullptr));
   RUN(run_up(c, h3, w3, P.t2lo, P.o[1], P.t2));                                     // bilinear x2 + skip1
+  RUN(join_dense(1));
   RUN(run_cbam_stage(c, P, CB_2, h2, w2, P.t2, &P.d[1], P.u2));
   RUN(run_conv(c, CV_D3, h2, w2, {P.u2}, P.t3lo, MDIE_ACT_RELU, 0, nullptr));
   RUN(run_up(c, h2, w2, P.t3lo, P.o[0], P.t3));
+  RUN(join_dense(0));
   RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3));
   RUN(run_conv(c, CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
   if (!(d->flags & MDIE_FWD_FUSED_TAIL)) {
@@ -504,6 +532,31 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" int mdie_aux_create(void** out) {
+  MDIE_REQUIRE(out != nullptr, "mdie_aux_create: null argument");
+  Aux* a = new Aux();
+  bool ok = true;
+  for (int i = 0; i < 3; ++i) {
+    ok = ok && hipStreamCreateWithFlags(&a->side[i], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&a->fork[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&a->join[i], hipEventDisableTiming) == hipSuccess;
+  }
+  if (!ok) { set_error("mdie_aux_create: HIP stream/event creation failed"); delete a; return MDIE_ELAUNCH; }
+  *out = a;
+  return MDIE_OK;
+}
+
+extern "C" void mdie_aux_destroy(void* aux) {
+  Aux* a = reinterpret_cast<Aux*>(aux);
+  if (!a) return;
+  for (int i = 0; i < 3; ++i) {
+    (void)hipStreamDestroy(a->side[i]);
+    (void)hipEventDestroy(a->fork[i]);
+    (void)hipEventDestroy(a->join[i]);
+  }
+  delete a;
+}
 
 extern "C" int mdie_cdan_forward(const mdie_cdan_fwd_desc* d, void* stream) {
   MDIE_REQUIRE(d != nullptr, "mdie_cdan_forward: null descriptor");

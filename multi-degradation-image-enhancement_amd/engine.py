@@ -4,6 +4,7 @@ PyTorch is used here only for device memory and streams; every numeric
 operation of the path runs in libmdie_hip.so.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -61,6 +62,18 @@ class CdanEngine:
         self.params = None
         self._ws = None
         self._ws_key = None
+        self.use_side_streams = os.environ.get("MDIE_SIDE_STREAMS", "1") != "0"
+        self._aux = C.c_void_p(0)
+        with torch.cuda.device(self.device):
+            L.check(L.lib.mdie_aux_create(C.byref(self._aux)), "mdie_aux_create")
+
+    def __del__(self):
+        try:
+            if self._aux:
+                L.lib.mdie_aux_destroy(self._aux)
+                self._aux = C.c_void_p(0)
+        except Exception:
+            pass
 
     def load(self, state_dict):
         self.params = pack_checkpoint(state_dict, self.dtype).to(self.device)
@@ -93,6 +106,7 @@ class CdanEngine:
         d.params, d.x, d.y = self.params.data_ptr(), x.data_ptr(), y.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         d.flags = L.FWD_FUSED_TAIL if fused_tail else 0
+        d.aux = self._aux if self.use_side_streams else None
         taps = (L.Tap * len(L.TAP_NAMES))() if want_taps else None
         if taps is not None:
             d.taps = taps

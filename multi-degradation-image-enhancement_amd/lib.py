@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 4
+ABI_VERSION = 5
 FWD_FUSED_TAIL = 1
 
 TAP_NAMES = ("skip0", "skip1", "skip2", "dense0", "dense1", "dense2", "enc", "bott", "dec1", "dec2", "dec3", "dec4")
@@ -70,7 +70,7 @@ class CdanFwdDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("params", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("taps", C.POINTER(Tap)), ("flags", C.c_int),
+                ("taps", C.POINTER(Tap)), ("flags", C.c_int), ("aux", C.c_void_p),
                 ("launch_ms", C.POINTER(C.c_float)), ("launch_kind", C.POINTER(C.c_int)),
                 ("max_launches", C.c_int), ("n_launches", C.POINTER(C.c_int))]
 
@@ -100,6 +100,8 @@ SIGNATURES = {
     "mdie_cdan_param_bytes": (C.c_size_t, [C.c_int]),
     "mdie_cdan_pack_params": (C.c_int, [C.c_int, C.POINTER(Tensor), C.c_int, C.c_void_p, C.c_size_t]),
     "mdie_cdan_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mdie_aux_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "mdie_aux_destroy": (None, [C.c_void_p]),
     "mdie_cdan_forward": (C.c_int, [C.POINTER(CdanFwdDesc), C.c_void_p]),
     "mdie_cdan_flops": (C.c_double, [C.c_int, C.c_int, C.c_int]),
     "mdie_cdan_algorithmic_bytes": (C.c_double, [C.c_int, C.c_int, C.c_int, C.c_int]),
