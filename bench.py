@@ -212,8 +212,15 @@ def main():
                          "TFLOPs": round(f / ms / 1e9, 1) if ms and f else None}
     dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
+    # HBM bytes per step from the committed rocprofv3 PMC passes of this exact workload (tools/traffic_from_pmc.py;
+    # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- bench.py cannot run the profiler itself
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", f"traffic_{args.precision}_b{B}_{S}.json")
+    if os.path.exists(tfile):
+        with open(tfile) as f:
+            traffic = json.load(f).get("hbm_bytes_per_step")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
                 "kernel": "cdan_forward (all launches of one step)", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_step": alg_bytes, "flops_per_step": flops,
                 "mfma_frac": round(flops / (kernel_ms * 1e-3) / 1e12 / MFMA_PEAK_TF[args.precision], 4) if kernel_ms else None,
