@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 5
+#define MDIE_ABI_VERSION 6
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -263,6 +263,39 @@ int mdie_cdan_forward(const mdie_cdan_fwd_desc* d, void* stream);
  * and fused-schedule activation bytes for element size `esize` */
 double mdie_cdan_flops(int B, int H, int W);
 double mdie_cdan_algorithmic_bytes(int B, int H, int W, int esize);
+
+/* ---------------------------------------------------------------------------------
+ * Either side of the network in the reference's inference loop.
+ * Images are 3-channel; fp32 NCHW [B,3,H,W] in [0,1] unless noted.
+ * --------------------------------------------------------------------------------- */
+/* feed: uint8 HWC [B,H,W,3] -> fp32 NCHW / 255  (albumentations Normalize(mean 0, std 1, max 255) + ToTensorV2,
+ * utils/transforms_factory.py:78-81) */
+int mdie_u8hwc_to_f32nchw(int B, int H, int W, const uint8_t* in, float* out, void* stream);
+/* output: (img * 255).clip(0, 255).astype(uint8), CHW -> HWC  (models/model.py:80-84) */
+int mdie_f32nchw_to_u8hwc(int B, int H, int W, const float* in, uint8_t* out, void* stream);
+
+/* utils/post_processing.py ops, applied in order (utils/postprocessing_factory.py:19-41).
+ * The reference's `if images.max() > 1: images /= 255` guard is unreachable on this path
+ * (inputs are sigmoid outputs; every op clamps to [0,1]) and is not implemented. */
+enum { MDIE_PP_CONTRAST = 0 /* param = contrast_factor, post_processing.py:5-15 */,
+       MDIE_PP_COLOR = 1    /* param = saturation_factor, :18-30 */,
+       MDIE_PP_SHARPEN = 2  /* param = strength, :33-54 */,
+       MDIE_PP_DENOISE = 3  /* param = sigma, :57-77 */ };
+typedef struct { int kind; float param; } mdie_pp_op;
+size_t mdie_postprocess_workspace_bytes(int B, int H, int W);
+/* ops: HOST array.  out_f32 (NCHW) and/or out_u8_hwc ([B,H,W,3]) receive the result; either may be NULL. */
+int mdie_postprocess(int B, int H, int W, const float* y, const mdie_pp_op* ops, int nops, float* out_f32,
+                     uint8_t* out_u8_hwc, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Batch PSNR and SSIM as torchmetrics computes them with default arguments
+ * (utils/metrics_factory.py:76,87; restated, torchmetrics is not available offline):
+ *   out2[0] = 10 log10(R^2 / MSE), R = max(target, 0) - min(target, 0), MSE over every element
+ *   out2[1] = mean SSIM, 11x11 Gaussian (sigma 1.5), k1 .01, k2 .03, data range = max(range(pred), range(target)),
+ *             windows fully inside the picture (reflect-pad 5, filter, crop 5)
+ * out2: device float[2].  H, W > 10. */
+size_t mdie_metrics_workspace_bytes(int B, int H, int W);
+int mdie_psnr_ssim(int B, int H, int W, const float* pred, const float* target, float* out2, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 const char* mdie_last_error(void);
 int mdie_abi_version(void);

@@ -12,7 +12,8 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 5
+ABI_VERSION = 6
+PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 
 TAP_NAMES = ("skip0", "skip1", "skip2", "dense0", "dense1", "dense2", "enc", "bott", "dec1", "dec2", "dec3", "dec4")
@@ -62,6 +63,10 @@ class TailDesc(C.Structure):
                 ("params", C.c_void_p)]
 
 
+class PpOp(C.Structure):
+    _fields_ = [("kind", C.c_int), ("param", C.c_float)]
+
+
 class Tap(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("channels", C.c_int), ("stride", C.c_int), ("H", C.c_int), ("W", C.c_int)]
 
@@ -105,6 +110,14 @@ SIGNATURES = {
     "mdie_cdan_forward": (C.c_int, [C.POINTER(CdanFwdDesc), C.c_void_p]),
     "mdie_cdan_flops": (C.c_double, [C.c_int, C.c_int, C.c_int]),
     "mdie_cdan_algorithmic_bytes": (C.c_double, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mdie_u8hwc_to_f32nchw": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdie_f32nchw_to_u8hwc": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdie_postprocess_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "mdie_postprocess": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(PpOp), C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mdie_metrics_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "mdie_psnr_ssim": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                 C.c_void_p]),
     "mdie_last_error": (C.c_char_p, []),
     "mdie_abi_version": (C.c_int, []),
 }

@@ -149,6 +149,21 @@ def main():
         up = F.interpolate(lo, scale_factor=2, mode="bilinear", align_corners=False)
         save("op_up2_add.npz", lo=np32(lo), skip=np32(skip), y=np32(torch.add(up, skip)))
 
+    # ---- post-processing (utils/post_processing.py is torch-only: imported from the reference) -------------------
+    from utils import post_processing as RPP  # noqa: E402  (reference)
+    from utils.postprocessing_factory import apply_postprocessing as ref_apply  # noqa: E402  (reference)
+    yp = torch.sigmoid(torch.randn(2, 3, 24, 40, generator=g) * 1.5)
+    chain = {"enabled": True, "ops": [{"name": "enhance_contrast", "args": {"contrast_factor": 1.03}},
+                                      {"name": "enhance_color", "args": {"saturation_factor": 1.55}}]}  # config/low_light.json:42-48
+    chain4 = {"enabled": True, "ops": [{"name": "soft_denoise", "args": {"sigma": 0.3}}, {"name": "sharpen", "args": {"strength": 0.7}},
+                                       {"name": "enhance_contrast", "args": {"contrast_factor": 1.2}},
+                                       {"name": "enhance_color", "args": {"saturation_factor": 0.8}}]}
+    out_chain = ref_apply(yp, chain)
+    save("op_postproc.npz", y=np32(yp), contrast=np32(RPP.enhance_contrast(yp, 1.03)), color=np32(RPP.enhance_color(yp, 1.55)),
+         sharpen=np32(RPP.sharpen(yp, 0.5)), denoise=np32(RPP.soft_denoise(yp, 0.2)), chain_lowlight=np32(out_chain),
+         chain4=np32(ref_apply(yp, chain4)),
+         chain_lowlight_u8=(out_chain.permute(0, 2, 3, 1).numpy() * 255).clip(0, 255).astype(np.uint8))
+
     # ---- one training step (batch-stat BN, dropout off) ----------------------------------------
     ref.load_state_dict(sd, strict=True)
     ref.train()

@@ -334,3 +334,56 @@ def test_fused_tail_equals_unfused_chain(E, net, precision, shape):
     # bf16: the fused kernel keeps the base in fp32 and rounds growth maps to bf16 in LDS like the
     # unfused chain does in HBM; both agree far inside the bf16 tolerance
     assert err <= (FP32_TOL if precision == "fp32" else 1e-2), f"{err:.3e}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# around the network: feed, post-processing, uint8 output, PSNR / SSIM
+# ---------------------------------------------------------------------------------------------------------------------
+def test_postprocessing_matches_reference_vectors(E, golden_dir):
+    import mdie_amd.pipeline as PL
+    z = np.load(os.path.join(golden_dir, "op_postproc.npz"))
+    y = torch.from_numpy(z["y"]).cuda()
+    one = lambda name, **a: {"enabled": True, "ops": [{"name": name, "args": a}]}
+    cases = {"contrast": one("enhance_contrast", contrast_factor=1.03), "color": one("enhance_color", saturation_factor=1.55),
+             "sharpen": one("sharpen", strength=0.5), "denoise": one("soft_denoise", sigma=0.2),
+             "chain_lowlight": {"enabled": True, "ops": [{"name": "enhance_contrast", "args": {"contrast_factor": 1.03}},
+                                                         {"name": "enhance_color", "args": {"saturation_factor": 1.55}}]},
+             "chain4": {"enabled": True, "ops": [{"name": "soft_denoise", "args": {"sigma": 0.3}}, {"name": "sharpen", "args": {"strength": 0.7}},
+                                                 {"name": "enhance_contrast", "args": {"contrast_factor": 1.2}},
+                                                 {"name": "enhance_color", "args": {"saturation_factor": 0.8}}]}}
+    for key, cfg in cases.items():
+        out = PL.apply_postprocessing(y, cfg)
+        err = (out.cpu() - torch.from_numpy(z[key])).abs().max().item()
+        assert err <= 2e-6, f"{key}: {err:.3e}"
+    out, u8 = PL.apply_postprocessing(y, cases["chain_lowlight"], want_uint8=True)
+    ref_u8 = torch.from_numpy(z["chain_lowlight_u8"])
+    diff = (u8.cpu().int() - ref_u8.int()).abs()
+    # truncation of x*255 can flip by one where the fp32 value sits within an ulp of an integer
+    assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 1e-3
+    assert PL.apply_postprocessing(y, {"enabled": False}) is y
+    with pytest.raises(ValueError):
+        PL.apply_postprocessing(y, {"enabled": True, "ops": [{"name": "posterize"}]})
+
+
+def test_feed_and_uint8_roundtrip(E):
+    import mdie_amd.pipeline as PL
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (3, 24, 40, 3), generator=g, dtype=torch.uint8)
+    x = PL.feed_uint8(img.cuda())
+    assert torch.equal(x.cpu(), img.permute(0, 3, 1, 2).float() / 255.0)
+    back = PL.to_uint8_hwc(x)
+    # (k/255)*255 truncates to k-1 for the k where the product lands just below k, exactly as numpy does
+    expect = torch.from_numpy(((img.float() / 255.0).numpy() * 255.0).clip(0, 255).astype(np.uint8))
+    assert torch.equal(back.cpu(), expect)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 32, 48), (4, 3, 64, 64), (1, 3, 17, 23), (8, 3, 256, 256)])
+def test_psnr_ssim_vs_oracle(E, shape):
+    import mdie_amd.pipeline as PL
+    from oracle import metrics_oracle as M
+    g = torch.Generator().manual_seed(shape[0] * 100 + shape[2])
+    t = torch.rand(shape, generator=g)
+    p = (t + 0.05 * torch.randn(shape, generator=g)).clamp(0, 1)
+    out = PL.psnr_ssim(p.cuda(), t.cuda()).cpu()
+    assert out[0].item() == pytest.approx(M.psnr(p, t), abs=2e-3)     # dB
+    assert out[1].item() == pytest.approx(M.ssim(p, t), abs=2e-5)
