@@ -1,0 +1,335 @@
+"""Boundary caller: the pieces of the reference's driver that sit directly on the hot path's boundary
+(SURVEY.md 8b / section 2 rows 3-6), rebuilt so that `run.py -c <config>.json -p test` drives the HIP
+engine with the reference's own config files:
+
+  load_config / instantiate      utils/parser.py:28-73   (JSON with // comments, None for missing keys,
+                                                           ["module", "Class"] factory)
+  ImageFolderPairs / ImageFolder  data/dataset.py:29-112  (pairing modes; PIL decode)
+  Model                           models/model.py:25-363, models/base.py:11-55 (test path)
+  RunLogger                       utils/logger.py:33-166  (csv / jsonl / summary rows)
+
+Differences that matter on MI355X: the `Normalize(mean 0, std 1) -> ToTensorV2` tail of the configs'
+transform list is executed ON THE GPU (uint8 HWC batches cross PCIe pinned and asynchronously, 4x fewer
+bytes than fp32; `mdie_u8hwc_to_f32nchw`), post-processing / uint8 conversion / PSNR / SSIM run as HIP
+kernels on the output while it is still in HBM.  LPIPS and the VGG loss need downloaded weights and are
+skipped with a warning.  Training is not built yet (`Model.train` raises).
+"""
+import csv
+import importlib
+import json
+import os
+import time
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from PIL import Image
+from torch.utils.data import DataLoader, Dataset
+
+IMAGE_EXT = (".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff", ".webp")
+
+
+# ---- configuration ------------------------------------------------------------------------------------------------
+class Cfg(dict):
+    """dict whose missing keys read as None (the reference's NoneDict contract, utils/parser.py:10-12)."""
+
+    def __missing__(self, key):
+        return None
+
+
+def _wrap(node):
+    if isinstance(node, dict):
+        return Cfg((k, _wrap(v)) for k, v in node.items())
+    if isinstance(node, list):
+        return [_wrap(v) for v in node]
+    return node
+
+
+def load_config(path, phase):
+    with open(path, "r") as f:
+        text = "\n".join(line.split("//")[0] for line in f.read().splitlines())
+    cfg = json.loads(text, object_pairs_hook=OrderedDict)
+    cfg["phase"] = phase
+    return _wrap(cfg)
+
+
+def instantiate(spec, *args, default_module=None, kind="Network", **extra):
+    """spec = {"name": ["module.path", "Attr"] | "Attr", "args": {...}}; failures surface as
+    NotImplementedError like the reference's factory (utils/parser.py:69-71) but keep their cause."""
+    name = spec["name"]
+    module_name, attr_name = (name[0], name[1]) if isinstance(name, (list, tuple)) else (default_module, name)
+    try:
+        attr = getattr(importlib.import_module(module_name), attr_name)
+        kwargs = dict(spec.get("args") or {})
+        kwargs.update(extra)
+        obj = attr(*args, **kwargs)
+        try:
+            obj.__name__ = type(obj).__name__
+        except Exception:
+            pass
+        return obj
+    except Exception as e:  # noqa: BLE001
+        raise NotImplementedError(f"{kind} [{attr_name}() from {module_name}] not recognized.") from e
+
+
+# ---- datasets ----------------------------------------------------------------------------------------------------------
+def _images(root):
+    return sorted(f for f in os.listdir(root) if f.lower().endswith(IMAGE_EXT))
+
+
+class _Transform:
+    """Deterministic subset of the configs' albumentations/torchvision op lists.  If the list ends with
+    Normalize(mean 0, std 1) + ToTensorV2 (every shipped config does), that tail is left to the GPU and
+    samples stay uint8 HWC."""
+
+    def __init__(self, cfg, device_tail=True):
+        self.ops = list((cfg or {}).get("ops", []))
+        names = [o["name"] for o in self.ops]
+        self.on_device = False
+        if device_tail and len(names) >= 2 and names[-2:] == ["Normalize", "ToTensorV2"]:
+            a = self.ops[-2].get("args") or {}
+            if all(abs(m) < 1e-12 for m in a.get("mean", [0, 0, 0])) and all(abs(s - 1) < 1e-12 for s in a.get("std", [1, 1, 1])):
+                self.ops, self.on_device = self.ops[:-2], True
+
+    def __call__(self, *imgs, rng=None):
+        arrs = [np.asarray(im.convert("RGB")) for im in imgs]
+        as_float = False
+        for op in self.ops:
+            name, a = op["name"], (op.get("args") or {})
+            if name == "Resize":
+                h, w = (a["size"] if "size" in a else (a["height"], a["width"]))
+                arrs = [np.asarray(Image.fromarray(x).resize((w, h), Image.BILINEAR)) for x in arrs]
+            elif name in ("HorizontalFlip", "RandomHorizontalFlip", "VerticalFlip", "RandomVerticalFlip", "RandomRotate90"):
+                if rng is not None and rng.random() < a.get("p", 0.5):
+                    if "Horizontal" in name:
+                        arrs = [x[:, ::-1] for x in arrs]
+                    elif "Vertical" in name:
+                        arrs = [x[::-1] for x in arrs]
+                    else:
+                        k = int(rng.integers(1, 4))
+                        arrs = [np.rot90(x, k) for x in arrs]
+            elif name == "Normalize":
+                mean, std = np.asarray(a["mean"], np.float32), np.asarray(a["std"], np.float32)
+                arrs = [(x.astype(np.float32) / 255.0 - mean) / std for x in arrs]
+                as_float = True
+            elif name in ("ToTensorV2", "ToTensor"):
+                if not as_float and name == "ToTensor":
+                    arrs = [x.astype(np.float32) / 255.0 for x in arrs]
+                    as_float = True
+            else:
+                raise ValueError(f"transform not supported by the MI355X host path: {name}")
+        out = []
+        for x in arrs:
+            x = np.ascontiguousarray(x)
+            out.append(torch.from_numpy(x) if self.on_device else torch.from_numpy(x.astype(np.float32)).permute(2, 0, 1).contiguous())
+        return out
+
+
+class ImageFolderPairs(Dataset):
+    """degraded/clean folders paired by "filename", "stem" or (legacy) "sorted" -- data/dataset.py:29-92."""
+
+    def __init__(self, input_root, target_root, pairing_mode="filename", transform=None, image_size=None):
+        a, b = _images(input_root), _images(target_root)
+        if pairing_mode == "sorted":
+            self.pairs = [(os.path.join(input_root, x), os.path.join(target_root, y)) for x, y in zip(a, b)]
+        elif pairing_mode in ("filename", "stem"):
+            key = (lambda f: f) if pairing_mode == "filename" else (lambda f: os.path.splitext(f)[0])
+            am, bm = {key(f): f for f in a}, {key(f): f for f in b}
+            common = sorted(set(am) & set(bm))
+            if not common:
+                raise RuntimeError(f"No paired files found with pairing_mode='{pairing_mode}'.\n"
+                                   f"input_root={input_root}\ntarget_root={target_root}")
+            self.pairs = [(os.path.join(input_root, am[k]), os.path.join(target_root, bm[k])) for k in common]
+        else:
+            raise ValueError(f"Unknown pairing_mode: {pairing_mode}")
+        self.tf = _Transform(transform)
+        self.rng = np.random.default_rng(42)
+
+    def __len__(self):
+        return len(self.pairs)
+
+    def __getitem__(self, i):
+        x, t = self.tf(Image.open(self.pairs[i][0]), Image.open(self.pairs[i][1]), rng=self.rng)
+        return x, t
+
+
+class ImageFolder(Dataset):
+    """data/dataset.py:95-112."""
+
+    def __init__(self, input_root, transform=None):
+        self.files = [os.path.join(input_root, f) for f in _images(input_root)]
+        self.tf = _Transform(transform)
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, i):
+        return self.tf(Image.open(self.files[i]))[0]
+
+
+def make_dataloader(dataset, args):
+    workers = int(args.get("num_workers", 0) or 0)
+    return DataLoader(dataset, batch_size=args["batch_size"], shuffle=bool(args.get("shuffle", False)), num_workers=workers,
+                      pin_memory=torch.cuda.is_available())
+
+
+# ---- logging ----------------------------------------------------------------------------------------------------------
+class RunLogger:
+    """runs/<name>/<timestamp>/{test,train}.{csv,jsonl} + summary.json (utils/logger.py:42-166), test rows only."""
+
+    def __init__(self, config):
+        log = config.get("logging") or {}
+        self.enabled = bool(log.get("enabled", False))
+        self._dir = None
+        self._csv = {}
+        if self.enabled:
+            self._dir = os.path.join(log.get("root_dir", "runs"), str(config.get("name") or "run"), time.strftime("%Y%m%d_%H%M%S"))
+            os.makedirs(self._dir, exist_ok=True)
+            if log.get("save_config_copy", True):
+                with open(os.path.join(self._dir, "config.json"), "w") as f:
+                    json.dump(config, f, indent=2)
+
+    def run_dir(self):
+        return self._dir
+
+    def log(self, split, row):
+        if not self.enabled:
+            return
+        with open(os.path.join(self._dir, f"{split}.jsonl"), "a") as f:
+            f.write(json.dumps(row) + "\n")
+        path = os.path.join(self._dir, f"{split}.csv")
+        new = split not in self._csv
+        if new:
+            self._csv[split] = list(row.keys())
+        with open(path, "a", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=self._csv[split], extrasaction="ignore")
+            if new:
+                w.writeheader()
+            w.writerow(row)
+
+    def summary(self, data):
+        if self.enabled:
+            with open(os.path.join(self._dir, "summary.json"), "w") as f:
+                json.dump(data, f, indent=2)
+
+    def generate_plots(self):
+        pass
+
+    def close(self):
+        pass
+
+
+# ---- model harness ------------------------------------------------------------------------------------------------------
+class Model:
+    """Same constructor and entry points as models.model.Model (models/model.py:26, models/base.py:12,35-42)."""
+
+    def __init__(self, network, *, config, dataloader, logger=None):
+        self.config, self.phase = config, config["phase"]
+        sect = config[self.phase]
+        self.device = torch.device(sect["device"])
+        self.model_path, self.model_name = sect["model_path"], sect["model_name"]
+        test = config.get("test") or {}
+        self.is_dataset_paired = bool((test.get("dataset") or {}).get("is_paired", True))
+        self.dataloader, self.logger = dataloader, logger
+        self.network = network.to(self.device)
+        self.postproc_cfg = config.get("post_processing") or {"enabled": False}
+        self.save_cfg = dict(config.get("save_outputs") or {})
+        self.save_cfg.setdefault("output_dir", test.get("output_images_path", "outputs/"))
+        self.save_cfg.setdefault("save_raw", False)
+        self.save_cfg.setdefault("save_postprocessed", True)
+        self.save_cfg.setdefault("raw_prefix", "raw_")
+        self.save_cfg.setdefault("post_prefix", self.save_cfg.get("prefix", "output_"))
+        ev = config.get("evaluation") or {}
+        self.eval_on_raw = bool(ev.get("raw", True))
+        self.eval_on_post = bool(ev.get("postprocessed", bool(self.postproc_cfg.get("enabled", False))))
+        mcfg = config.get("metrics") or {"enabled": False}
+        wanted = [m["name"] for m in (mcfg.get("items") or [])] if mcfg.get("enabled", False) else []
+        self.metric_names = [m for m in wanted if m in ("psnr", "ssim")]
+        for m in wanted:
+            if m not in ("psnr", "ssim"):
+                warnings.warn(f"metric '{m}' needs downloaded network weights and is skipped on the offline MI355X path")
+        self.results = {}
+
+    # -- reference entry points --
+    def train(self):
+        raise NotImplementedError("training (models/model.py:138-227) is not built on the MI355X engine yet; use -p test")
+
+    def test(self):
+        self.test_step()
+
+    def save_model(self, model):
+        os.makedirs(self.model_path, exist_ok=True)
+        torch.save(model.state_dict(), os.path.join(self.model_path, self.model_name))
+
+    # -- helpers --
+    def _to_device(self, batch):
+        from . import pipeline as PL
+        b = batch.to(self.device, non_blocking=True)
+        return PL.feed_uint8(b) if b.dtype == torch.uint8 else b.float()
+
+    def _save(self, u8_hwc, start, prefix):
+        out_dir = self.save_cfg["output_dir"]
+        os.makedirs(out_dir, exist_ok=True)
+        fmt = str(self.save_cfg.get("format", "png")).lower()
+        arr = u8_hwc.cpu().numpy()
+        for i in range(arr.shape[0]):
+            Image.fromarray(arr[i]).save(os.path.join(out_dir, f"{prefix}{start + i:05d}.{fmt}"))
+
+    def _metrics(self, out, tgt):
+        from . import pipeline as PL
+        if not self.metric_names:
+            return {}
+        v = PL.psnr_ssim(out, tgt).cpu()  # one D2H sync per evaluated tensor, not one per term
+        vals = {"psnr": float(v[0]), "ssim": float(v[1])}
+        return {k: vals[k] for k in self.metric_names}
+
+    def test_step(self):
+        from . import pipeline as PL
+        path = os.path.join(self.model_path, self.model_name)
+        if os.path.exists(path):
+            self.network.load_state_dict(torch.load(path, map_location="cpu"))
+        else:
+            warnings.warn(f"checkpoint {path} not found: evaluating the network's current weights")
+        self.network.eval()
+        sums = {"raw": {}, "post": {}}
+        n_batches = n_images = 0
+        max_save = self.save_cfg.get("max_images")
+        t0 = time.time()
+        with torch.no_grad():
+            for batch in self.dataloader:
+                inputs, targets = (batch if self.is_dataset_paired else (batch, None))
+                x = self._to_device(inputs)
+                t = self._to_device(targets) if targets is not None else None
+                raw = self.network(x)
+                want_post = bool(self.postproc_cfg.get("enabled", False))
+                saving = self.save_cfg.get("enabled", True) and (max_save is None or n_images < max_save)
+                pp, pp_u8 = PL.apply_postprocessing(raw, self.postproc_cfg, want_uint8=True) if want_post else (raw, None)
+                if t is not None:
+                    if self.eval_on_raw:
+                        for k, v in self._metrics(raw, t).items():
+                            sums["raw"][k] = sums["raw"].get(k, 0.0) + v
+                    if self.eval_on_post and want_post:
+                        for k, v in self._metrics(pp, t).items():
+                            sums["post"][k] = sums["post"].get(k, 0.0) + v
+                if saving:
+                    if self.save_cfg["save_raw"]:
+                        self._save(PL.to_uint8_hwc(raw), n_images, self.save_cfg["raw_prefix"])
+                    if self.save_cfg["save_postprocessed"]:
+                        self._save(pp_u8 if pp_u8 is not None else PL.to_uint8_hwc(pp), n_images, self.save_cfg["post_prefix"])
+                n_images += raw.shape[0]
+                n_batches += 1
+                if max_save is not None and n_images >= max_save:
+                    break
+        denom = max(1, n_batches)  # per-BATCH means, as the reference reports them (models/model.py:289-336)
+        self.results = {stage: {k: v / denom for k, v in d.items()} for stage, d in sums.items()}
+        self.results["n_images"], self.results["seconds"] = n_images, time.time() - t0
+        for stage in ("raw", "post"):
+            if self.results[stage]:
+                print(f"[TEST {stage.upper()}] " + ", ".join(f"{k}: {v:.4f}" for k, v in self.results[stage].items()))
+        if self.logger is not None:
+            row = {"split": "test", "n_images": n_images}
+            row.update({f"{s}_{k}": v for s in ("raw", "post") for k, v in self.results[s].items()})
+            self.logger.log("test", row)
+            self.logger.summary(self.results)
+        return self.results

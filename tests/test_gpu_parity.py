@@ -387,3 +387,52 @@ def test_psnr_ssim_vs_oracle(E, shape):
     out = PL.psnr_ssim(p.cuda(), t.cuda()).cpu()
     assert out[0].item() == pytest.approx(M.psnr(p, t), abs=2e-3)     # dB
     assert out[1].item() == pytest.approx(M.ssim(p, t), abs=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[0]: a noise-style config, 64x64, batch 4, driven through run.py's main()
+# ---------------------------------------------------------------------------------------------------------------------
+def test_run_py_test_phase_end_to_end(E, tmp_path):
+    import json as _json
+    from PIL import Image
+    from oracle import cdan_oracle as O
+    from oracle import params as P
+    import run as runner
+    from mdie_amd import host as H
+
+    root = str(tmp_path)
+    clean, _ = P.lowlight_batch(77, 6, 64, 64)
+    _, clean = P.lowlight_batch(77, 6, 64, 64)
+    g = torch.Generator().manual_seed(9)
+    noisy = (clean + 0.08 * torch.randn(clean.shape, generator=g)).clamp(0, 1)
+    for sub, data in (("degraded", noisy), ("clean", clean)):
+        os.makedirs(os.path.join(root, "data", sub))
+        for i in range(6):
+            a = (data[i].permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)
+            Image.fromarray(a).save(os.path.join(root, "data", sub, f"{i:03d}.png"))
+    sd = P.make_state_dict(42)
+    os.makedirs(os.path.join(root, "weights"))
+    torch.save(sd, os.path.join(root, "weights", "CDAN_noise.pt"))    # a "reference-trained" checkpoint: same 236 keys
+
+    cfg = H.load_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "example_noise_64.json"), "test")
+    cfg["test"]["dataset"]["args"]["input_root"] = os.path.join(root, "data", "degraded")
+    cfg["test"]["dataset"]["args"]["target_root"] = os.path.join(root, "data", "clean")
+    cfg["test"]["model_path"] = os.path.join(root, "weights")
+    cfg["save_outputs"]["output_dir"] = os.path.join(root, "out")
+    cfg["logging"]["root_dir"] = os.path.join(root, "runs")
+    with pytest.warns(UserWarning, match="lpips"):
+        model = runner.main(cfg)
+
+    res = model.results
+    assert res["n_images"] == 6 and set(res["raw"]) == {"psnr", "ssim"} and set(res["post"]) == {"psnr", "ssim"}
+    outs = sorted(os.listdir(os.path.join(root, "out")))
+    assert len(outs) == 12 and outs[0] == "pp_00000.png" and outs[-1] == "raw_00005.png"
+    # the saved raw image of sample 0 == the oracle on the same decoded uint8 input
+    x0 = torch.from_numpy(np.asarray(Image.open(os.path.join(root, "data", "degraded", "000.png")))).permute(2, 0, 1).float()[None] / 255.0
+    with torch.no_grad():
+        ref = O.cdan_forward(sd, x0)
+    ref_u8 = (ref[0].permute(1, 2, 0).numpy() * 255).clip(0, 255).astype(np.uint8)
+    got = np.asarray(Image.open(os.path.join(root, "out", "raw_00000.png")))
+    assert np.abs(got.astype(int) - ref_u8.astype(int)).max() <= 1
+    run_dirs = os.listdir(os.path.join(root, "runs", "noise_example"))
+    assert len(run_dirs) == 1 and os.path.exists(os.path.join(root, "runs", "noise_example", run_dirs[0], "summary.json"))
