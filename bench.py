@@ -240,10 +240,15 @@ def main():
         ref, cb = cpu_baseline(sd, x_cpu[:nb])
         yc = y[:nb].float().cpu()
         err = ((yc - ref).abs().max() / ref.abs().max()).item()
-        from oracle.cdan_oracle import psnr
-        cb["parity"] = {"max_abs_err_over_max": round(err, 6), "psnr_gpu_vs_cpu_db": round(psnr(yc, ref), 2),
-                        "psnr_gpu_vs_clean_db": round(psnr(yc, clean_cpu[:nb]), 2),
-                        "psnr_cpu_vs_clean_db": round(psnr(ref, clean_cpu[:nb]), 2)}
+        # PSNR / SSIM side by side (torchmetrics-default formulas of utils/metrics_factory.py, computed by the HIP
+        # metrics kernel on the GPU): engine output vs CPU-path output, and each against the clean targets
+        from mdie_amd import pipeline as PL
+        clean_d, ref_d = clean_cpu[:nb].to(dev), ref.to(dev)
+        m_gc, m_gt, m_ct = (PL.psnr_ssim(a, b).cpu().tolist() for a, b in ((y[:nb], ref_d), (y[:nb], clean_d), (ref_d, clean_d)))
+        cb["parity"] = {"max_abs_err_over_max": round(err, 6),
+                        "gpu_vs_cpu": {"psnr_db": round(m_gc[0], 2), "ssim": round(m_gc[1], 5)},
+                        "gpu_vs_clean": {"psnr_db": round(m_gt[0], 2), "ssim": round(m_gt[1], 5)},
+                        "cpu_vs_clean": {"psnr_db": round(m_ct[0], 2), "ssim": round(m_ct[1], 5)}}
         out["cpu_baseline"] = cb
     print(json.dumps(out))
     if dist is not None:
