@@ -219,11 +219,17 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
   const int lq = lane >> 4;   // 16-byte K group = LDS plane
   const int lp = lane & 15;
 
-  // grid = (n_tiles * tiles_x, tiles_y, B); n_tiles is a power of two (host checked)
-  const int nt = blockIdx.x & (a.n_tiles - 1);
-  const int tx = blockIdx.x >> a.n_tiles_log2;
-  const int y0 = blockIdx.y * TILE, x0 = tx * TILE, n0 = nt * BN;
-  const int img = blockIdx.z;
+  // grid = (8, n_tiles, ceil(patches / 8)): workgroups are dealt round-robin over the 8 XCDs in dispatch
+  // order, so the fastest grid index is the XCD slot.  All output-channel tiles (y) of one pixel patch
+  // share that slot: the patch is filled into ONE XCD's L2 and re-read there by the other n-tiles
+  // (speed only -- nothing depends on the placement).
+  const int patch = blockIdx.z * 8 + blockIdx.x;
+  if (patch >= a.tiles_x * a.tiles_y * a.B) return;
+  const int tpi = a.tiles_x * a.tiles_y;
+  const int img = patch / tpi;
+  const int trem = patch - img * tpi;
+  const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+  const int y0 = ty * TILE, x0 = tx * TILE, n0 = blockIdx.y * BN;
 
   const int q = tid & 3;  // this thread's 16-byte column while staging the patch (CONV_THREADS % 4 == 0)
   const bool has_pre = a.pre_scale != nullptr;
@@ -407,6 +413,13 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
 // work), which is the pairing the matrix and vector pipes co-issue on; the stages of consecutive tiles
 // form one continuous stream, so there is no per-tile launch, setup or pipeline drain.
 // One workgroup barrier per stage: the buffer written during stage s is the one read during stage s+1.
+//
+// STATUS: opt-in (MDIE_CONV_WS=1), parity-green, NOT the default.  Measured on MI355X (B=32, 256x256 shapes):
+// within +-7 % of the one-tile-per-workgroup kernel on the 64-wide convs (conv4 86 vs 93 us, conv2 125 vs 122 us)
+// and slower on the cout=16 layers once the second register set lowers occupancy.  Ablations (tools/, EXP_*
+// builds) show why: with every global load and store removed the kernels still take ~75 % of their time, so
+// the limiter is on-chip (LDS fill + fragment reads + MFMA issue + epilogue VALU), not the memory latency
+// that this structure hides.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int WS_THREADS = 512;
 
@@ -437,8 +450,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_ws_kernel(const ConvArgs a
   const int lane = tid & 63;
   const int lq = lane >> 4, lp = lane & 15;
 
-  const int tiles_per_img = a.n_tiles * a.tiles_x * a.tiles_y;
-  const int total_tiles = tiles_per_img * a.B;
+  const int total_tiles = a.n_tiles * a.tiles_x * a.tiles_y * a.B;
   const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int nstages = my_tiles * a.nchunk;
   auto decode = [&](int k) {
@@ -478,10 +490,18 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_ws_kernel(const ConvArgs a
         wsrc_off[it] = (qt * a.cout + c.n0 + n) * 16;
       }
     };
-    uint4 pv[PATCH_IT], wv[W_IT];
-    float ps_[VEC], pb_[VEC];
-    bool chunk_live = false;
-    auto issue = [&](int chunk) {
+    // Two register sets: the loads of stage s+3 are issued while stage s+1 is being written to LDS, so a
+    // request has two full stage times (~2 x 2.3k cycles of MFMA work) to come back.  Measured load-to-use
+    // latency of these 64-byte-segment gathers under load is ~6k cycles: one stage of lookahead was not enough.
+    struct StageRegs {
+      uint4 pv[PATCH_IT];
+      uint4 wv[W_IT];
+      float ps[VEC], pb[VEC];
+      unsigned inside;   // bit it: patch unit `it` lies inside the picture
+      bool live;
+    };
+    StageRegs R0, R1;
+    auto issue = [&](StageRegs& R, int chunk) {
       const int c0 = chunk * KC + q * VEC;
       const char* sbase = nullptr;
       int sstride = 0;
@@ -492,45 +512,49 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_ws_kernel(const ConvArgs a
           sstride = a.seg[sg].stride * (int)sizeof(T);
         }
       }
-      chunk_live = sbase != nullptr;
+      R.live = sbase != nullptr;
+      R.inside = 0;
 #pragma unroll
       for (int it = 0; it < PATCH_IT; ++it) {
-        pv[it] = make_uint4(0, 0, 0, 0);
+        R.pv[it] = make_uint4(0, 0, 0, 0);
         if (it < PATCH_IT - 1 || wave < PATCH_LAST_WAVES)
-          if (chunk_live && gpix[it] >= 0) pv[it] = *reinterpret_cast<const uint4*>(sbase + (size_t)gpix[it] * sstride);
+          if (R.live && gpix[it] >= 0) {
+            R.pv[it] = *reinterpret_cast<const uint4*>(sbase + (size_t)gpix[it] * sstride);
+            R.inside |= 1u << it;
+          }
       }
       const char* wsrc = a.weight + chunk * wchunk_bytes;
 #pragma unroll
       for (int it = 0; it < W_IT; ++it) {
-        wv[it] = make_uint4(0, 0, 0, 0);
+        R.wv[it] = make_uint4(0, 0, 0, 0);
         if (it < W_IT - 1 || wave < W_LAST_WAVES)
-          if (tid + it * LT < W_UNITS) wv[it] = *reinterpret_cast<const uint4*>(wsrc + wsrc_off[it]);
+          if (tid + it * LT < W_UNITS) R.wv[it] = *reinterpret_cast<const uint4*>(wsrc + wsrc_off[it]);
       }
-      if (has_pre && chunk_live) {
+      if (has_pre && R.live) {
         if constexpr (VEC == 8) {
           const float4 s0 = *reinterpret_cast<const float4*>(a.pre_scale + c0), s1 = *reinterpret_cast<const float4*>(a.pre_scale + c0 + 4);
           const float4 b0 = *reinterpret_cast<const float4*>(a.pre_shift + c0), b1 = *reinterpret_cast<const float4*>(a.pre_shift + c0 + 4);
-          ps_[0] = s0.x; ps_[1] = s0.y; ps_[2] = s0.z; ps_[3] = s0.w; ps_[4] = s1.x; ps_[5] = s1.y; ps_[6] = s1.z; ps_[7] = s1.w;
-          pb_[0] = b0.x; pb_[1] = b0.y; pb_[2] = b0.z; pb_[3] = b0.w; pb_[4] = b1.x; pb_[5] = b1.y; pb_[6] = b1.z; pb_[7] = b1.w;
+          R.ps[0] = s0.x; R.ps[1] = s0.y; R.ps[2] = s0.z; R.ps[3] = s0.w; R.ps[4] = s1.x; R.ps[5] = s1.y; R.ps[6] = s1.z; R.ps[7] = s1.w;
+          R.pb[0] = b0.x; R.pb[1] = b0.y; R.pb[2] = b0.z; R.pb[3] = b0.w; R.pb[4] = b1.x; R.pb[5] = b1.y; R.pb[6] = b1.z; R.pb[7] = b1.w;
         } else {
           const float4 s0 = *reinterpret_cast<const float4*>(a.pre_scale + c0);
           const float4 b0 = *reinterpret_cast<const float4*>(a.pre_shift + c0);
-          ps_[0] = s0.x; ps_[1] = s0.y; ps_[2] = s0.z; ps_[3] = s0.w;
-          pb_[0] = b0.x; pb_[1] = b0.y; pb_[2] = b0.z; pb_[3] = b0.w;
+          R.ps[0] = s0.x; R.ps[1] = s0.y; R.ps[2] = s0.z; R.ps[3] = s0.w;
+          R.pb[0] = b0.x; R.pb[1] = b0.y; R.pb[2] = b0.z; R.pb[3] = b0.w;
         }
       }
     };
-    auto store = [&](char* buf) {
+    auto store = [&](const StageRegs& R, char* buf) {
 #pragma unroll
       for (int it = 0; it < PATCH_IT; ++it) {
         if (it < PATCH_IT - 1 || wave < PATCH_LAST_WAVES) {
           if (pdst[it] >= 0) {
-            uint4 v = pv[it];
-            if (has_pre && chunk_live && gpix[it] >= 0) {
+            uint4 v = R.pv[it];
+            if (has_pre && ((R.inside >> it) & 1u)) {
               float f[VEC];
               Vec16<T>::unpack(v, f);
 #pragma unroll
-              for (int i = 0; i < VEC; ++i) f[i] = fmaxf(fmaf(f[i], ps_[i], pb_[i]), 0.0f);
+              for (int i = 0; i < VEC; ++i) f[i] = fmaxf(fmaf(f[i], R.ps[i], R.pb[i]), 0.0f);
               v = Vec16<T>::pack(f);
             }
             *reinterpret_cast<uint4*>(buf + pdst[it]) = v;
@@ -541,26 +565,33 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_ws_kernel(const ConvArgs a
       for (int it = 0; it < W_IT; ++it) {
         if (it < W_IT - 1 || wave < W_LAST_WAVES) {
           const int u = tid + it * LT;
-          if (u < W_UNITS) *reinterpret_cast<uint4*>(buf + 4 * G::PLANE + u * 16) = wv[it];
+          if (u < W_UNITS) *reinterpret_cast<uint4*>(buf + 4 * G::PLANE + u * 16) = R.wv[it];
         }
       }
     };
-    int ld_tile = 0, ld_chunk = 0;
-    auto advance = [&]() {
-      if (++ld_chunk == a.nchunk) { ld_chunk = 0; ++ld_tile; if (ld_tile < my_tiles) set_tile(decode(ld_tile)); }
+    int ld_tile = 0, ld_chunk = 0, issued = 0;   // `issued` = number of stages whose loads have been issued
+    auto issue_next = [&](StageRegs& R) {
+      if (issued >= nstages) return;
+      if (issued > 0 && ++ld_chunk == a.nchunk) { ld_chunk = 0; ++ld_tile; set_tile(decode(ld_tile)); }
+      issue(R, ld_chunk);
+      ++issued;
     };
     set_tile(decode(0));
-    issue(0);
-    store(smem);                                  // stage 0 -> buffer 0
-    if (nstages > 1) { advance(); issue(ld_chunk); }
+    issue_next(R0);                               // stage 0
+    issue_next(R1);                               // stage 1
+    store(R0, smem);                              // stage 0 -> buffer 0
+    issue_next(R0);                               // stage 2
     __syncthreads();
-    for (int s = 0; s < nstages; ++s) {
-      if (s + 1 < nstages) {
-        store(smem + ((s + 1) & 1) * G::BUF_BYTES);   // data issued one iteration ago
-        if (s + 2 < nstages) { advance(); issue(ld_chunk); }
-      }
+    // iteration s writes stage s+1 (register set (s+1)&1) into buffer (s+1)&1, then refills that set with stage s+3
+    int s = 0;
+    for (; s + 1 < nstages; s += 2) {
+      store(R1, smem + G::BUF_BYTES);             // stage s+1 (odd)
+      issue_next(R1);                             // stage s+3
+      __syncthreads();
+      if (s + 2 < nstages) { store(R0, smem); issue_next(R0); }   // stage s+2 (even), then stage s+4
       __syncthreads();
     }
+    if (s < nstages) __syncthreads();             // odd stage count: the consumers' last barrier
   } else {
     // =================================== consumer waves =======================================================
     f32x4 acc[NCS][NPS];
@@ -747,7 +778,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   while ((1 << lg) < a.n_tiles) ++lg;
   if ((1 << lg) != a.n_tiles) { set_error("mdie_conv_fwd: cout / %d = %d output tiles, must be a power of two", BN, a.n_tiles); return MDIE_EINVAL; }
   a.n_tiles_log2 = lg;
-  const dim3 grid(a.n_tiles * a.tiles_x, a.tiles_y, a.B);
+  const dim3 grid(8, a.n_tiles, cdiv(a.tiles_x * a.tiles_y * a.B, 8));
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, BN, TILE>),
