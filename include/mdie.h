@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 6
+#define MDIE_ABI_VERSION 7
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -149,6 +149,9 @@ typedef struct {
   const void* mul;     int mul_stride;  /* optional elementwise multiplicand, or NULL */
   void* out;           int out_stride;
   void* workspace;     size_t workspace_bytes; /* >= mdie_cbam_workspace_bytes */
+  const float* pool_partial; int pool_slabs; /* optional: per-(image, slab) channel sums / maxima of x,
+                                                [B][pool_slabs][2][C], already produced by the kernel that wrote x
+                                                (mdie_upsample2x_add); pass 1 is skipped */
 } mdie_cbam_desc;
 
 size_t mdie_cbam_workspace_bytes(int B, int H, int W, int C);
@@ -189,6 +192,11 @@ int mdie_tail_fwd(const mdie_tail_desc* d, void* stream);
  * align_corners=False) + torch.add, models/cdan.py:137-138,145-146,153-154) */
 int mdie_upsample2x_add(int dtype, int B, int H, int W, int C, const void* lo, int lo_stride,
                         const void* skip, int skip_stride, void* out, int out_stride, void* stream);
+/* Same, additionally reducing the tensor it writes for the CBAM that consumes it next (models/cdan.py:139,147):
+ * pool_partial[B][MDIE_UPSAMPLE_POOL_SLABS][2][C] receives per-slab channel sums and maxima (fp32). */
+#define MDIE_UPSAMPLE_POOL_SLABS 32
+int mdie_upsample2x_add_pool(int dtype, int B, int H, int W, int C, const void* lo, int lo_stride,
+                             const void* skip, int skip_stride, void* out, int out_stride, float* pool_partial, void* stream);
 
 /* Same, for the last decoder stage where the skip is the network input itself (`torch.add(out, x)`,
  * models/cdan.py:153-154): lo NHWC [B,H,W,lo_stride] (channels 0..2), x fp32 NCHW [B,3,2H,2W],

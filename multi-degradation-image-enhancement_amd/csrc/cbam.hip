@@ -1,6 +1,6 @@
 // CBAM (models/cbam.py:84-95) on NHWC tensors, four HBM-bound passes:
 //   pool      per-(image, channel) sum / max over H*W          ChannelGate pools, cbam.py:41,44
-//   gate      sigmoid(MLP(avg) + MLP(max))                     cbam.py:30-35,42-59
+//   gate      sigmoid(MLP(avg) + MLP(max))                     cbam.py:30-35,42-59  (folded into chanpool's prologue)
 //   chanpool  per-pixel max / mean over channels of x*gate     ChannelPool, cbam.py:68-70
 //   spatial   sigmoid(BN(conv7x7(map))) ; out = x*gate*s [*mul]  SpatialGate, cbam.py:72-82
 // The channel-scaled tensor x*gate is never written: passes 3 and 4 recompute it from x.
@@ -69,15 +69,10 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_pool_kernel(const CbamArgs a)
 // One block per image.  The hidden layer is split over (unit j, part q): 256/Hd parts per unit, each
 // part a contiguous run of C/parts channels for BOTH pooled vectors, so all weight loads of the block
 // are issued at once (a per-output loop serialises 2*Hd cold-miss round trips: 42 us at C=512).
-__global__ __launch_bounds__(CB_THREADS) void cbam_gate_kernel(const CbamArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char dyn[];
-  float* avg = reinterpret_cast<float*>(dyn);  // [C]
-  float* mx = avg + a.C;                       // [C]
-  float* part = mx + a.C;                      // [2][CB_THREADS]
-  float* hid = part + 2 * CB_THREADS;          // [Hd]  (h_avg + h_max)
+// gate[c] of image `img` into LDS (`gate`, [C]); scratch: avg[C], mx[C], part[2*CB_THREADS], hid[Hd]
+__device__ __forceinline__ void cbam_gate_block(const CbamArgs& a, int img, float* avg, float* mx, float* part, float* hid, float* gate) {
   const int Hd = a.C / 16;
   const int tid = threadIdx.x;
-  const int img = blockIdx.x;
   const float inv = 1.0f / (float)(a.H * a.W);
   for (int c = tid; c < a.C; c += CB_THREADS) {
     float s = 0.f, m = -INFINITY;
@@ -117,8 +112,21 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_gate_kernel(const CbamArgs a)
     float s = 2.0f * a.b2[c];  // the MLP (bias included) is applied to both pooled vectors
     const float* w = a.w2 + (size_t)c * Hd;
     for (int j = 0; j < Hd; ++j) s = fmaf(w[j], hid[j], s);
-    a.gate[(size_t)img * a.C + c] = sigmoidf(s);
+    gate[c] = sigmoidf(s);
   }
+  __syncthreads();
+}
+
+// standalone gate launch: only the channel-gate-only path (CBAM(no_spatial=True)) still uses it
+__global__ __launch_bounds__(CB_THREADS) void cbam_gate_kernel(const CbamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  float* avg = reinterpret_cast<float*>(dyn);
+  float* mx = avg + a.C;
+  float* part = mx + a.C;
+  float* hid = part + 2 * CB_THREADS;
+  float* gate = hid + a.C / 16;
+  cbam_gate_block(a, blockIdx.x, avg, mx, part, hid, gate);
+  for (int c = threadIdx.x; c < a.C; c += CB_THREADS) a.gate[(size_t)blockIdx.x * a.C + c] = gate[c];
 }
 
 // ---- pass 3 ----------------------------------------------------------------------------------------
@@ -131,11 +139,22 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_chanpool_kernel(const CbamArg
   const int npix = a.H * a.W;
   const int sub = tid % LPP;                 // lane within the pixel group
   const int groups = CB_THREADS / LPP;       // pixels in flight per block
+  // pass 2 folded in: every block derives the image's channel gate from the pooled partials (a few k MACs,
+  // weights L2-resident) instead of waiting for a separate 32-block launch; block 0 publishes it for pass 4
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  float* avg = reinterpret_cast<float*>(dyn);
+  float* mx = avg + a.C;
+  float* part = mx + a.C;
+  float* hid = part + 2 * CB_THREADS;
+  float* gsh = hid + a.C / 16;
+  cbam_gate_block(a, img, avg, mx, part, hid, gsh);
+  if (blockIdx.x == 0)
+    for (int c = tid; c < a.C; c += CB_THREADS) a.gate[(size_t)img * a.C + c] = gsh[c];
   float g[NV][VEC];
 #pragma unroll
   for (int k = 0; k < NV; ++k)
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) g[k][i] = a.gate[(size_t)img * a.C + (k * LPP + sub) * VEC + i];
+    for (int i = 0; i < VEC; ++i) g[k][i] = gsh[(k * LPP + sub) * VEC + i];
   const float invC = 1.0f / (float)a.C;
   for (int p = blockIdx.x * groups + tid / LPP; p < npix; p += gridDim.x * groups) {
     const char* px = a.x + ((size_t)img * npix + p) * a.x_stride * sizeof(T);
@@ -247,17 +266,21 @@ static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
   a.map = reinterpret_cast<float*>(ws);
 
   const int CV = d->C / VEC;
-  {
+  const size_t gate_lds = (size_t)(3 * d->C + 2 * CB_THREADS + d->C / 16) * sizeof(float);
+  if (d->pool_partial) {
+    // the producer of x already reduced it (mdie_upsample2x_add with pool_partial): skip pass 1
+    a.partial = const_cast<float*>(d->pool_partial);
+    a.nslab = d->pool_slabs;
+  } else {
     const int rows = CB_THREADS / CV;
     const size_t lds = (size_t)2 * rows * d->C * sizeof(float);
     TimedLaunch tl(MDIE_K_CBAM_POOL);
     hipLaunchKernelGGL((cbam_pool_kernel<T>), dim3(a.nslab, d->B), dim3(CB_THREADS), lds, stream, a);
     MDIE_LAUNCH_CHECK("cbam_pool");
   }
-  {
-    const size_t lds = (size_t)(2 * d->C + 2 * CB_THREADS + d->C / 16) * sizeof(float);
+  if (!spatial) {
     TimedLaunch tl(MDIE_K_CBAM_GATE);
-    hipLaunchKernelGGL(cbam_gate_kernel, dim3(d->B), dim3(CB_THREADS), lds, stream, a);
+    hipLaunchKernelGGL(cbam_gate_kernel, dim3(d->B), dim3(CB_THREADS), gate_lds, stream, a);
     MDIE_LAUNCH_CHECK("cbam_gate");
   }
   if (spatial) {
@@ -265,10 +288,14 @@ static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
     const int NV = CV / LPP;
     const int groups = CB_THREADS / LPP;
     int gx = cdiv(d->H * d->W, groups * 4);
+    // every block re-derives the gate: keep the block count per image moderate for the wide tensors, whose MLP
+    // weights are 32-128 KB (L2 reads per block)
+    const int cap = d->C >= 256 ? 16 : 64;
+    if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     TimedLaunch tl(MDIE_K_CBAM_CHANPOOL);
-    if (NV == 1) hipLaunchKernelGGL((cbam_chanpool_kernel<T, 1>), dim3(gx, d->B), dim3(CB_THREADS), 0, stream, a, LPP);
-    else if (NV == 2) hipLaunchKernelGGL((cbam_chanpool_kernel<T, 2>), dim3(gx, d->B), dim3(CB_THREADS), 0, stream, a, LPP);
+    if (NV == 1) hipLaunchKernelGGL((cbam_chanpool_kernel<T, 1>), dim3(gx, d->B), dim3(CB_THREADS), gate_lds, stream, a, LPP);
+    else if (NV == 2) hipLaunchKernelGGL((cbam_chanpool_kernel<T, 2>), dim3(gx, d->B), dim3(CB_THREADS), gate_lds, stream, a, LPP);
     else { set_error("mdie_cbam_fwd: C = %d too wide", d->C); return MDIE_EINVAL; }
     MDIE_LAUNCH_CHECK("cbam_chanpool");
   }
@@ -293,6 +320,7 @@ static int check_cbam(const mdie_cbam_desc* d) {
   MDIE_REQUIRE(d->x && d->out && d->w1 && d->b1 && d->w2 && d->b2 && d->w7 && d->bn && d->workspace, "mdie_cbam_fwd: null pointer");
   MDIE_REQUIRE(d->x_stride % 16 == 0 && d->out_stride % 16 == 0 && (!d->mul || d->mul_stride % 16 == 0), "mdie_cbam_fwd: strides must be multiples of 16");
   MDIE_REQUIRE(((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->out & 15) == 0 && ((uintptr_t)d->mul & 15) == 0, "mdie_cbam_fwd: alignment");
+  MDIE_REQUIRE(!d->pool_partial || (d->pool_slabs >= 1 && d->pool_slabs <= 64), "mdie_cbam_fwd: pool_slabs %d", d->pool_slabs);
   if (d->workspace_bytes < mdie_cbam_workspace_bytes(d->B, d->H, d->W, d->C)) {
     set_error("mdie_cbam_fwd: workspace %zu < %zu", d->workspace_bytes, mdie_cbam_workspace_bytes(d->B, d->H, d->W, d->C));
     return MDIE_ENOSPC;

@@ -206,6 +206,7 @@ struct Buf { size_t off; int C; };  // NHWC, stride == C
 struct Plan {
   Buf x16, o[3], g[3][4], d[3], e, bott, t1, u1, t2lo, t2, u2, t3lo, t3, u3, t4lo, t4, fg[4], out16;
   size_t cbam_ws, cbam_ws_bytes;
+  size_t pool_ws;   // [B][MDIE_UPSAMPLE_POOL_SLABS][2][128] floats: pooled partials written by upsample+skip
   size_t total;
 };
 
@@ -234,6 +235,7 @@ static Plan make_plan(int dtype, int B, int H, int W) {
   const int ch[4] = {512, 256, 128, 64}, chh[4] = {h3, h3, h2, h1}, cww[4] = {w3, w3, w2, w1};
   for (int i = 0; i < 4; ++i) { size_t b = mdie_cbam_workspace_bytes(B, chh[i], cww[i], ch[i]); cb = b > cb ? b : cb; }
   P.cbam_ws = off; P.cbam_ws_bytes = cb; off += align256(cb);
+  P.pool_ws = off; off += align256((size_t)B * MDIE_UPSAMPLE_POOL_SLABS * 2 * 128 * sizeof(float));
   P.total = off;
   return P;
 }
@@ -427,7 +429,8 @@ static int run_dense(const Ctx& c, int block, int H, int W, const Buf& base, con
   return run_conv(c, id0 + 4, H, W, {base, g[0], g[1], g[2], g[3]}, out, act, 0, nullptr, out_nchw3);
 }
 
-static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, const Buf& x, const Buf* mul, const Buf& out) {
+static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, const Buf& x, const Buf* mul, const Buf& out,
+                          bool pooled = false) {
   const CbamBlob& o = c.L.cbam[id];
   mdie_cbam_desc d{};
   d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.C = arch().cbam[id].C;
@@ -439,11 +442,14 @@ static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, con
   if (mul) { d.mul = c.ws + mul->off; d.mul_stride = mul->C; }
   d.out = c.ws + out.off; d.out_stride = out.C;
   d.workspace = c.ws + P.cbam_ws; d.workspace_bytes = P.cbam_ws_bytes;
+  if (pooled) { d.pool_partial = reinterpret_cast<const float*>(c.ws + P.pool_ws); d.pool_slabs = MDIE_UPSAMPLE_POOL_SLABS; }
   return mdie_cbam_fwd(&d, c.stream);
 }
 
-static int run_up(const Ctx& c, int H, int W, const Buf& lo, const Buf& skip, const Buf& out) {
-  return mdie_upsample2x_add(c.dtype, c.B, H, W, lo.C, c.ws + lo.off, lo.C, c.ws + skip.off, skip.C, c.ws + out.off, out.C, c.stream);
+static int run_up(const Ctx& c, const Plan& P, int H, int W, const Buf& lo, const Buf& skip, const Buf& out) {
+  // the upsampled + skip tensor feeds a CBAM: reduce it for the channel gate while writing it
+  return mdie_upsample2x_add_pool(c.dtype, c.B, H, W, lo.C, c.ws + lo.off, lo.C, c.ws + skip.off, skip.C, c.ws + out.off, out.C,
+                                  reinterpret_cast<float*>(c.ws + P.pool_ws), c.stream);
 }
 
 static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
@@ -499,13 +505,13 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   RUN(join_dense(2));
   RUN(run_cbam_stage(c, P, CB_1, h3, w3, P.t1, &P.d[2], P.u1));                     // cbam1, *= dense3
   RUN(run_conv(c, CV_D2, h3, w3, {P.u1}, P.t2lo, MDIE_ACT_RELU, 0, nullptr));
-  RUN(run_up(c, h3, w3, P.t2lo, P.o[1], P.t2));                                     // bilinear x2 + skip1
+  RUN(run_up(c, P, h3, w3, P.t2lo, P.o[1], P.t2));                                     // bilinear x2 + skip1
   RUN(join_dense(1));
-  RUN(run_cbam_stage(c, P, CB_2, h2, w2, P.t2, &P.d[1], P.u2));
+  RUN(run_cbam_stage(c, P, CB_2, h2, w2, P.t2, &P.d[1], P.u2, true));
   RUN(run_conv(c, CV_D3, h2, w2, {P.u2}, P.t3lo, MDIE_ACT_RELU, 0, nullptr));
-  RUN(run_up(c, h2, w2, P.t3lo, P.o[0], P.t3));
+  RUN(run_up(c, P, h2, w2, P.t3lo, P.o[0], P.t3));
   RUN(join_dense(0));
-  RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3));
+  RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3, true));
   RUN(run_conv(c, CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
   if (!(d->flags & MDIE_FWD_FUSED_TAIL)) {
     // bilinear x2 + x (x read from its fp32 NCHW planes), final_dense, sigmoid written straight to NCHW

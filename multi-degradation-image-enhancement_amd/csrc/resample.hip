@@ -51,6 +51,64 @@ __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_kernel(int B, int H
   }
 }
 
+// upsample + skip that also reduces what it writes (the next kernel is a CBAM whose first pass is exactly this
+// reduction): grid (slabs, B); thread = (channel vector v, pixel row r); per-slab sums / maxima -> partial[b][slab][2][C]
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void upsample2x_add_pool_kernel(int H, int W, int C, const char* lo, int lo_stride, const char* skip,
+                                                                         int skip_stride, char* out, int out_stride, float* partial) {
+  constexpr int VEC = Traits<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  const int CV = C / VEC;
+  const int rows = RS_THREADS / CV;
+  float* rsum = reinterpret_cast<float*>(dyn);
+  float* rmax = rsum + rows * C;
+  const int Ho = 2 * H, Wo = 2 * W, npix = Ho * Wo;
+  const int img = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
+  const int per = (npix + nslab - 1) / nslab;
+  const int p_begin = slab * per, p_end = min(npix, p_begin + per);
+  const int v = threadIdx.x % CV, r = threadIdx.x / CV;
+  float s[VEC], m[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s[i] = 0.f; m[i] = -INFINITY; }
+  const char* base = lo + (size_t)img * H * W * lo_stride * sizeof(T) + (size_t)v * 16;
+  if (r < rows) {
+    for (int p = p_begin + r; p < p_end; p += rows) {
+      const int oy = p / Wo, ox = p - oy * Wo;
+      int y0, y1, x0, x1;
+      float hy0, hy1, wx0, wx1;
+      src_index(oy, H, y0, y1, hy0, hy1);
+      src_index(ox, W, x0, x1, wx0, wx1);
+      auto at = [&](int y, int x) { return *reinterpret_cast<const uint4*>(base + ((size_t)y * W + x) * lo_stride * sizeof(T)); };
+      float a00[VEC], a01[VEC], a10[VEC], a11[VEC], sk[VEC], rr[VEC];
+      Vec16<T>::unpack(at(y0, x0), a00);
+      Vec16<T>::unpack(at(y0, x1), a01);
+      Vec16<T>::unpack(at(y1, x0), a10);
+      Vec16<T>::unpack(at(y1, x1), a11);
+      const size_t op = (size_t)img * npix + p;
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(skip + op * skip_stride * sizeof(T) + (size_t)v * 16), sk);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) rr[i] = hy0 * (wx0 * a00[i] + wx1 * a01[i]) + hy1 * (wx0 * a10[i] + wx1 * a11[i]) + sk[i];
+      const uint4 packed = Vec16<T>::pack(rr);
+      *reinterpret_cast<uint4*>(out + op * out_stride * sizeof(T) + (size_t)v * 16) = packed;
+      // reduce the STORED values (bf16-rounded), exactly what a separate pool pass over `out` would read
+      float q[VEC];
+      Vec16<T>::unpack(packed, q);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { s[i] += q[i]; m[i] = fmaxf(m[i], q[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { rsum[r * C + v * VEC + i] = s[i]; rmax[r * C + v * VEC + i] = m[i]; }
+  }
+  __syncthreads();
+  float* dst = partial + ((size_t)img * nslab + slab) * 2 * C;
+  for (int c = threadIdx.x; c < C; c += RS_THREADS) {
+    float ss = 0.f, mm = -INFINITY;
+    for (int k = 0; k < rows; ++k) { ss += rsum[k * C + c]; mm = fmaxf(mm, rmax[k * C + c]); }
+    dst[c] = ss;
+    dst[C + c] = mm;
+  }
+}
+
 // last decoder stage: out[B,2H,2W,16] = bilinear_x2(lo)[:, :3] + x (fp32 NCHW), one output pixel per thread
 template <typename T>
 __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_nchw3_kernel(int B, int H, int W, const T* lo, int lo_stride,
@@ -180,6 +238,29 @@ extern "C" int mdie_upsample2x_add(int dtype, int B, int H, int W, int C, const 
     hipLaunchKernelGGL((upsample2x_add_kernel<mdie::bf16>), dim3(grid_for(total)), dim3(RS_THREADS), 0, s, B, H, W, C, (const char*)lo,
                        lo_stride, (const char*)skip, skip_stride, (char*)out, out_stride);
   MDIE_LAUNCH_CHECK("mdie_upsample2x_add");
+  return MDIE_OK;
+}
+
+extern "C" int mdie_upsample2x_add_pool(int dtype, int B, int H, int W, int C, const void* lo, int lo_stride, const void* skip,
+                                        int skip_stride, void* out, int out_stride, float* pool_partial, void* stream) {
+  if (int e = check_layout("mdie_upsample2x_add_pool", dtype, B, C, H, W, lo, out)) return e;
+  MDIE_REQUIRE(skip != nullptr && pool_partial != nullptr, "mdie_upsample2x_add_pool: null skip / pool_partial");
+  MDIE_REQUIRE(C % 16 == 0 && C <= 512 && (C & (C - 1)) == 0 && lo_stride % 16 == 0 && skip_stride % 16 == 0 && out_stride % 16 == 0,
+               "mdie_upsample2x_add_pool: C must be a power of two <= 512, strides multiples of 16");
+  MDIE_REQUIRE((((uintptr_t)lo | (uintptr_t)skip | (uintptr_t)out) & 15) == 0, "mdie_upsample2x_add_pool: alignment");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int vec = dtype == MDIE_F32 ? 4 : 8;
+  const int rows = RS_THREADS / (C / vec);
+  const size_t lds = (size_t)2 * rows * C * sizeof(float);
+  TimedLaunch tl(MDIE_K_UPSAMPLE);
+  const dim3 grid(MDIE_UPSAMPLE_POOL_SLABS, B);
+  if (dtype == MDIE_F32)
+    hipLaunchKernelGGL((upsample2x_add_pool_kernel<float>), grid, dim3(RS_THREADS), lds, s, H, W, C, (const char*)lo, lo_stride, (const char*)skip,
+                       skip_stride, (char*)out, out_stride, pool_partial);
+  else
+    hipLaunchKernelGGL((upsample2x_add_pool_kernel<mdie::bf16>), grid, dim3(RS_THREADS), lds, s, H, W, C, (const char*)lo, lo_stride,
+                       (const char*)skip, skip_stride, (char*)out, out_stride, pool_partial);
+  MDIE_LAUNCH_CHECK("mdie_upsample2x_add_pool");
   return MDIE_OK;
 }
 

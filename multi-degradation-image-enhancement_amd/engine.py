@@ -225,6 +225,7 @@ def cbam_fwd(x, w1, b1, w2, b2, w7, bn, *, dtype, mul=None, channel_only=False):
     d.mul_stride = mul.stride(2) if mul is not None else 0
     d.out, d.out_stride = out.data_ptr(), out.stride(2)
     d.workspace, d.workspace_bytes = ws.data_ptr(), n
+    d.pool_partial, d.pool_slabs = None, 0
     fn = L.lib.mdie_cbam_channel_only_fwd if channel_only else L.lib.mdie_cbam_fwd
     L.check(fn(C.byref(d), _stream_ptr(x.device)), "mdie_cbam_fwd")
     return out

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 6
+ABI_VERSION = 7
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 
@@ -50,7 +50,8 @@ class CbamDesc(C.Structure):
                 ("w7", C.c_void_p), ("bn", C.c_void_p),
                 ("mul", C.c_void_p), ("mul_stride", C.c_int),
                 ("out", C.c_void_p), ("out_stride", C.c_int),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("pool_partial", C.c_void_p), ("pool_slabs", C.c_int)]
 
 
 class Tensor(C.Structure):
@@ -97,6 +98,8 @@ SIGNATURES = {
     "mdie_tail_fwd": (C.c_int, [C.POINTER(TailDesc), C.c_void_p]),
     "mdie_upsample2x_add": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mdie_upsample2x_add_pool": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mdie_upsample2x_add_nchw3": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdie_nchw3_to_nhwc16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdie_nhwc16_to_nchw3": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -292,6 +292,24 @@ def test_up2_add(E, golden_dir, precision):
     assert err <= (1e-6 if precision == "fp32" else BF16_TOL), f"{err:.3e}"
 
 
+def test_up2_add_with_fused_pool(E, L):
+    """upsample + skip that also emits the CBAM pooling partials of what it wrote."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(3)
+    for dt, td in ((L.F32, torch.float32), (L.BF16, torch.bfloat16)):
+        lo = torch.randn(2, 6, 10, 64, generator=g).cuda().to(td)
+        skip = torch.randn(2, 12, 20, 64, generator=g).cuda().to(td)
+        ref = E.upsample2x_add(lo, skip, dtype=dt)
+        out = torch.empty_like(skip)
+        part = torch.zeros(2, 32, 2, 64, device="cuda")
+        L.check(L.lib.mdie_upsample2x_add_pool(dt, 2, 6, 10, 64, lo.data_ptr(), 64, skip.data_ptr(), 64, out.data_ptr(), 64,
+                                               part.data_ptr(), None), "mdie_upsample2x_add_pool")
+        assert torch.equal(out, ref)
+        o = out.float().reshape(2, -1, 64)
+        assert torch.allclose(part[:, :, 0].sum(1), o.sum(1), rtol=1e-5, atol=1e-3)
+        assert torch.equal(part[:, :, 1].amax(1), o.amax(1))
+
+
 def test_conv_rejects_bad_arguments(E, L):
     x = torch.zeros(1, 4, 4, 16, device="cuda")
     w = torch.zeros(L.lib.mdie_conv_weight_bytes(L.F32, 3, 16, 16), dtype=torch.uint8, device="cuda")
