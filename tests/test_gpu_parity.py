@@ -304,7 +304,8 @@ def test_up2_add_with_fused_pool(E, L):
         part = torch.zeros(2, 32, 2, 64, device="cuda")
         L.check(L.lib.mdie_upsample2x_add_pool(dt, 2, 6, 10, 64, lo.data_ptr(), 64, skip.data_ptr(), 64, out.data_ptr(), 64,
                                                part.data_ptr(), None), "mdie_upsample2x_add_pool")
-        assert torch.equal(out, ref)
+        # same formula, separately compiled: FMA contraction may differ by an ulp
+        assert torch.allclose(out.float(), ref.float(), rtol=1e-2 if dt == L.BF16 else 1e-6, atol=1e-6)
         o = out.float().reshape(2, -1, 64)
         assert torch.allclose(part[:, :, 0].sum(1), o.sum(1), rtol=1e-5, atol=1e-3)
         assert torch.equal(part[:, :, 1].amax(1), o.amax(1))
