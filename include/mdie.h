@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 7
+#define MDIE_ABI_VERSION 8
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -104,6 +104,36 @@ int mdie_conv_fwd(const mdie_conv_desc* d, void* stream);
 size_t mdie_conv_weight_bytes(int dtype, int ksize, int cin_stored, int cout_stored);
 int mdie_pack_conv_weight(int dtype, int ksize, int transposed, const float* w, int cout, int cin,
                           int cout_stored, int cin_stored, int split, int gap, void* dst);
+
+/* ---------------------------------------------------------------------------------
+ * Training (models/model.py:159-166: forward, loss, backward, Adam).  The convolutions carry ~97 % of the
+ * FLOPs of a step; their three GEMMs run here:
+ *   forward  mdie_conv_fwd
+ *   dgrad    mdie_conv_fwd on weights repacked with the opposite `transposed` flag (the input gradient of a
+ *            3x3 / pad 1 convolution is a convolution with the flipped, in/out-swapped kernel)
+ *   wgrad    mdie_conv_wgrad: dW = sum over pixels of X (shifted per tap) x dY, exact-f32 MFMA, deterministic
+ * mdie_pack_conv_weight_dev is mdie_pack_conv_weight on the GPU (weights change every step).
+ * --------------------------------------------------------------------------------- */
+int mdie_pack_conv_weight_dev(int dtype, int ksize, int transposed, const float* w_dev, int cout, int cin,
+                              int cout_stored, int cin_stored, int split, int gap, void* dst_dev, void* stream);
+
+typedef struct {
+  int dtype;               /* element type of x segments and dy */
+  int B, H, W;
+  int ksize;               /* 3 or 1 */
+  int transposed;          /* layout of dw: 0 = [cout][cin][k][k] (nn.Conv2d), 1 = [cin][cout][k][k] flipped (nn.ConvTranspose2d) */
+  int nseg;
+  mdie_seg in[MDIE_MAX_SEG];   /* the convolution's input (stored channels, NHWC) */
+  int cin, cout;           /* real channel counts of dw */
+  int cout_stored;         /* stored channels of dy */
+  int split, gap;          /* real input channel c >= split is stored at c + gap */
+  const void* dy; int dy_stride;
+  float* dw;               /* fp32, PyTorch layout */
+  void* workspace; size_t workspace_bytes;   /* >= mdie_conv_wgrad_workspace_bytes */
+} mdie_wgrad_desc;
+
+size_t mdie_conv_wgrad_workspace_bytes(int B, int H, int W, int ksize, int cin_stored, int cout_stored);
+int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream);
 
 /* First layer, straight from the network input: out = pool2x2?(act(conv3x3(x) * post_scale + post_shift))
  * with x fp32 NCHW [B,3,H,W] (encoder.conv1 + maxpool, models/cdan.py:58,74-75).  K = 27 is im2col'ed

@@ -12,7 +12,8 @@ Differences that matter on MI355X: the `Normalize(mean 0, std 1) -> ToTensorV2` 
 transform list is executed ON THE GPU (uint8 HWC batches cross PCIe pinned and asynchronously, 4x fewer
 bytes than fp32; `mdie_u8hwc_to_f32nchw`), post-processing / uint8 conversion / PSNR / SSIM run as HIP
 kernels on the output while it is still in HBM.  LPIPS and the VGG loss need downloaded weights and are
-skipped with a warning.  Training is not built yet (`Model.train` raises).
+skipped with a warning.  `Model.train()` runs the training-mode graph of mdie_amd.train (HIP convolutions
+forward/dgrad/wgrad under autograd) with Adam and, under torch.distributed, bucketed gradient all-reduce.
 """
 import csv
 import importlib
@@ -220,6 +221,55 @@ class RunLogger:
         pass
 
 
+# ---- losses (utils/loss_factory.py:146-230; terms that need downloaded networks are skipped) ----------------------------------
+def _ssim_torch(p, t):
+    """Differentiable SSIM with torchmetrics' default arguments (see csrc/post.hip / oracle.metrics_oracle)."""
+    L_ = torch.maximum(p.max() - p.min(), t.max() - t.min()).detach()
+    c1, c2 = (0.01 * L_) ** 2, (0.03 * L_) ** 2
+    d = torch.arange(-5, 6, dtype=p.dtype, device=p.device)
+    g = torch.exp(-0.5 * (d / 1.5) ** 2)
+    g = g / g.sum()
+    k = (g[:, None] * g[None, :]).reshape(1, 1, 11, 11).repeat(p.shape[1], 1, 1, 1)
+    f = lambda z: torch.nn.functional.conv2d(z, k, groups=z.shape[1])
+    mp, mt = f(p), f(t)
+    spp, stt, spt = f(p * p) - mp * mp, f(t * t) - mt * mt, f(p * t) - mp * mt
+    m = ((2 * mp * mt + c1) * (2 * spt + c2)) / ((mp * mp + mt * mt + c1) * (spp + stt + c2))
+    return m.reshape(m.shape[0], -1).mean(-1).mean()
+
+
+def _sobel(x):
+    kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]], device=x.device, dtype=x.dtype)
+    k = torch.stack((kx, kx.t()), 0).unsqueeze(1).repeat(x.shape[1], 1, 1, 1)
+    b, c, h, w = x.shape
+    return torch.nn.functional.conv2d(x.reshape(b * c, 1, h, w), k[:2], padding=1)
+
+
+def build_losses(loss_cfg):
+    terms = []
+    for t in ((loss_cfg or {}).get("terms") or []) if (loss_cfg or {}).get("enabled", True) else []:
+        name, weight, args = t["name"], float(t.get("weight", 1.0)), (t.get("args") or {})
+        if name == "mse":
+            fn = lambda o, y: torch.mean((o - y) ** 2)
+        elif name == "l1":
+            fn = lambda o, y: torch.mean(torch.abs(o - y))
+        elif name == "charbonnier":
+            eps = float(args.get("eps", 1e-3))
+            fn = lambda o, y, eps=eps: torch.mean(torch.sqrt((o - y) ** 2 + eps * eps))
+        elif name == "ssim":
+            fn = lambda o, y: 1.0 - _ssim_torch(o, y)
+        elif name == "gradient_l1":
+            gray = bool(args.get("to_gray", False))
+            lum = lambda z: 0.2989 * z[:, 0:1] + 0.5870 * z[:, 1:2] + 0.1140 * z[:, 2:3]
+            fn = lambda o, y, gray=gray: torch.mean(torch.abs(_sobel(lum(o) if gray else o) - _sobel(lum(y) if gray else y)))
+        elif name in ("vgg_perceptual", "lpips"):
+            warnings.warn(f"loss term '{name}' needs downloaded network weights and is skipped on the offline MI355X path")
+            continue
+        else:
+            raise ValueError(f"Unknown loss term: {name}")
+        terms.append((name, weight, fn))
+    return terms
+
+
 # ---- model harness ------------------------------------------------------------------------------------------------------
 class Model:
     """Same constructor and entry points as models.model.Model (models/model.py:26, models/base.py:12,35-42)."""
@@ -253,7 +303,58 @@ class Model:
 
     # -- reference entry points --
     def train(self):
-        raise NotImplementedError("training (models/model.py:138-227) is not built on the MI355X engine yet; use -p test")
+        since = time.time()
+        self.train_step()
+        t = time.time() - since
+        print(f"Training completed in {t // 60:.0f}m {t % 60:.0f}s")
+
+    def train_step(self):
+        """models/model.py:138-227: Adam(lr), loss pipeline, best-on-train-loss checkpoint.  No GradScaler: the
+        HIP convolutions accumulate in fp32 and activations are fp32 or bf16 (no fp16 overflow to guard)."""
+        import torch.distributed as dist
+        from . import train as T
+        tr = self.config["train"]
+        n_epoch, lr = int(tr["n_epoch"]), float(tr["lr"])
+        losses = build_losses(self.config.get("loss"))
+        if not losses:
+            raise ValueError("training needs at least one usable loss term")
+        opt = torch.optim.Adam(self.network.parameters(), lr=lr)
+        buckets = T.GradBuckets(self.network.parameters()) if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
+        best = float("inf")
+        self.history = []
+        for epoch in range(n_epoch):
+            t0 = time.time()
+            self.network.train()
+            sums, n = {}, 0
+            for inputs, targets in self.dataloader:
+                x, y = self._to_device(inputs), self._to_device(targets)
+                opt.zero_grad(set_to_none=False)
+                out = self.network(x)
+                parts = {name: fn(out, y) for name, _, fn in losses}
+                total = sum(w * parts[name] for name, w, _ in losses)
+                total.backward()
+                if buckets is not None:
+                    buckets.finish()     # averaged gradients (RCCL all-reduce launched from the grad hooks during backward)
+                opt.step()
+                vals = torch.stack([total.detach()] + [parts[name].detach() for name, _, _ in losses]).cpu().tolist()  # one sync per step
+                for k, v in zip(["total"] + [name for name, _, _ in losses], vals):
+                    sums[k] = sums.get(k, 0.0) + v
+                n += 1
+            avg = {k: v / max(1, n) for k, v in sums.items()}
+            if avg["total"] < best:
+                best = avg["total"]
+                if not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0:
+                    self.save_model(self.network)
+            self.history.append(avg)
+            print(f"Epoch [{epoch + 1}/{n_epoch}] Train total: {avg['total']:.4f} | " +
+                  ", ".join(f"{k}: {v:.4f}" for k, v in avg.items() if k != "total") + f" | best: {best:.4f}")
+            if self.logger is not None:
+                row = {"type": "epoch", "epoch": epoch + 1, "epoch_time_sec": time.time() - t0, "lr": lr, "best_loss_so_far": best}
+                row.update({f"loss_{k}": v for k, v in avg.items()})
+                self.logger.log("train", row)
+        if buckets is not None:
+            buckets.remove()
+        return self.history
 
     def test(self):
         self.test_step()

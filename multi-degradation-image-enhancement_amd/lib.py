@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 7
+ABI_VERSION = 8
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 
@@ -35,6 +35,13 @@ class ConvDesc(C.Structure):
                 ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int), ("pool", C.c_int),
                 ("residual", C.c_void_p), ("res_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int),
                 ("out_nchw3", C.c_void_p)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("ksize", C.c_int), ("transposed", C.c_int),
+                ("nseg", C.c_int), ("inp", Seg * MAX_SEG), ("cin", C.c_int), ("cout", C.c_int), ("cout_stored", C.c_int),
+                ("split", C.c_int), ("gap", C.c_int), ("dy", C.c_void_p), ("dy_stride", C.c_int), ("dw", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 class ConvFirstDesc(C.Structure):
@@ -87,6 +94,10 @@ SIGNATURES = {
     "mdie_conv_weight_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mdie_pack_conv_weight": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p]),
+    "mdie_pack_conv_weight_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p]),
+    "mdie_conv_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mdie_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     "mdie_conv_first_fwd": (C.c_int, [C.POINTER(ConvFirstDesc), C.c_void_p]),
     "mdie_conv_first_weight_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mdie_pack_conv_first_weight": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

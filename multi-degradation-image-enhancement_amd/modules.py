@@ -70,6 +70,7 @@ class CDAN(nn.Module):
         super().__init__()
         _attach(self, arch.cdan_param_spec())
         self.precision = precision or os.environ.get("MDIE_PRECISION", "fp32")
+        self.dropout_p = 0.2      # nn.Dropout(0.2), models/cdan.py:68 (training mode only)
         self._engines = {}
         self._packed = {}
 
@@ -86,14 +87,11 @@ class CDAN(nn.Module):
         return eng
 
     def forward(self, x):
-        if self.training or torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x.requires_grad:
-            pass
-        if self.training:
-            raise NotImplementedError(
-                "CDAN.forward in training mode: the MI355X engine currently implements the eval path "
-                "(network.eval(), models/model.py:232); call .eval() first")
         if not x.is_cuda:
             raise L.MdieError(f"CDAN.forward: input is on {x.device}; this engine runs on the GPU only (no CPU fallback)")
+        if self.training:
+            from . import train as T   # batch-statistic BatchNorm, dropout, autograd through the HIP convolutions
+            return T.forward_train(self, x, self.precision, self.dropout_p)
         return self._engine(x.device).forward(x)
 
     def forward_with_taps(self, x):

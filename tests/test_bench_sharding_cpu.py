@@ -39,3 +39,46 @@ def test_two_rank_timing_and_sharding():
     for rank, t, sums in res:
         assert t == 2.0                      # max over ranks, identical on every rank
         assert sums[0] != sums[1]            # ranks hold different batches
+
+
+def _bucket_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mdie_amd.train import GradBuckets
+    torch.manual_seed(0)                       # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(12, 20), torch.nn.ReLU(), torch.nn.Linear(20, 7), torch.nn.Linear(7, 3))
+    buckets = GradBuckets(net.parameters(), n_buckets=3)
+    g = torch.Generator().manual_seed(100 + rank)   # different shard per rank
+    x = torch.randn(5, 12, generator=g)
+    net(x).pow(2).mean().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    buckets.finish()
+    gathered = []
+    for p, l in zip(net.parameters(), local):
+        parts = [torch.zeros_like(l) for _ in range(world)]
+        dist.all_gather(parts, l)
+        gathered.append(torch.allclose(p.grad, sum(parts) / world, atol=1e-7))
+    # a second step reuses the buckets
+    net.zero_grad()
+    net(x).pow(2).mean().backward()
+    buckets.finish()
+    q.put((rank, all(gathered), len(buckets.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_two_ranks():
+    """SURVEY.md 8e / fixture c-4 semantics: after the exchange every rank holds the MEAN of the per-shard gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, nb in res:
+        assert ok and nb >= 2

@@ -455,3 +455,120 @@ def test_run_py_test_phase_end_to_end(E, tmp_path):
     assert np.abs(got.astype(int) - ref_u8.astype(int)).max() <= 1
     run_dirs = os.listdir(os.path.join(root, "runs", "noise_example"))
     assert len(run_dirs) == 1 and os.path.exists(os.path.join(root, "runs", "noise_example", run_dirs[0], "summary.json"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training mode: HIP convolutions (forward / dgrad / wgrad) under autograd
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("transposed", [False, True])
+@pytest.mark.parametrize("ks,cin_segs,cout,hw", [(3, [16], 16, (8, 12)), (3, [32, 16], 64, (16, 16)), (1, [64, 16, 16], 64, (8, 8)),
+                                                 (3, [64], 128, (5, 7))])
+def test_conv_autograd_against_torch_cpu(E, L, ks, cin_segs, cout, hw, transposed):
+    """forward, input gradient and weight/bias gradients of the conv Function vs torch's CPU convolution."""
+    import torch.nn.functional as F
+    import mdie_amd.train as T
+    if transposed and ks == 1:
+        pytest.skip("the network has no 1x1 transposed convolution")
+    g = torch.Generator().manual_seed(ks * 100 + cout)
+    cin = sum(cin_segs)
+    segs = [torch.randn(2, c, *hw, generator=g) for c in cin_segs]
+    w = torch.randn((cin, cout, ks, ks) if transposed else (cout, cin, ks, ks), generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    dy = torch.randn(2, cout, *hw, generator=g)
+    # reference on the CPU
+    rs = [s.clone().requires_grad_(True) for s in segs]
+    rw, rb = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    x = torch.cat(rs, 1)
+    ry = F.conv_transpose2d(x, rw, rb, padding=ks // 2) if transposed else F.conv2d(x, rw, rb, padding=ks // 2)
+    ry.backward(dy)
+    # engine
+    gs = [s.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) for s in segs]
+    gw, gb = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = T.conv(L.F32, gw, gb, gs, transposed=transposed)
+    y.backward(dy.cuda())
+    assert rel_to_max(y, ry) <= 2e-5
+    assert rel_to_max(gw.grad, rw.grad) <= 5e-5
+    assert rel_to_max(gb.grad, rb.grad) <= 5e-5
+    for a, r in zip(gs, rs):
+        assert rel_to_max(a.grad, r.grad) <= 5e-5
+
+
+def test_train_step_matches_reference(E, golden_dir):
+    """One training-mode forward/backward (batch-stat BatchNorm, dropout off as in the fixture) against the values the
+    reference produced: output, charbonnier loss, twelve parameter gradients, updated running statistics."""
+    import json as _json
+    from models.cdan import CDAN
+    from oracle import params as P
+    z = np.load(os.path.join(golden_dir, "train_step_32.npz"))
+    net = CDAN(precision="fp32")
+    net.load_state_dict(P.make_state_dict(42), strict=True)
+    net = net.cuda().train()
+    net.dropout_p = 0.0
+    y = net(torch.from_numpy(z["x"]).cuda())
+    t = torch.from_numpy(z["t"]).cuda()
+    loss = torch.sqrt((y - t) ** 2 + 1e-6).mean()
+    loss.backward()
+    assert rel_to_max(y, torch.from_numpy(z["y"])) <= 1e-4
+    assert loss.item() == pytest.approx(float(z["loss"]), rel=1e-5)
+    named = dict(net.named_parameters())
+    for k in z.files:
+        if k.startswith("g:"):
+            err = rel_to_max(named[k[2:]].grad, torch.from_numpy(z[k]))
+            assert err <= 2e-3, f"{k}: {err:.3e}"
+    sd = net.state_dict()
+    for k in z.files:
+        if k.startswith("s:"):
+            assert rel_to_max(sd[k[2:]], torch.from_numpy(z[k])) <= 1e-4, k
+    norms = _json.loads(str(z["grad_norms"]))
+    bad = [k for k, n in norms.items() if abs(float(named[k].grad.double().norm()) - n) > 2e-3 * n + 1e-6]
+    assert not bad, bad[:5]
+    assert int(sd["encoder.conv1.bn.num_batches_tracked"]) == 1
+
+
+def test_training_reduces_loss_and_dropout_is_active(E):
+    from models.cdan import CDAN
+    from oracle import params as P
+    torch.manual_seed(0)
+    net = CDAN(precision="bf16").cuda().train()
+    x, t = P.lowlight_batch(31, 4, 32, 32)
+    x, t = x.cuda(), t.cuda()
+    with torch.no_grad():
+        a, b = net(x), net(x)
+    assert not torch.equal(a, b)               # dropout masks differ between calls
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        loss = torch.sqrt((net(x) - t) ** 2 + 1e-6).mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0]
+
+
+def test_run_py_train_phase(E, tmp_path):
+    from PIL import Image
+    from oracle import params as P
+    import run as runner
+    from mdie_amd import host as H
+    root = str(tmp_path)
+    _, clean = P.lowlight_batch(5, 4, 32, 32)
+    deg = (clean * 0.3)
+    for sub, data in (("degraded", deg), ("clean", clean)):
+        os.makedirs(os.path.join(root, "data", sub))
+        for i in range(4):
+            Image.fromarray((data[i].permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)).save(os.path.join(root, "data", sub, f"{i}.png"))
+    cfg = H.load_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "example_noise_64.json"), "train")
+    cfg["loss"] = H._wrap({"enabled": True, "terms": [{"name": "charbonnier", "weight": 1.0}, {"name": "ssim", "weight": 0.5}]})
+    cfg["train"]["dataset"] = H._wrap({"name": ["data.dataset", "PairedDataset"], "args": {
+        "input_root": os.path.join(root, "data", "degraded"), "target_root": os.path.join(root, "data", "clean"), "pairing_mode": "filename",
+        "transform": {"backend": "albumentations", "ops": [{"name": "HorizontalFlip", "args": {"p": 0.5}},
+                                                           {"name": "Normalize", "args": {"mean": [0, 0, 0], "std": [1, 1, 1]}},
+                                                           {"name": "ToTensorV2", "args": {}}]}}})
+    cfg["train"]["dataloader"] = H._wrap({"args": {"batch_size": 2, "shuffle": True, "num_workers": 0}})
+    cfg["train"]["n_epoch"], cfg["train"]["model_path"], cfg["train"]["model_name"] = 2, os.path.join(root, "weights"), "CDAN_t.pt"
+    cfg["logging"]["root_dir"] = os.path.join(root, "runs")
+    model = runner.main(cfg)
+    assert len(model.history) == 2 and all(np.isfinite(h["total"]) for h in model.history)
+    assert set(model.history[0]) == {"total", "charbonnier", "ssim"}
+    assert len(torch.load(os.path.join(root, "weights", "CDAN_t.pt"))) == 236
