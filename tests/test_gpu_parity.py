@@ -135,15 +135,6 @@ def test_cpu_input_rejected(E, L, net):
         net(torch.rand(1, 3, 32, 32))
 
 
-def test_train_mode_rejected(E, net):
-    net.train()
-    try:
-        with pytest.raises(NotImplementedError):
-            net(torch.rand(1, 3, 32, 32, device="cuda"))
-    finally:
-        net.eval()
-
-
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_full_batch_properties(E, net, precision):
     """BASELINE configs[1] at full size (B=32, 256x256): size-independent properties --
