@@ -774,10 +774,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   // (tile, chunk) stages with two LDS stage buffers were 5-25 % SLOWER on every layer shape --
   // the doubled LDS/VGPR footprint halves the resident workgroups, and resident workgroups are what
   // hides the staging latency here.)
-  int lg = 0;
-  while ((1 << lg) < a.n_tiles) ++lg;
-  if ((1 << lg) != a.n_tiles) { set_error("mdie_conv_fwd: cout / %d = %d output tiles, must be a power of two", BN, a.n_tiles); return MDIE_EINVAL; }
-  a.n_tiles_log2 = lg;
+  a.n_tiles_log2 = 0;   // only the wave-specialised kernel needs a power-of-two tile count
   const dim3 grid(8, a.n_tiles, cdiv(a.tiles_x * a.tiles_y * a.B, 8));
   static bool attr_set = false;
   if (!attr_set) {
@@ -865,7 +862,7 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   const bool small = wgs16 < (bn == 16 ? 1024 : 512) || (force8 == 1 && bn == 16) || force8 == 2;
   // MDIE_CONV_WS: 0 = one tile per 256-thread workgroup, 1 = wave-specialised persistent kernel for the 16x16-tile shapes
   static const int ws = getenv("MDIE_CONV_WS") ? atoi(getenv("MDIE_CONV_WS")) : 0;
-  if (ws && !small) {
+  if (ws && !small && (a.n_tiles & (a.n_tiles - 1)) == 0) {
     if (d->ksize == 3) return bn == 64 ? launch_conv_ws<T, 3, 64, 16>(a, stream) : launch_conv_ws<T, 3, 16, 16>(a, stream);
     return bn == 64 ? launch_conv_ws<T, 1, 64, 16>(a, stream) : launch_conv_ws<T, 1, 16, 16>(a, stream);
   }
