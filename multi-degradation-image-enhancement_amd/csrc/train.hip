@@ -179,6 +179,234 @@ __global__ __launch_bounds__(TR_THREADS) void wgrad_reduce_kernel(int splits, in
   }
 }
 
+// ---- wgrad, bf16: pixel-tiled, all taps from one LDS image, v_mfma_f32_16x16x32_bf16 ---------------------------------
+// The K dimension of the weight-gradient GEMM is the pixel index, but NHWC keeps the CHANNEL contiguous, so a
+// 16x16x32 operand (8 consecutive k per lane) cannot be loaded directly.  gfx950's transposing LDS read
+// ds_read_b64_tr_b16 delivers exactly that: the tile is staged in its natural layout -- planes of 16 channels,
+// one 32-byte row per pixel -- and each 16-lane group reads 4 pixel rows x 16 channels column-major.
+//   * one workgroup = (c-tile x o-tile) x a run of 16x16-pixel tiles; the X patch (18x18 with halo) and the dY
+//     tile are staged once and serve all 9 taps: a tap is a constant byte offset into the patch image, so every
+//     fragment read is `base + immediate`;
+//   * k <-> pixel map of one 32-pixel step (rows 2k, 2k+1 of the tile): lane group g, read h, element q holds
+//     pixel (2k + h, 4g + q); a 32-lane half then reads 8 consecutive 32-byte rows = all 64 banks once;
+//   * accumulators (taps x c-subtiles x o-subtiles of 16x16) stay in registers over the whole run and are
+//     written once to the split's scratch slab; wgrad_reduce_kernel folds the splits in a fixed order.
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+
+struct WgradTileArgs {
+  int B, H, W;
+  int nseg;
+  SegT seg[MDIE_MAX_SEG];
+  int cin_st, cout_st;
+  const char* dy; int dy_stride;
+  float* scratch;
+  int tiles_x, tiles_y, total_tiles, tiles_per_split;
+  int o_tiles;
+};
+
+constexpr int WT = 16;  // tile edge
+#ifndef WG_KUNROLL
+#define WG_KUNROLL 2
+#endif
+
+template <int NTAP> struct WgGeom {
+  static constexpr int PAD = NTAP == 9 ? 1 : 0;
+  static constexpr int PWD = WT + 2 * PAD;
+  static constexpr int PROWS = PWD * PWD;
+  static constexpr int XPLANE = PROWS * 32 + 32;   // 32-byte rows; +32 staggers the planes' banks for the staging writes
+  static constexpr int YPLANE = WT * WT * 32;
+};
+
+__device__ __forceinline__ v4s lds_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p));
+}
+
+// waves are arranged WC x WO; each owns CSW x OSW 16x16 subtiles of every tap
+template <int NTAP, int CSW, int OSW, int WC, int WO>
+__global__ __launch_bounds__(TR_THREADS, 2) void wgrad_tile_kernel(const WgradTileArgs a) {
+  using G = WgGeom<NTAP>;
+  constexpr int KS = NTAP == 9 ? 3 : 1;
+  constexpr int NCS_T = CSW * WC, NOS_T = OSW * WO;
+  constexpr int UPX = NCS_T * 2, UPY = NOS_T * 2;             // 16-byte units per pixel
+  constexpr int X_UNITS = G::PROWS * UPX, Y_UNITS = WT * WT * UPY;
+  constexpr int X_IT = (X_UNITS + TR_THREADS - 1) / TR_THREADS, Y_IT = (Y_UNITS + TR_THREADS - 1) / TR_THREADS;
+  constexpr int X_BATCH = X_IT > 6 ? 6 : X_IT;
+  constexpr int X_PPI = TR_THREADS / UPX, Y_PPI = TR_THREADS / UPY;   // pixels advanced per staging iteration
+  static_assert(WC * WO == TR_THREADS / 64, "wave grid");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_x = smem;
+  char* lds_y = smem + NCS_T * G::XPLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave % WC, wo = wave / WC;
+  const int ot = blockIdx.x % a.o_tiles, ct = blockIdx.x / a.o_tiles;
+  const int c0 = ct * NCS_T * 16, o0 = ot * NOS_T * 16;
+  const int split = blockIdx.y;
+
+  // ---- staging geometry (tile independent) ----
+  const int xchunk = tid % UPX;                      // this thread's 16-byte channel column of the c-tile
+  const char* xbase = nullptr; int xstride = 0;
+  {
+    const int c = c0 + xchunk * 8;
+#pragma unroll
+    for (int s = 0; s < MDIE_MAX_SEG; ++s)
+      if (s < a.nseg && c >= a.seg[s].ch_begin && c < a.seg[s].ch_end) {
+        xbase = a.seg[s].ptr + (size_t)(c - a.seg[s].ch_begin) * 2;
+        xstride = a.seg[s].stride * 2;
+      }
+  }
+  const int xdst0 = (xchunk >> 1) * G::XPLANE + (xchunk & 1) * 16;
+  const int ychunk = tid % UPY;
+  const bool ylive = o0 + ychunk * 8 < a.cout_st;
+  const char* ybase = a.dy + (size_t)(o0 + ychunk * 8) * 2;
+  const int ydst0 = (ychunk >> 1) * G::YPLANE + (ychunk & 1) * 16;
+
+  // ---- fragment read addresses ----
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const char* xrd = lds_x + (wc * CSW) * G::XPLANE + (4 * g + q) * 32 + p * 8;
+  const char* yrd = lds_y + (wo * OSW) * G::YPLANE + (4 * g + q) * 32 + p * 8;
+  const bool wave_live = c0 + wc * CSW * 16 < a.cin_st && o0 + wo * OSW * 16 < a.cout_st;
+
+  f32x4 acc[NTAP][CSW][OSW];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int i = 0; i < CSW; ++i)
+#pragma unroll
+      for (int j = 0; j < OSW; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int t_begin = split * a.tiles_per_split, t_end = min(t_begin + a.tiles_per_split, a.total_tiles);
+  const int tpi = a.tiles_x * a.tiles_y;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int img = tile / tpi;
+    const int trem = tile - img * tpi;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int y0 = ty * WT, x0 = tx * WT;
+    const size_t ibase = (size_t)img * a.H * a.W;
+
+    if (tile > t_begin) __syncthreads();   // the previous tile's fragment reads are done
+    // ---- stage X patch: unit u = tid + it*256 -> patch pixel u / UPX (in batches, to bound the registers in flight) ----
+    {
+      int pix = tid / UPX;
+      int py = pix / G::PWD, px = pix - py * G::PWD;
+#pragma unroll
+      for (int b0 = 0; b0 < X_IT; b0 += X_BATCH) {
+        uint4 v[X_BATCH];
+        int dsts[X_BATCH];
+#pragma unroll
+        for (int j = 0; j < X_BATCH; ++j) {
+          const int gy = y0 + py - G::PAD, gx = x0 + px - G::PAD;
+          const bool in_patch = b0 + j < X_IT && py < G::PWD;
+          const bool ok = in_patch && xbase != nullptr && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+          v[j] = make_uint4(0, 0, 0, 0);
+          if (ok) v[j] = *reinterpret_cast<const uint4*>(xbase + (ibase + (size_t)gy * a.W + gx) * xstride);
+          dsts[j] = in_patch ? xdst0 + (py * G::PWD + px) * 32 : -1;
+          px += X_PPI % G::PWD; py += X_PPI / G::PWD;
+          if (px >= G::PWD) { px -= G::PWD; py += 1; }
+        }
+#pragma unroll
+        for (int j = 0; j < X_BATCH; ++j)
+          if (dsts[j] >= 0) *reinterpret_cast<uint4*>(lds_x + dsts[j]) = v[j];
+      }
+    }
+    // ---- stage dY tile ----
+    {
+      uint4 v[Y_IT];
+      int pix = tid / UPY;
+#pragma unroll
+      for (int it = 0; it < Y_IT; ++it) {
+        const int py = pix >> 4, px = pix & 15;
+        const int gy = y0 + py, gx = x0 + px;
+        v[it] = make_uint4(0, 0, 0, 0);
+        if (pix < WT * WT && ylive && gy < a.H && gx < a.W)
+          v[it] = *reinterpret_cast<const uint4*>(ybase + (ibase + (size_t)gy * a.W + gx) * a.dy_stride * 2);
+        pix += Y_PPI;
+      }
+      pix = tid / UPY;
+#pragma unroll
+      for (int it = 0; it < Y_IT; ++it) {
+        if (pix < WT * WT) *reinterpret_cast<uint4*>(lds_y + ydst0 + pix * 32) = v[it];
+        pix += Y_PPI;
+      }
+    }
+    __syncthreads();
+
+    if (wave_live) {   // wave-uniform: EXEC stays all ones around the transposing reads
+#pragma unroll WG_KUNROLL
+      for (int k = 0; k < WT / 2; ++k) {
+        v8s bf[OSW];
+#pragma unroll
+        for (int os = 0; os < OSW; ++os) {
+          const v4s lo = lds_tr16(yrd + os * G::YPLANE + (2 * k) * WT * 32);
+          const v4s hi = lds_tr16(yrd + os * G::YPLANE + (2 * k + 1) * WT * 32);
+          bf[os] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+          const int kh = t / KS, kw = t - kh * KS;
+#pragma unroll
+          for (int cs = 0; cs < CSW; ++cs) {
+            const v4s lo = lds_tr16(xrd + cs * G::XPLANE + ((2 * k + kh) * G::PWD + kw) * 32);
+            const v4s hi = lds_tr16(xrd + cs * G::XPLANE + ((2 * k + 1 + kh) * G::PWD + kw) * 32);
+            const v8s af = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int os = 0; os < OSW; ++os)
+              acc[t][cs][os] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf[os]),
+                                                                       acc[t][cs][os], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  if (wave_live) {
+    float* out = a.scratch + (size_t)split * NTAP * a.cin_st * a.cout_st;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+      for (int cs = 0; cs < CSW; ++cs)
+#pragma unroll
+        for (int os = 0; os < OSW; ++os)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = c0 + (wc * CSW + cs) * 16 + g * 4 + r, o = o0 + (wo * OSW + os) * 16 + (lane & 15);
+            if (c < a.cin_st && o < a.cout_st) out[((size_t)t * a.cin_st + c) * a.cout_st + o] = acc[t][cs][os][r];
+          }
+  }
+}
+
+struct WgTilePlan { int cfg, c_tile, o_tile, c_tiles, o_tiles, splits, tiles_per_split, total_tiles, tiles_x, tiles_y; };
+
+// cfg 0: 64c x 64o (2x2 waves of 32x32); 1: 64c x 16o (cout-thin); 2: 16c x 64o (cin-thin)
+static WgTilePlan wgrad_tile_plan(int B, int H, int W, int cin_st, int cout_st) {
+  WgTilePlan p{};
+  if (cout_st % 64 != 0) { p.cfg = 1; p.c_tile = 64; p.o_tile = 16; }
+  else if (cin_st <= 16) { p.cfg = 2; p.c_tile = 16; p.o_tile = 64; }
+  else { p.cfg = 0; p.c_tile = 64; p.o_tile = 64; }
+  p.c_tiles = cdiv(cin_st, p.c_tile); p.o_tiles = cdiv(cout_st, p.o_tile);
+  p.tiles_x = cdiv(W, WT); p.tiles_y = cdiv(H, WT);
+  p.total_tiles = B * p.tiles_x * p.tiles_y;
+  const int base = p.c_tiles * p.o_tiles;
+  int splits = cdiv(512, base);                       // ~2 resident workgroups per CU
+  if (splits > p.total_tiles) splits = p.total_tiles;
+  if (splits < 1) splits = 1;
+  p.tiles_per_split = cdiv(p.total_tiles, splits);
+  p.splits = cdiv(p.total_tiles, p.tiles_per_split);
+  return p;
+}
+
+template <int NTAP, int CSW, int OSW, int WC, int WO>
+static void launch_wgrad_tile(const WgradTileArgs& a, const WgTilePlan& p, hipStream_t s) {
+  using G = WgGeom<NTAP>;
+  const size_t lds = (size_t)CSW * WC * G::XPLANE + (size_t)OSW * WO * G::YPLANE;
+  auto kern = wgrad_tile_kernel<NTAP, CSW, OSW, WC, WO>;
+  static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+  if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  hipLaunchKernelGGL(kern, dim3(p.c_tiles * p.o_tiles, p.splits), dim3(TR_THREADS), lds, s, a);
+}
+
 static int tr_grid(size_t total) {
   size_t g = (total + TR_THREADS - 1) / TR_THREADS;
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -222,7 +450,10 @@ extern "C" size_t mdie_conv_wgrad_workspace_bytes(int B, int H, int W, int ksize
   if (B <= 0 || H <= 0 || W <= 0 || cin_stored <= 0 || cout_stored <= 0) return 0;
   const int nos = cout_stored % 64 == 0 ? 4 : 1;
   const int base = (cout_stored / (16 * nos)) * cdiv(cin_stored, 64) * ksize * ksize;
-  return (size_t)wgrad_splits(B, H, W, base) * ksize * ksize * cin_stored * cout_stored * sizeof(float);
+  const size_t slab = (size_t)ksize * ksize * cin_stored * cout_stored * sizeof(float);
+  const size_t f32_need = (size_t)wgrad_splits(B, H, W, base) * slab;
+  const size_t bf16_need = (size_t)wgrad_tile_plan(B, H, W, cin_stored, cout_stored).splits * slab;
+  return f32_need > bf16_need ? f32_need : bf16_need;   // the query is dtype-agnostic
 }
 
 extern "C" int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream) {
@@ -246,15 +477,42 @@ extern "C" int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream) {
   a.cin_st = c; a.cout_st = d->cout_stored;
   MDIE_REQUIRE(c >= d->cin + (d->split < d->cin ? d->gap : 0), "mdie_conv_wgrad: segments hold %d channels < cin %d + gap", c, d->cin);
   a.dy = reinterpret_cast<const char*>(d->dy); a.dy_stride = d->dy_stride;
+  const int taps = d->ksize * d->ksize;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == MDIE_BF16) {
+    const WgTilePlan p = wgrad_tile_plan(d->B, d->H, d->W, c, d->cout_stored);
+    const size_t need = (size_t)p.splits * taps * c * d->cout_stored * sizeof(float);
+    if (d->workspace_bytes < need) { set_error("mdie_conv_wgrad: workspace %zu < %zu", d->workspace_bytes, need); return MDIE_ENOSPC; }
+    WgradTileArgs t{};
+    t.B = d->B; t.H = d->H; t.W = d->W; t.nseg = a.nseg;
+    for (int i = 0; i < a.nseg; ++i) t.seg[i] = a.seg[i];
+    t.cin_st = c; t.cout_st = d->cout_stored; t.dy = a.dy; t.dy_stride = a.dy_stride;
+    t.scratch = reinterpret_cast<float*>(d->workspace);
+    t.tiles_x = p.tiles_x; t.tiles_y = p.tiles_y; t.total_tiles = p.total_tiles; t.tiles_per_split = p.tiles_per_split; t.o_tiles = p.o_tiles;
+    if (taps == 9) {
+      if (p.cfg == 0) launch_wgrad_tile<9, 2, 2, 2, 2>(t, p, s);
+      else if (p.cfg == 1) launch_wgrad_tile<9, 1, 1, 4, 1>(t, p, s);
+      else launch_wgrad_tile<9, 1, 1, 1, 4>(t, p, s);
+    } else {
+      if (p.cfg == 0) launch_wgrad_tile<1, 2, 2, 2, 2>(t, p, s);
+      else if (p.cfg == 1) launch_wgrad_tile<1, 1, 1, 4, 1>(t, p, s);
+      else launch_wgrad_tile<1, 1, 1, 1, 4>(t, p, s);
+    }
+    MDIE_LAUNCH_CHECK("mdie_conv_wgrad");
+    const size_t total = (size_t)d->cout * d->cin * taps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tr_grid(total)), dim3(TR_THREADS), 0, s, p.splits, d->ksize, d->transposed, d->cout, d->cin,
+                       d->cout_stored, c, d->split, d->gap, t.scratch, d->dw);
+    MDIE_LAUNCH_CHECK("mdie_conv_wgrad");
+    return MDIE_OK;
+  }
   const int nos = d->cout_stored % 64 == 0 ? 4 : 1;
-  const int o_tiles = d->cout_stored / (16 * nos), c_tiles = cdiv(c, 64), taps = d->ksize * d->ksize;
+  const int o_tiles = d->cout_stored / (16 * nos), c_tiles = cdiv(c, 64);
   a.splits = wgrad_splits(d->B, d->H, d->W, o_tiles * c_tiles * taps);
   const long groups = ((long)d->B * d->H * d->W + 3) / 4;
   a.groups_per_split = (int)((groups + a.splits - 1) / a.splits);
   const size_t need = (size_t)a.splits * taps * c * d->cout_stored * sizeof(float);
   if (d->workspace_bytes < need) { set_error("mdie_conv_wgrad: workspace %zu < %zu", d->workspace_bytes, need); return MDIE_ENOSPC; }
   a.scratch = reinterpret_cast<float*>(d->workspace);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid(o_tiles * c_tiles, taps, a.splits);
   if (d->dtype == MDIE_F32) {
     if (nos == 4) hipLaunchKernelGGL((wgrad_kernel<float, 4>), grid, dim3(TR_THREADS), 0, s, a);

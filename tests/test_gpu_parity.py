@@ -451,21 +451,27 @@ def test_run_py_test_phase_end_to_end(E, tmp_path):
 # ---------------------------------------------------------------------------------------------------------------------
 # training mode: HIP convolutions (forward / dgrad / wgrad) under autograd
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("transposed", [False, True])
 @pytest.mark.parametrize("ks,cin_segs,cout,hw", [(3, [16], 16, (8, 12)), (3, [32, 16], 64, (16, 16)), (1, [64, 16, 16], 64, (8, 8)),
-                                                 (3, [64], 128, (5, 7))])
-def test_conv_autograd_against_torch_cpu(E, L, ks, cin_segs, cout, hw, transposed):
-    """forward, input gradient and weight/bias gradients of the conv Function vs torch's CPU convolution."""
+                                                 (3, [64], 128, (5, 7)), (3, [16], 64, (20, 37)), (3, [64, 16, 16, 16], 16, (33, 18)),
+                                                 (1, [16, 16, 16, 16, 16], 16, (17, 40)), (3, [128], 64, (32, 48))])
+def test_conv_autograd_against_torch_cpu(E, L, ks, cin_segs, cout, hw, transposed, prec):
+    """forward, input gradient and weight/bias gradients of the conv Function vs torch's CPU convolution.
+    bf16: operands are rounded to bf16 first, so products are exact on both sides and only the bf16 rounding of the
+    stored forward output / input gradient (2^-8 relative) and fp32 summation order differ."""
     import torch.nn.functional as F
     import mdie_amd.train as T
     if transposed and ks == 1:
         pytest.skip("the network has no 1x1 transposed convolution")
+    bf = prec == "bf16"
+    rnd = (lambda t: t.bfloat16().float()) if bf else (lambda t: t)
     g = torch.Generator().manual_seed(ks * 100 + cout)
     cin = sum(cin_segs)
-    segs = [torch.randn(2, c, *hw, generator=g) for c in cin_segs]
-    w = torch.randn((cin, cout, ks, ks) if transposed else (cout, cin, ks, ks), generator=g) * 0.1
+    segs = [rnd(torch.randn(2, c, *hw, generator=g)) for c in cin_segs]
+    w = rnd(torch.randn((cin, cout, ks, ks) if transposed else (cout, cin, ks, ks), generator=g) * 0.1)
     b = torch.randn(cout, generator=g)
-    dy = torch.randn(2, cout, *hw, generator=g)
+    dy = rnd(torch.randn(2, cout, *hw, generator=g))
     # reference on the CPU
     rs = [s.clone().requires_grad_(True) for s in segs]
     rw, rb = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
@@ -473,15 +479,17 @@ def test_conv_autograd_against_torch_cpu(E, L, ks, cin_segs, cout, hw, transpose
     ry = F.conv_transpose2d(x, rw, rb, padding=ks // 2) if transposed else F.conv2d(x, rw, rb, padding=ks // 2)
     ry.backward(dy)
     # engine
-    gs = [s.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) for s in segs]
+    td = torch.bfloat16 if bf else torch.float32
+    gs = [s.cuda().to(td).contiguous(memory_format=torch.channels_last).requires_grad_(True) for s in segs]
     gw, gb = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
-    y = T.conv(L.F32, gw, gb, gs, transposed=transposed)
-    y.backward(dy.cuda())
-    assert rel_to_max(y, ry) <= 2e-5
+    y = T.conv(L.BF16 if bf else L.F32, gw, gb, gs, transposed=transposed)
+    y.backward(dy.cuda().to(td))
+    act_tol = 8e-3 if bf else 2e-5      # bf16: one rounding of the stored result
+    assert rel_to_max(y, ry) <= act_tol
     assert rel_to_max(gw.grad, rw.grad) <= 5e-5
     assert rel_to_max(gb.grad, rb.grad) <= 5e-5
     for a, r in zip(gs, rs):
-        assert rel_to_max(a.grad, r.grad) <= 5e-5
+        assert rel_to_max(a.grad, r.grad) <= (act_tol if bf else 5e-5)
 
 
 def test_train_step_matches_reference(E, golden_dir):
