@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 8
+#define MDIE_ABI_VERSION 9
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -334,6 +334,24 @@ int mdie_postprocess(int B, int H, int W, const float* y, const mdie_pp_op* ops,
 size_t mdie_metrics_workspace_bytes(int B, int H, int W);
 int mdie_psnr_ssim(int B, int H, int W, const float* pred, const float* target, float* out2, void* workspace,
                    size_t workspace_bytes, void* stream);
+
+/* Training loss, value and gradient in one call (utils/loss_factory.py:146-230; models/model.py:161-164 evaluates the
+ * pipeline and calls backward on it every step).  Terms that need downloaded networks (vgg_perceptual, lpips) are
+ * not here.  ssim is 1 - SSIM with the torchmetrics defaults restated as for mdie_psnr_ssim; the data range is
+ * taken from the tensors and treated as a constant in the gradient.
+ *   values: device float[nterms + 1]: each term unweighted, then sum_k weight_k * term_k
+ *   grad:   device fp32 NCHW [B,3,H,W] = d values[nterms] / d pred, or NULL (values only)
+ * terms: HOST array, each kind at most once. */
+enum { MDIE_LOSS_MSE = 0          /* loss_factory.py:146-151 */,
+       MDIE_LOSS_L1 = 1           /* :153-158 */,
+       MDIE_LOSS_CHARBONNIER = 2  /* param = eps, :160-167 */,
+       MDIE_LOSS_SSIM = 3         /* :180-189 */,
+       MDIE_LOSS_GRADIENT_L1 = 4  /* param = to_gray (0/1), :90-103, 203-230 */ };
+#define MDIE_LOSS_MAX_TERMS 5
+typedef struct { int kind; float weight; float param; } mdie_loss_term;
+size_t mdie_loss_workspace_bytes(int B, int H, int W);
+int mdie_loss_fwd_bwd(int B, int H, int W, const float* pred, const float* target, const mdie_loss_term* terms,
+                      int nterms, float* values, float* grad, void* workspace, size_t workspace_bytes, void* stream);
 
 const char* mdie_last_error(void);
 int mdie_abi_version(void);

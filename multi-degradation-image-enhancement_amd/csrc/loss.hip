@@ -1,0 +1,413 @@
+// Training loss on the device: every network-free term of utils/loss_factory.py:146-230
+// -- mse, l1, charbonnier, ssim, gradient_l1 -- evaluated AND differentiated in one call:
+//   values[k]      = term k (unweighted), values[nterms] = sum_k weight_k * term_k
+//   grad           = d(values[nterms]) / d(pred), fp32 NCHW like pred
+// so the host needs neither autograd through a dozen elementwise ops nor MIOpen's depthwise 11x11
+// convolutions (5 forward + 3 backward per step at 1.5 ms each for B=8, 512x512).
+//
+//   pointwise terms   one pass: value partial sums per block + the gradient (which also initialises `grad`)
+//   ssim              1 - mean(SSIM map), torchmetrics defaults restated as in post.hip (11x11 Gaussian sigma 1.5,
+//                     k1 0.01, k2 0.03, valid windows, data range from the tensors and treated as a constant).
+//                     With m = A1*A2 / (B1*B2), A1 = 2 mu_p mu_t + c1, A2 = 2 s_pt + c2, B1 = mu_p^2 + mu_t^2 + c1,
+//                     B2 = s_pp + s_tt + c2, the forward kernel stores three maps per window
+//                        a = dm/dE[p^2] = -m/B2,  b = dm/dE[pt] = 2 A1/(B1 B2),
+//                        c = dm/dmu_p  = 2 mu_t (A2 - A1)/(B1 B2) + 2 mu_p m (1/B2 - 1/B1)
+//                     and the backward kernel filters them with the same (symmetric) Gaussian:
+//                        dm/dp = G*c + 2 p (G*a) + t (G*b).
+//   gradient_l1       mean |Sobel(x) - Sobel(y)| with zero padding (loss_factory.py:90-103, 207-230); Sobel is
+//                     linear, so the kernel works on d = x - y (luminance of it with to_gray) and applies the
+//                     transposed stencil to sign(Sobel(d)) in the same tile.
+// Reductions are two-level and ordered (no float atomics): results are bit-reproducible run to run.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace mdie {
+
+constexpr int LS_THREADS = 256;
+constexpr int LS_SLABS = 32;
+constexpr int LS_PW_BLOCKS = 1024;   // partial-sum blocks of the pointwise pass
+
+__device__ __forceinline__ float ls_block_sum(float v, float* red) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < LS_THREADS / 64; ++i) s += red[i];
+  return s;
+}
+
+struct LossCoef {
+  float w_mse, w_l1, w_charb, eps2;   // weights already divided by the element count; 0 = term absent
+};
+
+// grid LS_PW_BLOCKS; part[block][3] = sums of d^2, |d|, sqrt(d^2 + eps^2)
+__global__ __launch_bounds__(LS_THREADS) void loss_pointwise_kernel(size_t n, const float* pred, const float* target, LossCoef k, float* part,
+                                                                    float* grad) {
+  __shared__ float red[LS_THREADS / 64];
+  float s2 = 0.f, s1 = 0.f, sc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * LS_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * LS_THREADS) {
+    const float d = pred[i] - target[i];
+    const float r = sqrtf(fmaf(d, d, k.eps2));
+    s2 = fmaf(d, d, s2); s1 += fabsf(d); sc += r;
+    if (grad) {
+      const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      grad[i] = 2.f * k.w_mse * d + k.w_l1 * sg + k.w_charb * d / r;
+    }
+  }
+  s2 = ls_block_sum(s2, red); s1 = ls_block_sum(s1, red); sc = ls_block_sum(sc, red);
+  if (threadIdx.x == 0) { part[blockIdx.x * 3 + 0] = s2; part[blockIdx.x * 3 + 1] = s1; part[blockIdx.x * 3 + 2] = sc; }
+}
+
+// min / max of pred and target per (plane, slab): mm[(plane*SLABS + slab)*4]
+__global__ __launch_bounds__(LS_THREADS) void loss_minmax_kernel(int HW, const float* pred, const float* target, float* mm) {
+  __shared__ float sm[4][LS_THREADS / 64];
+  const int plane = blockIdx.y, slab = blockIdx.x;
+  const int per = (HW + LS_SLABS - 1) / LS_SLABS;
+  const int b = slab * per, e = min(HW, b + per);
+  float pmin = INFINITY, pmax = -INFINITY, tmin = INFINITY, tmax = -INFINITY;
+  for (int i = b + threadIdx.x; i < e; i += LS_THREADS) {
+    const float p = pred[(size_t)plane * HW + i], t = target[(size_t)plane * HW + i];
+    pmin = fminf(pmin, p); pmax = fmaxf(pmax, p); tmin = fminf(tmin, t); tmax = fmaxf(tmax, t);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    pmin = fminf(pmin, __shfl_xor(pmin, d)); pmax = fmaxf(pmax, __shfl_xor(pmax, d));
+    tmin = fminf(tmin, __shfl_xor(tmin, d)); tmax = fmaxf(tmax, __shfl_xor(tmax, d));
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sm[0][wave] = pmin; sm[1][wave] = pmax; sm[2][wave] = tmin; sm[3][wave] = tmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < LS_THREADS / 64; ++i) {
+      sm[0][0] = fminf(sm[0][0], sm[0][i]); sm[1][0] = fmaxf(sm[1][0], sm[1][i]);
+      sm[2][0] = fminf(sm[2][0], sm[2][i]); sm[3][0] = fmaxf(sm[3][0], sm[3][i]);
+    }
+    float* o = mm + ((size_t)plane * LS_SLABS + slab) * 4;
+    o[0] = sm[0][0]; o[1] = sm[1][0]; o[2] = sm[2][0]; o[3] = sm[3][0];
+  }
+}
+
+// range[0] = max(range(pred), range(target))  (torchmetrics SSIM, data_range=None)
+__global__ __launch_bounds__(LS_THREADS) void loss_range_kernel(int nparts, const float* mm, float* range) {
+  __shared__ float sm[4][LS_THREADS];
+  float pmin = INFINITY, pmax = -INFINITY, tmin = INFINITY, tmax = -INFINITY;
+  for (int i = threadIdx.x; i < nparts; i += LS_THREADS) {
+    pmin = fminf(pmin, mm[i * 4 + 0]); pmax = fmaxf(pmax, mm[i * 4 + 1]); tmin = fminf(tmin, mm[i * 4 + 2]); tmax = fmaxf(tmax, mm[i * 4 + 3]);
+  }
+  sm[0][threadIdx.x] = pmin; sm[1][threadIdx.x] = pmax; sm[2][threadIdx.x] = tmin; sm[3][threadIdx.x] = tmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < LS_THREADS; ++i) {
+      pmin = fminf(pmin, sm[0][i]); pmax = fmaxf(pmax, sm[1][i]); tmin = fminf(tmin, sm[2][i]); tmax = fmaxf(tmax, sm[3][i]);
+    }
+    range[0] = fmaxf(pmax - pmin, tmax - tmin);
+  }
+}
+
+struct Gauss11 { float g[11]; };
+
+// SSIM map on 16x16 tiles of window centres; grid (tiles, planes).  Writes the tile's sum of m and, when
+// `maps` is set, a / b / c (zero outside the interior [5, H-5) x [5, W-5)).
+__global__ __launch_bounds__(LS_THREADS) void loss_ssim_fwd_kernel(int H, int W, const float* pred, const float* target, const float* range,
+                                                                   Gauss11 gw, float* spart, float* maps, size_t map_stride) {
+  constexpr int TS = 16, PW = TS + 10;
+  __shared__ float sp[PW][PW + 1], st[PW][PW + 1];
+  __shared__ float hrow[5][PW][TS + 1];
+  __shared__ float red[LS_THREADS / 64];
+  const int tiles_x = cdiv(W, TS);
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, plane = blockIdx.y;
+  const int y0 = ty * TS - 5, x0 = tx * TS - 5;
+  const float* P = pred + (size_t)plane * H * W;
+  const float* T = target + (size_t)plane * H * W;
+  for (int i = threadIdx.x; i < PW * PW; i += LS_THREADS) {
+    const int py = i / PW, px = i - py * PW;
+    const int gy = y0 + py, gx = x0 + px;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    sp[py][px] = in ? P[(size_t)gy * W + gx] : 0.f;
+    st[py][px] = in ? T[(size_t)gy * W + gx] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PW * TS; i += LS_THREADS) {
+    const int py = i / TS, ox = i - py * TS;
+    float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float p = sp[py][ox + k], t = st[py][ox + k], w = gw.g[k];
+      a = fmaf(w, p, a); b = fmaf(w, t, b); aa = fmaf(w, p * p, aa); bb = fmaf(w, t * t, bb); ab = fmaf(w, p * t, ab);
+    }
+    hrow[0][py][ox] = a; hrow[1][py][ox] = b; hrow[2][py][ox] = aa; hrow[3][py][ox] = bb; hrow[4][py][ox] = ab;
+  }
+  __syncthreads();
+  const int oy = threadIdx.x / TS, ox = threadIdx.x % TS;
+  float mu_p = 0.f, mu_t = 0.f, e_pp = 0.f, e_tt = 0.f, e_pt = 0.f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float w = gw.g[k];
+    mu_p = fmaf(w, hrow[0][oy + k][ox], mu_p); mu_t = fmaf(w, hrow[1][oy + k][ox], mu_t);
+    e_pp = fmaf(w, hrow[2][oy + k][ox], e_pp); e_tt = fmaf(w, hrow[3][oy + k][ox], e_tt);
+    e_pt = fmaf(w, hrow[4][oy + k][ox], e_pt);
+  }
+  const float L = range[0];
+  const float c1 = (0.01f * L) * (0.01f * L), c2 = (0.03f * L) * (0.03f * L);
+  const float s_pp = e_pp - mu_p * mu_p, s_tt = e_tt - mu_t * mu_t, s_pt = e_pt - mu_p * mu_t;
+  const float A1 = 2.f * mu_p * mu_t + c1, A2 = 2.f * s_pt + c2, B1 = mu_p * mu_p + mu_t * mu_t + c1, B2 = s_pp + s_tt + c2;
+  const float inv = 1.f / (B1 * B2);
+  float m = A1 * A2 * inv;
+  const int gy = ty * TS + oy, gx = tx * TS + ox;
+  const bool interior = gy >= 5 && gy < H - 5 && gx >= 5 && gx < W - 5;
+  if (maps && gy < H && gx < W) {
+    const size_t o = (size_t)plane * H * W + (size_t)gy * W + gx;
+    maps[o] = interior ? -m / B2 : 0.f;
+    maps[o + map_stride] = interior ? 2.f * A1 * inv : 0.f;
+    maps[o + 2 * map_stride] = interior ? 2.f * mu_t * (A2 - A1) * inv + 2.f * mu_p * m * (1.f / B2 - 1.f / B1) : 0.f;
+  }
+  if (!interior) m = 0.f;
+  m = ls_block_sum(m, red);
+  if (threadIdx.x == 0) spart[(size_t)plane * gridDim.x + blockIdx.x] = m;
+}
+
+// grad += coef * (G*c + 2 p G*a + t G*b) on 16x16 pixel tiles; coef = -weight / (planes * interior windows)
+__global__ __launch_bounds__(LS_THREADS) void loss_ssim_bwd_kernel(int H, int W, const float* pred, const float* target, Gauss11 gw,
+                                                                   const float* maps, size_t map_stride, float coef, float* grad) {
+  constexpr int TS = 16, PW = TS + 10;
+  __shared__ float sm[3][PW][PW + 1];
+  __shared__ float hrow[3][PW][TS + 1];
+  const int tiles_x = cdiv(W, TS);
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, plane = blockIdx.y;
+  const int y0 = ty * TS - 5, x0 = tx * TS - 5;
+  const float* M = maps + (size_t)plane * H * W;
+  for (int i = threadIdx.x; i < PW * PW; i += LS_THREADS) {
+    const int py = i / PW, px = i - py * PW;
+    const int gy = y0 + py, gx = x0 + px;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const size_t o = (size_t)gy * W + gx;
+    sm[0][py][px] = in ? M[o] : 0.f;
+    sm[1][py][px] = in ? M[o + map_stride] : 0.f;
+    sm[2][py][px] = in ? M[o + 2 * map_stride] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PW * TS; i += LS_THREADS) {
+    const int py = i / TS, ox = i - py * TS;
+    float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float w = gw.g[k];
+      a = fmaf(w, sm[0][py][ox + k], a); b = fmaf(w, sm[1][py][ox + k], b); c = fmaf(w, sm[2][py][ox + k], c);
+    }
+    hrow[0][py][ox] = a; hrow[1][py][ox] = b; hrow[2][py][ox] = c;
+  }
+  __syncthreads();
+  const int oy = threadIdx.x / TS, ox = threadIdx.x % TS;
+  float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float w = gw.g[k];
+    a = fmaf(w, hrow[0][oy + k][ox], a); b = fmaf(w, hrow[1][oy + k][ox], b); c = fmaf(w, hrow[2][oy + k][ox], c);
+  }
+  const int gy = ty * TS + oy, gx = tx * TS + ox;
+  if (gy < H && gx < W) {
+    const size_t o = (size_t)plane * H * W + (size_t)gy * W + gx;
+    grad[o] += coef * (c + 2.f * pred[o] * a + target[o] * b);
+  }
+}
+
+// gradient_l1 on 16x16 tiles; grid (tiles, B * (gray ? 1 : 3)).  d = x - y (luminance when gray) is staged with a
+// halo of 2, Sobel(d) is evaluated on the tile + halo 1 (zero padding at the picture edge), the tile's |.| sum goes
+// to gpart and the transposed stencil of sign(.) -- only of positions inside the picture -- to grad.
+__global__ __launch_bounds__(LS_THREADS) void loss_sobel_kernel(int H, int W, int gray, const float* pred, const float* target, float coef,
+                                                                float* gpart, float* grad) {
+  constexpr int TS = 16, PD = TS + 4, PG = TS + 2;
+  __shared__ float sd[PD][PD + 1];
+  __shared__ float sx[PG][PG + 1], sy[PG][PG + 1];
+  __shared__ float red[LS_THREADS / 64];
+  const int tiles_x = cdiv(W, TS);
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const size_t HW = (size_t)H * W;
+  const size_t pbase = gray ? (size_t)blockIdx.y * 3 * HW : (size_t)blockIdx.y * HW;
+  for (int i = threadIdx.x; i < PD * PD; i += LS_THREADS) {
+    const int py = i / PD, px = i - py * PD;
+    const int gy = ty * TS + py - 2, gx = tx * TS + px - 2;
+    float d = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      const size_t o = pbase + (size_t)gy * W + gx;
+      if (gray) d = 0.2989f * (pred[o] - target[o]) + 0.5870f * (pred[o + HW] - target[o + HW]) + 0.1140f * (pred[o + 2 * HW] - target[o + 2 * HW]);
+      else d = pred[o] - target[o];
+    }
+    sd[py][px] = d;
+  }
+  __syncthreads();
+  float asum = 0.f;
+  for (int i = threadIdx.x; i < PG * PG; i += LS_THREADS) {
+    const int py = i / PG, px = i - py * PG;             // Sobel position (ty*TS + py - 1, tx*TS + px - 1)
+    const int gy = ty * TS + py - 1, gx = tx * TS + px - 1;
+    float vx = 0.f, vy = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      const float d00 = sd[py][px], d01 = sd[py][px + 1], d02 = sd[py][px + 2];
+      const float d10 = sd[py + 1][px], d12 = sd[py + 1][px + 2];
+      const float d20 = sd[py + 2][px], d21 = sd[py + 2][px + 1], d22 = sd[py + 2][px + 2];
+      const float gxv = (d02 - d00) + 2.f * (d12 - d10) + (d22 - d20);
+      const float gyv = (d20 - d00) + 2.f * (d21 - d01) + (d22 - d02);
+      if (py >= 1 && py <= TS && px >= 1 && px <= TS) asum += fabsf(gxv) + fabsf(gyv);
+      vx = gxv > 0.f ? 1.f : (gxv < 0.f ? -1.f : 0.f);
+      vy = gyv > 0.f ? 1.f : (gyv < 0.f ? -1.f : 0.f);
+    }
+    sx[py][px] = vx; sy[py][px] = vy;
+  }
+  asum = ls_block_sum(asum, red);   // contains the barrier that publishes sx / sy
+  if (threadIdx.x == 0) gpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = asum;
+  if (!grad) return;
+  const int oy = threadIdx.x / TS, ox = threadIdx.x % TS;
+  const int gy = ty * TS + oy, gx = tx * TS + ox;
+  if (gy < H && gx < W) {
+    // dL/dd(p) = sum_{i,j} k[i][j] * s(p - (i-1, j-1)); s-tile index of position q is q - tile origin + 1
+    float g = 0.f;
+    // kx = [[-1,0,1],[-2,0,2],[-1,0,1]]: column j=0 weight -, j=2 weight +  -> s at x+1 (j=0), x-1 (j=2)
+    g += -(sx[oy + 2][ox + 2] + 2.f * sx[oy + 1][ox + 2] + sx[oy][ox + 2]) + (sx[oy + 2][ox] + 2.f * sx[oy + 1][ox] + sx[oy][ox]);
+    // ky = kx^T: row i=0 weight -, i=2 weight +  -> s at y+1 (i=0), y-1 (i=2)
+    g += -(sy[oy + 2][ox + 2] + 2.f * sy[oy + 2][ox + 1] + sy[oy + 2][ox]) + (sy[oy][ox + 2] + 2.f * sy[oy][ox + 1] + sy[oy][ox]);
+    g *= coef;
+    const size_t o = pbase + (size_t)gy * W + gx;
+    if (gray) { grad[o] += 0.2989f * g; grad[o + HW] += 0.5870f * g; grad[o + 2 * HW] += 0.1140f * g; }
+    else grad[o] += g;
+  }
+}
+
+struct LossFinal {
+  int nterms;
+  int kind[MDIE_LOSS_MAX_TERMS];
+  float weight[MDIE_LOSS_MAX_TERMS];
+  int n_pw, n_ssim, n_sobel;           // partial counts
+  double n_elem, n_win, n_grad;        // normalisers: elements, SSIM windows, Sobel outputs
+};
+
+// one block: ordered double-precision sums of the partials -> values[0..nterms-1], values[nterms] = weighted total
+__global__ __launch_bounds__(LS_THREADS) void loss_final_kernel(LossFinal f, const float* pw_part, const float* spart, const float* gpart,
+                                                                float* values) {
+  __shared__ double red[5][LS_THREADS];
+  double s[5] = {0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < f.n_pw; i += LS_THREADS) { s[0] += pw_part[i * 3]; s[1] += pw_part[i * 3 + 1]; s[2] += pw_part[i * 3 + 2]; }
+  for (int i = threadIdx.x; i < f.n_ssim; i += LS_THREADS) s[3] += spart[i];
+  for (int i = threadIdx.x; i < f.n_sobel; i += LS_THREADS) s[4] += gpart[i];
+  for (int k = 0; k < 5; ++k) red[k][threadIdx.x] = s[k];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int k = 0; k < 5; ++k) {
+    double t = 0.0;
+    for (int i = 0; i < LS_THREADS; ++i) t += red[k][i];
+    s[k] = t;
+  }
+  double total = 0.0;
+  for (int k = 0; k < f.nterms; ++k) {
+    double v = 0.0;
+    switch (f.kind[k]) {
+      case MDIE_LOSS_MSE: v = s[0] / f.n_elem; break;
+      case MDIE_LOSS_L1: v = s[1] / f.n_elem; break;
+      case MDIE_LOSS_CHARBONNIER: v = s[2] / f.n_elem; break;
+      case MDIE_LOSS_SSIM: v = 1.0 - s[3] / f.n_win; break;
+      case MDIE_LOSS_GRADIENT_L1: v = s[4] / f.n_grad; break;
+    }
+    values[k] = (float)v;
+    total += (double)f.weight[k] * v;
+  }
+  values[f.nterms] = (float)total;
+}
+
+static size_t ls256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct LossWs {
+  size_t pw_part, mm, range, spart, gpart, maps, total;
+};
+
+static LossWs loss_ws(int B, int H, int W) {
+  LossWs w{};
+  const size_t planes = (size_t)B * 3, tiles = (size_t)cdiv(W, 16) * cdiv(H, 16);
+  size_t o = 0;
+  w.pw_part = o; o += ls256(LS_PW_BLOCKS * 3 * sizeof(float));
+  w.mm = o; o += ls256(planes * LS_SLABS * 4 * sizeof(float));
+  w.range = o; o += ls256(4 * sizeof(float));
+  w.spart = o; o += ls256(planes * tiles * sizeof(float));
+  w.gpart = o; o += ls256(planes * tiles * sizeof(float));
+  w.maps = o; o += ls256(3 * planes * (size_t)H * W * sizeof(float));
+  w.total = o;
+  return w;
+}
+
+}  // namespace mdie
+
+using namespace mdie;
+
+extern "C" size_t mdie_loss_workspace_bytes(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return loss_ws(B, H, W).total;
+}
+
+extern "C" int mdie_loss_fwd_bwd(int B, int H, int W, const float* pred, const float* target, const mdie_loss_term* terms, int nterms,
+                                 float* values, float* grad, void* workspace, size_t workspace_bytes, void* stream) {
+  MDIE_REQUIRE(B > 0 && H > 0 && W > 0 && pred && target && values, "mdie_loss_fwd_bwd: bad argument");
+  MDIE_REQUIRE(nterms >= 1 && nterms <= MDIE_LOSS_MAX_TERMS && terms, "mdie_loss_fwd_bwd: nterms %d (1..%d)", nterms, MDIE_LOSS_MAX_TERMS);
+  const LossWs L = loss_ws(B, H, W);
+  if (!workspace || workspace_bytes < L.total) { set_error("mdie_loss_fwd_bwd: workspace %zu < %zu", workspace_bytes, L.total); return MDIE_ENOSPC; }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  float* pw_part = reinterpret_cast<float*>(ws + L.pw_part);
+  float* mm = reinterpret_cast<float*>(ws + L.mm);
+  float* range = reinterpret_cast<float*>(ws + L.range);
+  float* spart = reinterpret_cast<float*>(ws + L.spart);
+  float* gpart = reinterpret_cast<float*>(ws + L.gpart);
+  float* maps = reinterpret_cast<float*>(ws + L.maps);
+  const int planes = B * 3, HW = H * W, tiles = cdiv(W, 16) * cdiv(H, 16);
+  const size_t n = (size_t)planes * HW;
+
+  LossCoef k{0.f, 0.f, 0.f, 1e-6f};
+  LossFinal f{};
+  f.nterms = nterms;
+  f.n_pw = LS_PW_BLOCKS; f.n_elem = (double)n;
+  float w_ssim = 0.f, w_sobel = 0.f;
+  int has_ssim = 0, has_sobel = 0, sobel_gray = 0, seen[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < nterms; ++i) {
+    const int kind = terms[i].kind;
+    MDIE_REQUIRE(kind >= 0 && kind <= MDIE_LOSS_GRADIENT_L1, "mdie_loss_fwd_bwd: unknown term kind %d", kind);
+    MDIE_REQUIRE(!seen[kind], "mdie_loss_fwd_bwd: term kind %d given twice", kind);
+    seen[kind] = 1;
+    f.kind[i] = kind; f.weight[i] = terms[i].weight;
+    const float w = terms[i].weight;
+    switch (kind) {
+      case MDIE_LOSS_MSE: k.w_mse = w / (float)n; break;
+      case MDIE_LOSS_L1: k.w_l1 = w / (float)n; break;
+      case MDIE_LOSS_CHARBONNIER: k.w_charb = w / (float)n; k.eps2 = terms[i].param * terms[i].param; break;
+      case MDIE_LOSS_SSIM: has_ssim = 1; w_ssim = w; break;
+      case MDIE_LOSS_GRADIENT_L1: has_sobel = 1; w_sobel = w; sobel_gray = terms[i].param != 0.f; break;
+    }
+  }
+  if (has_ssim) MDIE_REQUIRE(H > 10 && W > 10, "mdie_loss_fwd_bwd: SSIM needs H, W > 10 (11x11 window), got %dx%d", H, W);
+
+  hipLaunchKernelGGL(loss_pointwise_kernel, dim3(LS_PW_BLOCKS), dim3(LS_THREADS), 0, s, n, pred, target, k, pw_part, grad);
+  if (has_ssim) {
+    Gauss11 gw;
+    double gs = 0.0;
+    for (int i = 0; i < 11; ++i) { const double d = (i - 5) / 1.5; gw.g[i] = (float)exp(-0.5 * d * d); gs += gw.g[i]; }
+    for (int i = 0; i < 11; ++i) gw.g[i] = (float)(gw.g[i] / gs);
+    const double n_win = (double)planes * (H - 10) * (W - 10);
+    f.n_ssim = planes * tiles; f.n_win = n_win;
+    hipLaunchKernelGGL(loss_minmax_kernel, dim3(LS_SLABS, planes), dim3(LS_THREADS), 0, s, HW, pred, target, mm);
+    hipLaunchKernelGGL(loss_range_kernel, dim3(1), dim3(LS_THREADS), 0, s, planes * LS_SLABS, mm, range);
+    hipLaunchKernelGGL(loss_ssim_fwd_kernel, dim3(tiles, planes), dim3(LS_THREADS), 0, s, H, W, pred, target, range, gw, spart, grad ? maps : nullptr, n);
+    if (grad)
+      hipLaunchKernelGGL(loss_ssim_bwd_kernel, dim3(tiles, planes), dim3(LS_THREADS), 0, s, H, W, pred, target, gw, maps, n, (float)(-(double)w_ssim / n_win),
+                         grad);
+  }
+  if (has_sobel) {
+    const int gplanes = sobel_gray ? B : planes;
+    const double n_grad = (double)gplanes * 2.0 * HW;
+    f.n_sobel = gplanes * tiles; f.n_grad = n_grad;
+    hipLaunchKernelGGL(loss_sobel_kernel, dim3(tiles, gplanes), dim3(LS_THREADS), 0, s, H, W, sobel_gray, pred, target, (float)((double)w_sobel / n_grad), gpart,
+                       grad);
+  }
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(LS_THREADS), 0, s, f, pw_part, spart, gpart, values);
+  MDIE_LAUNCH_CHECK("mdie_loss_fwd_bwd");
+  return MDIE_OK;
+}

@@ -160,23 +160,30 @@ __global__ __launch_bounds__(TR_THREADS) void wgrad_kernel(const WgradArgs a) {
 //   transposed = 1: dw[c][o][ks-1-kh][ks-1-kw]   (nn.ConvTranspose2d run as a flipped convolution)
 __global__ __launch_bounds__(TR_THREADS) void wgrad_reduce_kernel(int splits, int ks, int transposed, int cout, int cin, int cout_st, int cin_st,
                                                                   int split_c, int gap, const float* scratch, float* dw) {
+  // threads walk the slab in ITS order (output channel fastest): the `splits` reads of every element are
+  // coalesced; only the single write per element is scattered into PyTorch's layout
   const int ntap = ks * ks;
-  const size_t total = (size_t)cout * cin * ntap;
   const size_t slab = (size_t)ntap * cin_st * cout_st;
-  for (size_t u = (size_t)blockIdx.x * TR_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * TR_THREADS) {
+  for (size_t u = (size_t)blockIdx.x * TR_THREADS + threadIdx.x; u < slab; u += (size_t)gridDim.x * TR_THREADS) {
     size_t r = u;
-    const int tap = (int)(r % ntap); r /= ntap;
-    int o, c;
-    if (transposed) { o = (int)(r % cout); c = (int)(r / cout); }
-    else { c = (int)(r % cin); o = (int)(r / cin); }
-    const int kh = tap / ks, kw = tap - kh * ks;
-    const int stap = transposed ? (ks - 1 - kh) * ks + (ks - 1 - kw) : tap;   // tap of the convolution that was run
-    const int cs = c + (c >= split_c ? gap : 0);
-    const float* p = scratch + ((size_t)stap * cin_st + cs) * cout_st + o;
+    const int o = (int)(r % cout_st); r /= cout_st;
+    const int cs = (int)(r % cin_st);
+    const int stap = (int)(r / cin_st);                  // tap of the convolution that was run
+    int c = -1;                                          // real input channel of stored channel cs
+    if (cs < split_c) c = cs;
+    else if (cs >= split_c + gap) c = cs - gap;
+    if (o >= cout || c < 0 || c >= cin) continue;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += p[(size_t)k * slab];
-    dw[u] = s;
+    for (int k = 0; k < splits; ++k) s += scratch[(size_t)k * slab + u];
+    const int skh = stap / ks, skw = stap - skh * ks;
+    if (transposed) dw[(((size_t)c * cout + o) * ks + (ks - 1 - skh)) * ks + (ks - 1 - skw)] = s;
+    else dw[(((size_t)o * cin + c) * ks + skh) * ks + skw] = s;
   }
+}
+
+static int tr_grid(size_t total) {
+  size_t g = (total + TR_THREADS - 1) / TR_THREADS;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
 // ---- wgrad, bf16: pixel-tiled, all taps from one LDS image, v_mfma_f32_16x16x32_bf16 ---------------------------------
@@ -389,7 +396,7 @@ static WgTilePlan wgrad_tile_plan(int B, int H, int W, int cin_st, int cout_st) 
   p.tiles_x = cdiv(W, WT); p.tiles_y = cdiv(H, WT);
   p.total_tiles = B * p.tiles_x * p.tiles_y;
   const int base = p.c_tiles * p.o_tiles;
-  int splits = cdiv(512, base);                       // ~2 resident workgroups per CU
+  int splits = cdiv(base >= 16 ? 256 : 512, base);     // 1-2 resident workgroups per CU; fewer slabs for the big layers
   if (splits > p.total_tiles) splits = p.total_tiles;
   if (splits < 1) splits = 1;
   p.tiles_per_split = cdiv(p.total_tiles, splits);
@@ -405,11 +412,6 @@ static void launch_wgrad_tile(const WgradTileArgs& a, const WgTilePlan& p, hipSt
   static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
   if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   hipLaunchKernelGGL(kern, dim3(p.c_tiles * p.o_tiles, p.splits), dim3(TR_THREADS), lds, s, a);
-}
-
-static int tr_grid(size_t total) {
-  size_t g = (total + TR_THREADS - 1) / TR_THREADS;
-  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
 }  // namespace mdie
@@ -499,7 +501,7 @@ extern "C" int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream) {
       else launch_wgrad_tile<1, 1, 1, 1, 4>(t, p, s);
     }
     MDIE_LAUNCH_CHECK("mdie_conv_wgrad");
-    const size_t total = (size_t)d->cout * d->cin * taps;
+    const size_t total = (size_t)taps * c * d->cout_stored;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tr_grid(total)), dim3(TR_THREADS), 0, s, p.splits, d->ksize, d->transposed, d->cout, d->cin,
                        d->cout_stored, c, d->split, d->gap, t.scratch, d->dw);
     MDIE_LAUNCH_CHECK("mdie_conv_wgrad");
@@ -522,7 +524,7 @@ extern "C" int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream) {
     else hipLaunchKernelGGL((wgrad_kernel<mdie::bf16, 1>), grid, dim3(TR_THREADS), 0, s, a);
   }
   MDIE_LAUNCH_CHECK("mdie_conv_wgrad");
-  const size_t total = (size_t)d->cout * d->cin * taps;
+  const size_t total = (size_t)taps * c * d->cout_stored;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tr_grid(total)), dim3(TR_THREADS), 0, s, a.splits, d->ksize, d->transposed, d->cout, d->cin, d->cout_stored, c,
                      d->split, d->gap, a.scratch, d->dw);
   MDIE_LAUNCH_CHECK("mdie_conv_wgrad");

@@ -221,53 +221,43 @@ class RunLogger:
         pass
 
 
-# ---- losses (utils/loss_factory.py:146-230; terms that need downloaded networks are skipped) ----------------------------------
-def _ssim_torch(p, t):
-    """Differentiable SSIM with torchmetrics' default arguments (see csrc/post.hip / oracle.metrics_oracle)."""
-    L_ = torch.maximum(p.max() - p.min(), t.max() - t.min()).detach()
-    c1, c2 = (0.01 * L_) ** 2, (0.03 * L_) ** 2
-    d = torch.arange(-5, 6, dtype=p.dtype, device=p.device)
-    g = torch.exp(-0.5 * (d / 1.5) ** 2)
-    g = g / g.sum()
-    k = (g[:, None] * g[None, :]).reshape(1, 1, 11, 11).repeat(p.shape[1], 1, 1, 1)
-    f = lambda z: torch.nn.functional.conv2d(z, k, groups=z.shape[1])
-    mp, mt = f(p), f(t)
-    spp, stt, spt = f(p * p) - mp * mp, f(t * t) - mt * mt, f(p * t) - mp * mt
-    m = ((2 * mp * mt + c1) * (2 * spt + c2)) / ((mp * mp + mt * mt + c1) * (spp + stt + c2))
-    return m.reshape(m.shape[0], -1).mean(-1).mean()
+# ---- losses (utils/loss_factory.py:106-235; terms that need downloaded networks are skipped) -----------------------------------
+class LossPipeline:
+    """The reference's LossPipeline (utils/loss_factory.py:24-55) over the network-free terms, evaluated and
+    differentiated by ONE HIP call (csrc/loss.hip): `pipeline(outputs, targets) -> (total, values)` where total is
+    differentiable w.r.t. outputs and values[k] is term k unweighted (device tensor, values[-1] = total)."""
 
+    def __init__(self, terms):
+        self.terms = terms                       # [(name, weight, param)]
+        self.names = [n for n, _, _ in terms]
 
-def _sobel(x):
-    kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]], device=x.device, dtype=x.dtype)
-    k = torch.stack((kx, kx.t()), 0).unsqueeze(1).repeat(x.shape[1], 1, 1, 1)
-    b, c, h, w = x.shape
-    return torch.nn.functional.conv2d(x.reshape(b * c, 1, h, w), k[:2], padding=1)
+    def __len__(self):
+        return len(self.terms)
+
+    def __call__(self, outputs, targets):
+        from . import pipeline as PL
+        return PL.fused_loss(outputs, targets, self.terms)
 
 
 def build_losses(loss_cfg):
+    if not loss_cfg or not loss_cfg.get("enabled", True):
+        loss_cfg = {"terms": [{"name": "mse", "weight": 1.0}]}      # utils/loss_factory.py:120-122
     terms = []
-    for t in ((loss_cfg or {}).get("terms") or []) if (loss_cfg or {}).get("enabled", True) else []:
+    for t in loss_cfg.get("terms") or []:
         name, weight, args = t["name"], float(t.get("weight", 1.0)), (t.get("args") or {})
-        if name == "mse":
-            fn = lambda o, y: torch.mean((o - y) ** 2)
-        elif name == "l1":
-            fn = lambda o, y: torch.mean(torch.abs(o - y))
+        if name in ("mse", "l1", "ssim"):
+            param = 0.0
         elif name == "charbonnier":
-            eps = float(args.get("eps", 1e-3))
-            fn = lambda o, y, eps=eps: torch.mean(torch.sqrt((o - y) ** 2 + eps * eps))
-        elif name == "ssim":
-            fn = lambda o, y: 1.0 - _ssim_torch(o, y)
+            param = float(args.get("eps", 1e-3))
         elif name == "gradient_l1":
-            gray = bool(args.get("to_gray", False))
-            lum = lambda z: 0.2989 * z[:, 0:1] + 0.5870 * z[:, 1:2] + 0.1140 * z[:, 2:3]
-            fn = lambda o, y, gray=gray: torch.mean(torch.abs(_sobel(lum(o) if gray else o) - _sobel(lum(y) if gray else y)))
+            param = 1.0 if bool(args.get("to_gray", False)) else 0.0
         elif name in ("vgg_perceptual", "lpips"):
             warnings.warn(f"loss term '{name}' needs downloaded network weights and is skipped on the offline MI355X path")
             continue
         else:
             raise ValueError(f"Unknown loss term: {name}")
-        terms.append((name, weight, fn))
-    return terms
+        terms.append((name, weight, param))
+    return LossPipeline(terms)
 
 
 # ---- model harness ------------------------------------------------------------------------------------------------------
@@ -316,7 +306,7 @@ class Model:
         tr = self.config["train"]
         n_epoch, lr = int(tr["n_epoch"]), float(tr["lr"])
         losses = build_losses(self.config.get("loss"))
-        if not losses:
+        if len(losses) == 0:
             raise ValueError("training needs at least one usable loss term")
         opt = torch.optim.Adam(self.network.parameters(), lr=lr)
         buckets = T.GradBuckets(self.network.parameters()) if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
@@ -330,14 +320,13 @@ class Model:
                 x, y = self._to_device(inputs), self._to_device(targets)
                 opt.zero_grad(set_to_none=False)
                 out = self.network(x)
-                parts = {name: fn(out, y) for name, _, fn in losses}
-                total = sum(w * parts[name] for name, w, _ in losses)
+                total, values = losses(out, y)
                 total.backward()
                 if buckets is not None:
                     buckets.finish()     # averaged gradients (RCCL all-reduce launched from the grad hooks during backward)
                 opt.step()
-                vals = torch.stack([total.detach()] + [parts[name].detach() for name, _, _ in losses]).cpu().tolist()  # one sync per step
-                for k, v in zip(["total"] + [name for name, _, _ in losses], vals):
+                vals = values.cpu().tolist()  # one sync per step
+                for k, v in zip(losses.names + ["total"], vals):
                     sums[k] = sums.get(k, 0.0) + v
                 n += 1
             avg = {k: v / max(1, n) for k, v in sums.items()}

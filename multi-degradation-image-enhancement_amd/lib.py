@@ -12,9 +12,10 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 8
+ABI_VERSION = 9
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
+LOSS_KINDS = {"mse": 0, "l1": 1, "charbonnier": 2, "ssim": 3, "gradient_l1": 4}
 
 TAP_NAMES = ("skip0", "skip1", "skip2", "dense0", "dense1", "dense2", "enc", "bott", "dec1", "dec2", "dec3", "dec4")
 KERNEL_KINDS = ("layout", "conv3x3", "conv1x1", "cbam_pool", "cbam_gate", "cbam_chanpool", "cbam_spatial", "upsample_add", "tail")
@@ -42,6 +43,10 @@ class WgradDesc(C.Structure):
                 ("nseg", C.c_int), ("inp", Seg * MAX_SEG), ("cin", C.c_int), ("cout", C.c_int), ("cout_stored", C.c_int),
                 ("split", C.c_int), ("gap", C.c_int), ("dy", C.c_void_p), ("dy_stride", C.c_int), ("dw", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class LossTerm(C.Structure):
+    _fields_ = [("kind", C.c_int), ("weight", C.c_float), ("param", C.c_float)]
 
 
 class ConvFirstDesc(C.Structure):
@@ -132,6 +137,9 @@ SIGNATURES = {
     "mdie_metrics_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mdie_psnr_ssim": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                  C.c_void_p]),
+    "mdie_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "mdie_loss_fwd_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(LossTerm), C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "mdie_last_error": (C.c_char_p, []),
     "mdie_abi_version": (C.c_int, []),
 }

@@ -71,3 +71,37 @@ def psnr_ssim(pred, target):
     L.check(L.lib.mdie_psnr_ssim(B, H, W, p.data_ptr(), t.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, _stream_ptr(p.device)),
             "mdie_psnr_ssim")
     return out
+
+
+# ---- training loss (utils/loss_factory.py:146-230), value + gradient in one HIP call -------------------------------------
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, terms):
+        p, t = pred.detach().contiguous().float(), target.detach().contiguous().float()
+        B, ch, H, W = p.shape
+        if ch != 3:
+            raise L.MdieError(f"fused_loss: 3-channel images only, got {ch}")
+        arr = (L.LossTerm * len(terms))(*[L.LossTerm(L.LOSS_KINDS[n], float(w), float(a)) for n, w, a in terms])
+        nws = L.lib.mdie_loss_workspace_bytes(B, H, W)
+        ws = torch.empty(nws, dtype=torch.uint8, device=p.device)
+        values = torch.empty(len(terms) + 1, dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p) if pred.requires_grad else None
+        L.check(L.lib.mdie_loss_fwd_bwd(B, H, W, p.data_ptr(), t.data_ptr(), arr, len(terms), values.data_ptr(),
+                                        grad.data_ptr() if grad is not None else None, ws.data_ptr(), nws, _stream_ptr(p.device)),
+                "mdie_loss_fwd_bwd")
+        ctx.grad = grad
+        ctx.mark_non_differentiable(values)
+        return values[len(terms)].clone(), values
+
+    @staticmethod
+    def backward(ctx, g_total, _g_values):
+        g = ctx.grad
+        ctx.grad = None
+        return (g * g_total if g is not None else None), None, None
+
+
+def fused_loss(pred, target, terms):
+    """terms: [(name, weight, param)], name in lib.LOSS_KINDS; param = eps (charbonnier) / to_gray (gradient_l1).
+    Returns (total, values): total is differentiable w.r.t. pred; values[k] is term k unweighted, values[-1] = total."""
+    _require_gpu(pred, "fused_loss")
+    return _LossFn.apply(pred, target, tuple(terms))

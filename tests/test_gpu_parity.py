@@ -575,3 +575,53 @@ def test_run_py_train_phase(E, tmp_path):
     assert len(model.history) == 2 and all(np.isfinite(h["total"]) for h in model.history)
     assert set(model.history[0]) == {"total", "charbonnier", "ssim"}
     assert len(torch.load(os.path.join(root, "weights", "CDAN_t.pt"))) == 236
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training loss on the device: value and gradient of every network-free term vs the CPU oracle
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("terms,shape", [
+    ([("charbonnier", 1.0, 1e-3), ("ssim", 0.5, 0.0)], (2, 3, 64, 64)),                                   # blur / noise configs
+    ([("mse", 1.0, 0.0), ("ssim", 0.5, 0.0)], (1, 3, 40, 56)),                                            # low_light (network-free part)
+    ([("l1", 1.0, 0.0), ("ssim", 0.5, 0.0)], (3, 3, 23, 37)),                                             # jpeg, ragged tiles
+    ([("charbonnier", 1.0, 1e-3), ("ssim", 0.5, 0.0), ("gradient_l1", 0.35, 1.0)], (2, 3, 48, 33)),       # pixelation_hard
+    ([("gradient_l1", 1.0, 0.0), ("mse", 0.25, 0.0)], (2, 3, 17, 16)),
+    ([("ssim", 1.0, 0.0)], (1, 3, 11, 11)),                                                               # one window
+])
+def test_fused_loss_matches_oracle(E, terms, shape):
+    from mdie_amd import pipeline as PL
+    from oracle import loss_oracle as LO
+    g = torch.Generator().manual_seed(shape[2] * 31 + shape[3])
+    t = torch.rand(*shape, generator=g)
+    o = (t * 0.6 + 0.15 * torch.rand(*shape, generator=g)).clamp(0, 1)
+    ro = o.double().requires_grad_(True)
+    rtotal, rvals = LO.pipeline(ro, t.double(), terms)
+    rtotal.backward()
+    go = o.cuda().requires_grad_(True)
+    total, values = PL.fused_loss(go, t.cuda(), terms)
+    (2.0 * total).backward()                               # upstream gradient is honoured
+    assert total.item() == pytest.approx(rtotal.item(), rel=2e-5)           # fp32 kernels vs fp64 oracle
+    for k, rv in enumerate(rvals):
+        assert values[k].item() == pytest.approx(rv.item(), rel=2e-5, abs=1e-7), terms[k][0]
+    assert values[-1].item() == pytest.approx(rtotal.item(), rel=2e-5)
+    # sign() terms flip where |d| is at rounding level: compare where the fp64 argument is clear of zero
+    err = (go.grad.cpu().double() / 2.0 - ro.grad).abs()
+    tol = 2e-4 * ro.grad.abs().max().item()
+    if any(n in ("l1", "gradient_l1") for n, _, _ in terms):
+        assert (err > tol).double().mean().item() < 1e-3
+    else:
+        assert err.max().item() <= tol
+
+
+def test_fused_loss_values_only_and_errors(E):
+    from mdie_amd import pipeline as PL
+    t = torch.rand(1, 3, 16, 16).cuda()
+    o = torch.rand(1, 3, 16, 16).cuda()
+    total, values = PL.fused_loss(o, t, [("mse", 1.0, 0.0)])          # no grad requested: values only
+    assert not total.requires_grad and total.item() == pytest.approx(((o - t) ** 2).mean().item(), rel=1e-5)
+    with pytest.raises(Exception):
+        PL.fused_loss(o.cpu(), t.cpu(), [("mse", 1.0, 0.0)])           # no CPU fallback
+    with pytest.raises(Exception):
+        PL.fused_loss(o[:, :, :8, :8], t[:, :, :8, :8], [("ssim", 1.0, 0.0)])   # smaller than one 11x11 window
+    with pytest.raises(Exception):
+        PL.fused_loss(o, t, [("mse", 1.0, 0.0), ("mse", 1.0, 0.0)])

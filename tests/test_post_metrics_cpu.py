@@ -70,3 +70,57 @@ def test_psnr_restatement():
     t[0, 0, 0, 0] = 0.9  # data range = max(target) - min(target, 0) = 0.9
     p = t + 0.1
     assert M.psnr(p, t) == pytest.approx(10 * np.log10(0.81 / 0.01), rel=1e-6)
+
+
+# ---- loss oracle (utils/loss_factory.py:146-230 restated) -----------------------------------------------------------
+def _pair(seed, b=2, h=24, w=20):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.rand(b, 3, h, w, generator=g, dtype=torch.float64)
+    o = (t + 0.1 * torch.randn(b, 3, h, w, generator=g, dtype=torch.float64)).clamp(0, 1)
+    return o, t
+
+
+def test_loss_oracle_ssim_term_is_one_minus_the_metric():
+    from oracle import loss_oracle as LO
+    o, t = _pair(3)
+    assert LO.ssim_loss(o, t).item() == pytest.approx(1.0 - M.ssim(o, t), abs=1e-12)
+
+
+def test_loss_oracle_known_answers():
+    """hand-computable cases of each term"""
+    from oracle import loss_oracle as LO
+    o = torch.zeros(1, 3, 12, 12, dtype=torch.float64)
+    t = torch.full((1, 3, 12, 12), 0.5, dtype=torch.float64)
+    assert LO.mse(o, t).item() == pytest.approx(0.25)
+    assert LO.l1(o, t).item() == pytest.approx(0.5)
+    assert LO.charbonnier(o, t, 1e-3).item() == pytest.approx((0.25 + 1e-6) ** 0.5)
+    # Sobel of a constant difference is zero inside and +-(3|4)*0.5 at the zero-padded border
+    d = LO._sobel(o[:, :1] - t[:, :1])
+    assert d[0, 0, :, 1:-1, 1:-1].abs().max().item() == 0.0
+    assert d[0, 0, 0, 5, 0].item() == pytest.approx(-(1 + 2 + 1) * 0.5)     # dx at the left edge: right column only
+    # a horizontal unit ramp has dx = 8 everywhere inside
+    ramp = torch.arange(12, dtype=torch.float64).reshape(1, 1, 1, 12).expand(1, 1, 12, 12)
+    assert torch.all(LO._sobel(ramp)[0, 0, 0, 1:-1, 1:-1] == 8.0)
+    # luminance weights
+    rgb = torch.zeros(1, 3, 12, 12, dtype=torch.float64)
+    rgb[:, 1] = ramp[0]
+    assert LO.gradient_l1(rgb, torch.zeros_like(rgb), to_gray=True).item() > 0
+
+
+def test_loss_oracle_gradients_by_finite_differences():
+    from oracle import loss_oracle as LO
+    terms = [("charbonnier", 1.0, 1e-3), ("ssim", 0.5, 0.0), ("mse", 0.3, 0.0)]
+    o, t = _pair(5, b=1, h=14, w=13)
+    o = o.requires_grad_(True)
+    total, _ = LO.pipeline(o, t, terms)
+    total.backward()
+    g = o.grad.clone()
+    idx = [(0, 0, 7, 6), (0, 2, 0, 0), (0, 1, 13, 12), (0, 1, 5, 9)]
+    for i in idx:
+        e = torch.zeros_like(o)
+        e[i] = 1e-6
+        with torch.no_grad():
+            # interior points only move the data range when they are the extreme: central difference is robust to that
+            fp, _ = LO.pipeline(o + e, t, terms)
+            fm, _ = LO.pipeline(o - e, t, terms)
+        assert ((fp - fm) / 2e-6).item() == pytest.approx(g[i].item(), rel=2e-4, abs=1e-9)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Training-step timing (BASELINE configs[2] shape: blur-style loss, 512x512, batch 8 per GPU).
-  python tools/bench_train.py [bf16|fp32] [B] [S]      (under torchrun: one rank per GPU, bucketed RCCL all-reduce)"""
+  python tools/bench_train.py [bf16|fp32] [B] [S] [loss terms, e.g. charbonnier:1,ssim:0.5]      (under torchrun: one rank per GPU, bucketed RCCL all-reduce)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,14 +23,15 @@ torch.manual_seed(42)
 net = CDAN(precision=prec).cuda().train()
 x, t = P.lowlight_batch(100 + rank, B, S, S)
 x, t = x.cuda(), t.cuda()
-losses = H.build_losses({"enabled": True, "terms": [{"name": "charbonnier", "weight": 1.0}, {"name": "ssim", "weight": 0.5}]})
+spec = sys.argv[4] if len(sys.argv) > 4 else "charbonnier:1,ssim:0.5"
+losses = H.build_losses({"enabled": True, "terms": [{"name": s.split(":")[0], "weight": float(s.split(":")[1])} for s in spec.split(",")]})
 opt = torch.optim.Adam(net.parameters(), lr=1e-3)
 buckets = T.GradBuckets(net.parameters()) if dist is not None else None
 
 def step():
     opt.zero_grad(set_to_none=False)
     out = net(x)
-    total = sum(w * fn(out, t) for _, w, fn in losses)
+    total, _ = losses(out, t)
     total.backward()
     if buckets is not None:
         buckets.finish()
@@ -47,4 +48,4 @@ for _ in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 if rank == 0:
-    print(f"train[{prec}] B={B}x{world} {S}x{S}: {dt*1e3:.1f} ms/step, {B*world/dt:.1f} img/s, loss {l.item():.4f}")
+    print(f"train[{prec}] B={B}x{world} {S}x{S} loss={spec}: {dt*1e3:.1f} ms/step, {B*world/dt:.1f} img/s, loss {l.item():.4f}")
