@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 9
+#define MDIE_ABI_VERSION 10
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -130,6 +130,8 @@ typedef struct {
   const void* dy; int dy_stride;
   float* dw;               /* fp32, PyTorch layout */
   void* workspace; size_t workspace_bytes;   /* >= mdie_conv_wgrad_workspace_bytes */
+  const float* pre_scale;  /* optional, per stored input channel: the convolution's input was relu(x * pre_scale + pre_shift), */
+  const float* pre_shift;  /* applied while staging exactly as mdie_conv_fwd does (dense layers, models/cdan.py:41-46) */
 } mdie_wgrad_desc;
 
 size_t mdie_conv_wgrad_workspace_bytes(int B, int H, int W, int ksize, int cin_stored, int cout_stored);
@@ -334,6 +336,77 @@ int mdie_postprocess(int B, int H, int W, const float* y, const mdie_pp_op* ops,
 size_t mdie_metrics_workspace_bytes(int B, int H, int W);
 int mdie_psnr_ssim(int B, int H, int W, const float* pred, const float* target, float* out2, void* workspace,
                    size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Training-mode glue (csrc/bn.hip): batch-statistic BatchNorm (models/cdan.py:12,43,50,105-116) split into
+ * statistics / fold / fused apply, its backward, and the ops fused with it (ReLU, nn.MaxPool2d(2,2) :67,
+ * nn.Dropout(0.2) :68, F.interpolate x2 + add :137-138, the final sigmoid :157).  All tensors NHWC with a
+ * pixel stride in elements; C a multiple of 16.
+ * --------------------------------------------------------------------------------- */
+size_t mdie_bn_workspace_bytes(int C);
+/* mean[C], var[C] (biased) over N pixels */
+int mdie_bn_stats(int dtype, long N, const void* x, int C, int stride, float* mean, float* var, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* scale = gamma / sqrt(var + eps), shift = beta - mean * scale, invstd, per STORED channel (mean / var / outputs are
+ * indexed by stored channel; gamma / beta / running_* by real channel: real c >= split is stored at c + gap; padding
+ * gets scale = shift = 0).  running_* (nullable) are updated with `momentum` and the unbiased variance. */
+int mdie_bn_fold(int C_stored, int C_real, int split, int gap, const float* mean, const float* var, const float* gamma,
+                 const float* beta, float eps, float momentum, long count, float* running_mean, float* running_var,
+                 float* scale, float* shift, float* invstd, void* stream);
+/* out = pool2x2?(relu(y * scale + shift)); out_drop = dropout_p(out) (mask = hash(seed, element index), recomputed by
+ * the backward); either output may be NULL */
+int mdie_bn_act_pool_fwd(int dtype, int B, int H, int W, int C, const void* y, int y_stride, const float* scale,
+                         const float* shift, int pool, void* out, int out_stride, void* out_drop, int drop_stride,
+                         float p, unsigned seed, void* stream);
+typedef struct {
+  int dtype, B, H, W, C, c_real;          /* H, W: resolution of y */
+  const void* y; int y_stride;
+  const float *scale, *shift, *mean, *invstd;
+  int pool;
+  const void* d_out; int d_out_stride;    /* gradient w.r.t. `out` (or NULL) */
+  const void* d_drop; int d_drop_stride;  /* gradient w.r.t. `out_drop` (or NULL) */
+  float p; unsigned seed;
+  void* dz; int dz_stride;                /* out: masked, pool-routed gradient at y's resolution */
+  float* dgamma; float* dbeta;            /* out: [c_real] */
+  float* coef;                            /* out: [2][C], consumed by mdie_bn_bwd_apply */
+  void* workspace; size_t workspace_bytes;
+} mdie_bn_pool_bwd_desc;
+int mdie_bn_act_pool_bwd(const mdie_bn_pool_bwd_desc* d, void* stream);
+/* out = up2x?(relu(y * scale + shift)) + skip (skip nullable); y at [B,H,W], out / skip at [B,2H,2W] when up */
+int mdie_bn_act_up_add_fwd(int dtype, int B, int H, int W, int C, const void* y, int y_stride, const float* scale,
+                           const float* shift, int up, const void* skip, int skip_stride, void* out, int out_stride,
+                           void* stream);
+typedef struct {
+  int dtype, B, H, W, C, c_real;          /* H, W: resolution of y (low) */
+  const void* y; int y_stride;
+  const float *scale, *shift, *mean, *invstd;
+  const void* dout; int dout_stride;      /* [B,2H,2W,C] */
+  void* dz; int dz_stride;
+  float* dgamma; float* dbeta;
+  float* coef;
+  void* workspace; size_t workspace_bytes;
+} mdie_bn_up_bwd_desc;
+int mdie_bn_act_up_bwd(const mdie_bn_up_bwd_desc* d, void* stream);
+/* BatchNorm backward proper.  reduce: dz = da * [x * scale + shift > 0] (relu != 0) -> dgamma, dbeta, coef.
+ * apply: g (=|+=, bit s of `accumulate` per segment) scale * (dz - coef[0] - xhat * coef[1]). */
+typedef struct {
+  int dtype; long N;
+  int nseg; mdie_seg x[MDIE_MAX_SEG];     /* the normalised tensor (a concatenation of segments) */
+  mdie_seg g[MDIE_MAX_SEG];               /* apply: destination, same partition */
+  unsigned accumulate;
+  const void* da; int da_stride;
+  const float *mean, *invstd, *scale, *shift;
+  int relu;
+  int c_real, split, gap;                 /* reduce: layout of dgamma / dbeta */
+  float* dgamma; float* dbeta;
+  float* coef;                            /* [2][C] */
+  void* workspace; size_t workspace_bytes;
+} mdie_bn_bwd_desc;
+int mdie_bn_bwd_reduce(const mdie_bn_bwd_desc* d, void* stream);
+int mdie_bn_bwd_apply(const mdie_bn_bwd_desc* d, void* stream);
+/* dz[NHWC16] = grad[NCHW3] * y * (1 - y), padding channels zero (torch.sigmoid, models/cdan.py:157) */
+int mdie_sigmoid_bwd_nchw3(int dtype, int B, int H, int W, const float* grad_nchw, const float* y_nchw, void* dz_nhwc16,
+                           int dz_stride, void* stream);
 
 /* Training loss, value and gradient in one call (utils/loss_factory.py:146-230; models/model.py:161-164 evaluates the
  * pipeline and calls backward on it every step).  Terms that need downloaded networks (vgg_perceptual, lpips) are

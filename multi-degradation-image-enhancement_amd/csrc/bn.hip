@@ -1,0 +1,749 @@
+// Training-mode glue around the convolutions: batch-statistic
+// BatchNorm, ReLU, 2x2 max-pool, dropout, bilinear 2x upsampling + skip add, the final sigmoid -- forward and
+// backward -- as a handful of fused bandwidth kernels over NHWC tensors.
+//
+// BatchNorm in training mode (nn.BatchNorm2d, models/cdan.py:12,43,50,105-116) splits into
+//   stats     per-channel sum / sum of squares over B*H*W         (two-level, ordered: bit-reproducible)
+//   fold      mean, biased var -> scale = gamma / sqrt(var + eps), shift = beta - mean * scale, invstd; running
+//             statistics updated with momentum and the unbiased variance
+//   apply     never on its own: the normalisation is either the PROLOGUE of the next convolution (dense layers:
+//             relu(x * scale + shift) while staging, mdie_conv_fwd / mdie_conv_wgrad pre_scale) or fused with
+//             ReLU + max-pool + dropout (encoder ConvBlocks) or ReLU + upsample + skip add (decoder stages).
+// and its backward into
+//   producer  the masked upstream gradient dz = da * [z > 0] (+ pool routing / dropout / transposed upsampling)
+//             together with per-block partial sums of dz and dz * xhat
+//   final     dgamma = sum dz * xhat, dbeta = sum dz, per-channel constants k2 = dbeta / N, k3 = dgamma / N
+//   apply     dx = scale * (dz - k2 - xhat * k3), written or accumulated into the input's gradient
+// A dense block's channel statistics are computed ONCE per segment (every later layer normalises the same
+// tensor with the same batch statistics and only its own gamma / beta), instead of once per consuming layer.
+#include "common.hpp"
+
+namespace mdie {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_MAX_BLOCKS = 512;
+
+struct SegP { const char* ptr; int ch_begin, ch_end, stride; };   // stride in elements
+struct SegW { char* ptr; int ch_begin, ch_end, stride; };
+
+// (channel vector, pixel row) decomposition of a block: thread t -> cv = t % CV, row = t / CV, rows = 256 / CV
+struct BlkMap {
+  int cv, row, rows;
+  bool active;
+};
+__device__ __forceinline__ BlkMap blk_map(int CV) {
+  BlkMap m;
+  m.rows = BN_THREADS / CV;
+  m.cv = threadIdx.x % CV;
+  m.row = threadIdx.x / CV;
+  m.active = m.row < m.rows;
+  return m;
+}
+
+// fold the per-thread sums s[K][VEC] over the rows of the block and write partial[blk][k][c]
+template <int VEC, int K>
+__device__ __forceinline__ void block_fold(const float (&s)[K][VEC], const BlkMap& m, int CV, int C, float* lds, float* partial) {
+  // lds[row][k][cv*VEC + i]
+  if (m.active) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) lds[(m.row * K + k) * C + m.cv * VEC + i] = s[k][i];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < K * C; o += BN_THREADS) {
+    float t = 0.f;
+    for (int r = 0; r < m.rows; ++r) t += lds[r * K * C + o];
+    partial[(size_t)blockIdx.x * K * C + o] = t;
+  }
+}
+
+// ---- statistics ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(long N, const char* x, int C, int stride, long chunk, float* partial) {
+  constexpr int VEC = Traits<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  const int CV = C / VEC;
+  const BlkMap m = blk_map(CV);
+  float s[2][VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[0][i] = s[1][i] = 0.f;
+  if (m.active) {
+    const long b = (long)blockIdx.x * chunk, e = min(N, b + chunk);
+    for (long p = b + m.row; p < e; p += m.rows) {
+      float f[VEC];
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + ((size_t)p * stride) * sizeof(T) + (size_t)m.cv * 16), f);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { s[0][i] += f[i]; s[1][i] = fmaf(f[i], f[i], s[1][i]); }
+    }
+  }
+  block_fold<VEC, 2>(s, m, CV, C, reinterpret_cast<float*>(dyn), partial);
+}
+
+// one 64-lane block per channel: ordered double-precision fold of the block partials
+__global__ __launch_bounds__(64) void bn_stats_final_kernel(int nblk, int C, double n, const float* partial, float* mean, float* var) {
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) { s1 += partial[((size_t)b * 2 + 0) * C + c]; s2 += partial[((size_t)b * 2 + 1) * C + c]; }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
+  if (threadIdx.x == 0) {
+    const double mu = s1 / n;
+    mean[c] = (float)mu;
+    var[c] = (float)fmax(s2 / n - mu * mu, 0.0);
+  }
+}
+
+// stored channel cs -> real parameter channel (or -1 for padding): real c >= split sits at c + gap
+__device__ __forceinline__ int real_channel(int cs, int split, int gap, int c_real) {
+  int c = -1;
+  if (cs < split) c = cs;
+  else if (cs >= split + gap) c = cs - gap;
+  return (c >= 0 && c < c_real) ? c : -1;
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_fold_kernel(int C_st, int C_real, int split, int gap, const float* mean, const float* var, const float* gamma,
+                                                             const float* beta, float eps, float momentum, double n, float* rmean, float* rvar, float* scale,
+                                                             float* shift, float* invstd) {
+  const int cs = blockIdx.x * BN_THREADS + threadIdx.x;
+  if (cs >= C_st) return;
+  const int c = real_channel(cs, split, gap, C_real);
+  if (c < 0) { scale[cs] = 0.f; shift[cs] = 0.f; invstd[cs] = 0.f; return; }
+  const float is = 1.0f / sqrtf(var[cs] + eps);
+  const float sc = gamma[c] * is;
+  scale[cs] = sc; shift[cs] = beta[c] - mean[cs] * sc; invstd[cs] = is;
+  if (rmean) {
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[cs];
+    const float unbiased = n > 1.0 ? (float)(var[cs] * n / (n - 1.0)) : var[cs];
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+  }
+}
+
+// ---- dropout: counter-based, recomputed in backward from (seed, element index) ----------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+// multiplier applied to element idx: 0 (dropped) or 1 / (1 - p)
+__device__ __forceinline__ float drop_factor(uint32_t seed, size_t idx, float p, float keep_scale) {
+  const uint32_t h = mix32((uint32_t)idx ^ mix32(seed ^ (uint32_t)(idx >> 32) * 0x9e3779b9U));
+  return ((h >> 8) * (1.0f / 16777216.0f)) >= p ? keep_scale : 0.f;
+}
+
+// ---- forward: BN + ReLU (+ 2x2 max-pool) (+ dropout) ---------------------------------------------------------------------
+// out_o = pool?(relu(y * scale + shift)), out_t = dropout(out_o); either output may be null
+template <typename T, bool POOL>
+__global__ __launch_bounds__(BN_THREADS) void bn_act_pool_fwd_kernel(int B, int H, int W, int C, const char* y, int y_stride, const float* scale,
+                                                                     const float* shift, char* out_o, int o_stride, char* out_t, int t_stride, float p,
+                                                                     uint32_t seed) {
+  constexpr int VEC = Traits<T>::VEC;
+  const int CV = C / VEC;
+  const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+  const size_t total = (size_t)B * Ho * Wo * CV;
+  const float ks = 1.0f / (1.0f - p);
+  for (size_t u = (size_t)blockIdx.x * BN_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * BN_THREADS) {
+    const int v = (int)(u % CV);
+    const size_t op = u / CV;                       // output pixel index
+    float sc[VEC], sh[VEC], r[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { sc[i] = scale[v * VEC + i]; sh[i] = shift[v * VEC + i]; }
+    if (POOL) {
+      const int ox = (int)(op % Wo);
+      const size_t q = op / Wo;
+      const int oy = (int)(q % Ho), img = (int)(q / Ho);
+      const size_t ip = ((size_t)img * H + 2 * oy) * W + 2 * ox;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) r[i] = 0.f;      // relu folded into the running maximum
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float f[VEC];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(y + (ip + (k >> 1) * W + (k & 1)) * y_stride * sizeof(T) + (size_t)v * 16), f);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r[i] = fmaxf(r[i], fmaf(f[i], sc[i], sh[i]));
+      }
+    } else {
+      float f[VEC];
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(y + op * y_stride * sizeof(T) + (size_t)v * 16), f);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) r[i] = fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f);
+    }
+    if (out_o) *reinterpret_cast<uint4*>(out_o + op * o_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(r);
+    if (out_t) {
+      if (p > 0.f) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r[i] *= drop_factor(seed, op * C + v * VEC + i, p, ks);
+      }
+      *reinterpret_cast<uint4*>(out_t + op * t_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(r);
+    }
+  }
+}
+
+// ---- backward producer of the same site ------------------------------------------------------------------------------------
+// g = d_o + dropout_mask * d_t (at the output resolution); dz = g routed to the arg-max of the 2x2 window (first maximum in
+// scan order, like ATen) and masked by z > 0; writes dz at the input resolution and the block's partial sums.
+struct BnBwdPoolArgs {
+  int B, H, W, C;
+  const char* y; int y_stride;
+  const float *scale, *shift, *mean, *invstd;
+  const char* d_o; int do_stride;
+  const char* d_t; int dt_stride;
+  float p; uint32_t seed;
+  char* dz; int dz_stride;
+  float* partial;
+  long chunk;    // output pixels per block
+};
+
+template <typename T, bool POOL>
+__global__ __launch_bounds__(BN_THREADS) void bn_act_pool_bwd_kernel(const BnBwdPoolArgs a) {
+  constexpr int VEC = Traits<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  const int CV = a.C / VEC;
+  const BlkMap m = blk_map(CV);
+  const int Ho = POOL ? a.H / 2 : a.H, Wo = POOL ? a.W / 2 : a.W;
+  const long NO = (long)a.B * Ho * Wo;
+  const float ks = 1.0f / (1.0f - a.p);
+  float s[2][VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[0][i] = s[1][i] = 0.f;
+  if (m.active) {
+    const int v = m.cv;
+    float sc[VEC], sh[VEC], mu[VEC], is[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { sc[i] = a.scale[v * VEC + i]; sh[i] = a.shift[v * VEC + i]; mu[i] = a.mean[v * VEC + i]; is[i] = a.invstd[v * VEC + i]; }
+    const long b = (long)blockIdx.x * a.chunk, e = min(NO, b + a.chunk);
+    for (long op = b + m.row; op < e; op += m.rows) {
+      float g[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+      if (a.d_o) {
+        float f[VEC];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.d_o + (size_t)op * a.do_stride * sizeof(T) + (size_t)v * 16), f);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g[i] = f[i];
+      }
+      if (a.d_t) {
+        float f[VEC];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.d_t + (size_t)op * a.dt_stride * sizeof(T) + (size_t)v * 16), f);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g[i] += a.p > 0.f ? f[i] * drop_factor(a.seed, (size_t)op * a.C + v * VEC + i, a.p, ks) : f[i];
+      }
+      if (POOL) {
+        const int ox = (int)(op % Wo);
+        const long q = op / Wo;
+        const int oy = (int)(q % Ho), img = (int)(q / Ho);
+        const size_t ip = ((size_t)img * a.H + 2 * oy) * a.W + 2 * ox;
+        float yv[4][VEC];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.y + (ip + (k >> 1) * a.W + (k & 1)) * a.y_stride * sizeof(T) + (size_t)v * 16), yv[k]);
+        float dz[4][VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          float best = fmaf(yv[0][i], sc[i], sh[i]);
+          int arg = 0;
+#pragma unroll
+          for (int k = 1; k < 4; ++k) {
+            const float z = fmaf(yv[k][i], sc[i], sh[i]);
+            if (z > best) { best = z; arg = k; }
+          }
+          const float d = best > 0.f ? g[i] : 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dz[k][i] = k == arg ? d : 0.f;
+          float ya = yv[0][i];
+#pragma unroll
+          for (int k = 1; k < 4; ++k) ya = k == arg ? yv[k][i] : ya;
+          s[0][i] += d;
+          s[1][i] = fmaf(d, (ya - mu[i]) * is[i], s[1][i]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          *reinterpret_cast<uint4*>(a.dz + (ip + (k >> 1) * a.W + (k & 1)) * a.dz_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(dz[k]);
+      } else {
+        float yv[VEC], dz[VEC];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.y + (size_t)op * a.y_stride * sizeof(T) + (size_t)v * 16), yv);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float d = fmaf(yv[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
+          dz[i] = d;
+          s[0][i] += d;
+          s[1][i] = fmaf(d, (yv[i] - mu[i]) * is[i], s[1][i]);
+        }
+        *reinterpret_cast<uint4*>(a.dz + (size_t)op * a.dz_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(dz);
+      }
+    }
+  }
+  block_fold<VEC, 2>(s, m, CV, a.C, reinterpret_cast<float*>(dyn), a.partial);
+}
+
+// ---- forward: BN + ReLU (+ bilinear 2x) + skip ---------------------------------------------------------------------------
+__device__ __forceinline__ void up_src(int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
+  // ATen's half-pixel source index (align_corners=False): src = max(0, (dst + 0.5) / 2 - 0.5)
+  float src = ((float)dst + 0.5f) * 0.5f - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+// out = up2?(relu(y * scale + shift)) + skip    (y at [B,H,W]; out and skip at [B,2H,2W] when UP)
+template <typename T, bool UP>
+__global__ __launch_bounds__(BN_THREADS) void bn_act_up_add_fwd_kernel(int B, int H, int W, int C, const char* y, int y_stride, const float* scale,
+                                                                       const float* shift, const char* skip, int skip_stride, char* out, int out_stride) {
+  constexpr int VEC = Traits<T>::VEC;
+  const int CV = C / VEC;
+  const int Ho = UP ? 2 * H : H, Wo = UP ? 2 * W : W;
+  const size_t total = (size_t)B * Ho * Wo * CV;
+  for (size_t u = (size_t)blockIdx.x * BN_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * BN_THREADS) {
+    const int v = (int)(u % CV);
+    const size_t op = u / CV;
+    float sc[VEC], sh[VEC], r[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { sc[i] = scale[v * VEC + i]; sh[i] = shift[v * VEC + i]; }
+    auto act = [&](size_t pix, float* f) {
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(y + pix * y_stride * sizeof(T) + (size_t)v * 16), f);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) f[i] = fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f);
+    };
+    if (UP) {
+      const int ox = (int)(op % Wo);
+      const size_t q = op / Wo;
+      const int oy = (int)(q % Ho), img = (int)(q / Ho);
+      int y0, y1, x0, x1;
+      float hy0, hy1, wx0, wx1;
+      up_src(oy, H, y0, y1, hy0, hy1);
+      up_src(ox, W, x0, x1, wx0, wx1);
+      const size_t ib = (size_t)img * H * W;
+      float a00[VEC], a01[VEC], a10[VEC], a11[VEC];
+      act(ib + (size_t)y0 * W + x0, a00); act(ib + (size_t)y0 * W + x1, a01);
+      act(ib + (size_t)y1 * W + x0, a10); act(ib + (size_t)y1 * W + x1, a11);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) r[i] = hy0 * (wx0 * a00[i] + wx1 * a01[i]) + hy1 * (wx0 * a10[i] + wx1 * a11[i]);
+    } else {
+      act(op, r);
+    }
+    if (skip) {
+      float sk[VEC];
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(skip + op * skip_stride * sizeof(T) + (size_t)v * 16), sk);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) r[i] += sk[i];
+    }
+    *reinterpret_cast<uint4*>(out + op * out_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(r);
+  }
+}
+
+// backward producer: dz[lo] = (transposed bilinear 2x of dout)[lo] * [z > 0], + partial sums
+struct BnBwdUpArgs {
+  int B, H, W, C;                    // low (y) resolution
+  const char* y; int y_stride;
+  const float *scale, *shift, *mean, *invstd;
+  const char* dout; int dout_stride; // [B, 2H, 2W, C]
+  char* dz; int dz_stride;
+  float* partial;
+  long chunk;
+};
+
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_act_up_bwd_kernel(const BnBwdUpArgs a) {
+  constexpr int VEC = Traits<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  const int CV = a.C / VEC;
+  const BlkMap m = blk_map(CV);
+  const long N = (long)a.B * a.H * a.W;
+  const int Ho = 2 * a.H, Wo = 2 * a.W;
+  float s[2][VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[0][i] = s[1][i] = 0.f;
+  if (m.active) {
+    const int v = m.cv;
+    float sc[VEC], sh[VEC], mu[VEC], is[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { sc[i] = a.scale[v * VEC + i]; sh[i] = a.shift[v * VEC + i]; mu[i] = a.mean[v * VEC + i]; is[i] = a.invstd[v * VEC + i]; }
+    const long b = (long)blockIdx.x * a.chunk, e = min(N, b + a.chunk);
+    for (long p = b + m.row; p < e; p += m.rows) {
+      const int x = (int)(p % a.W);
+      const long q = p / a.W;
+      const int yy = (int)(q % a.H), img = (int)(q / a.H);
+      float g[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+      // every output row/column whose two sources can include (yy, x): 2*yy-1 .. 2*yy+2
+      for (int dy = -1; dy <= 2; ++dy) {
+        const int oy = 2 * yy + dy;
+        if (oy < 0 || oy >= Ho) continue;
+        int y0, y1; float h0, h1;
+        up_src(oy, a.H, y0, y1, h0, h1);
+        const float wy = (y0 == yy ? h0 : 0.f) + (y1 == yy ? h1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int dx = -1; dx <= 2; ++dx) {
+          const int ox = 2 * x + dx;
+          if (ox < 0 || ox >= Wo) continue;
+          int x0, x1; float w0, w1;
+          up_src(ox, a.W, x0, x1, w0, w1);
+          const float wx = (x0 == x ? w0 : 0.f) + (x1 == x ? w1 : 0.f);
+          if (wx == 0.f) continue;
+          float f[VEC];
+          Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.dout + (((size_t)img * Ho + oy) * Wo + ox) * a.dout_stride * sizeof(T) + (size_t)v * 16), f);
+          const float wgt = wy * wx;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) g[i] = fmaf(wgt, f[i], g[i]);
+        }
+      }
+      float yv[VEC], dz[VEC];
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.y + (size_t)p * a.y_stride * sizeof(T) + (size_t)v * 16), yv);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float d = fmaf(yv[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
+        dz[i] = d;
+        s[0][i] += d;
+        s[1][i] = fmaf(d, (yv[i] - mu[i]) * is[i], s[1][i]);
+      }
+      *reinterpret_cast<uint4*>(a.dz + (size_t)p * a.dz_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(dz);
+    }
+  }
+  block_fold<VEC, 2>(s, m, CV, a.C, reinterpret_cast<float*>(dyn), a.partial);
+}
+
+// ---- backward of a pre-activation BN (dense layers): reduce over (da, x), then apply -----------------------------------------
+struct BnBwdArgs {
+  long N;
+  int nseg;
+  SegP x[MDIE_MAX_SEG];
+  SegW g[MDIE_MAX_SEG];          // gradient destination, same channel partition as x (apply only)
+  unsigned accumulate;            // bit s: g[s] += instead of =
+  const char* da; int da_stride;
+  int C;
+  const float *mean, *invstd, *scale, *shift;
+  int relu;                       // mask da by x * scale + shift > 0
+  const float* coef;              // [2][C]: k2, k3 (apply only)
+  float* partial;                 // (reduce only)
+  long chunk;
+};
+
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
+  constexpr int VEC = Traits<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  const int CV = a.C / VEC;
+  const BlkMap m = blk_map(CV);
+  float s[2][VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[0][i] = s[1][i] = 0.f;
+  if (m.active) {
+    const int v = m.cv, c0 = v * VEC;
+    const char* xb = nullptr; int xs = 0;
+#pragma unroll
+    for (int k = 0; k < MDIE_MAX_SEG; ++k)
+      if (k < a.nseg && c0 >= a.x[k].ch_begin && c0 < a.x[k].ch_end) { xb = a.x[k].ptr + (size_t)(c0 - a.x[k].ch_begin) * sizeof(T); xs = a.x[k].stride; }
+    float sc[VEC], sh[VEC], mu[VEC], is[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { sc[i] = a.scale[c0 + i]; sh[i] = a.shift[c0 + i]; mu[i] = a.mean[c0 + i]; is[i] = a.invstd[c0 + i]; }
+    const long b = (long)blockIdx.x * a.chunk, e = min(a.N, b + a.chunk);
+    for (long p = b + m.row; p < e; p += m.rows) {
+      float xv[VEC], d[VEC];
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + (size_t)p * xs * sizeof(T)), xv);
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.da + (size_t)p * a.da_stride * sizeof(T) + (size_t)v * 16), d);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float dd = (!a.relu || fmaf(xv[i], sc[i], sh[i]) > 0.f) ? d[i] : 0.f;
+        s[0][i] += dd;
+        s[1][i] = fmaf(dd, (xv[i] - mu[i]) * is[i], s[1][i]);
+      }
+    }
+  }
+  block_fold<VEC, 2>(s, m, CV, a.C, reinterpret_cast<float*>(dyn), a.partial);
+}
+
+// dgamma / dbeta in the parameter's (real-channel) layout, k2 / k3 per stored channel
+__global__ __launch_bounds__(64) void bn_bwd_final_kernel(int nblk, int C_st, int C_real, int split, int gap, double n, const float* partial, float* dgamma,
+                                                          float* dbeta, float* coef) {
+  const int cs = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) { s1 += partial[((size_t)b * 2 + 0) * C_st + cs]; s2 += partial[((size_t)b * 2 + 1) * C_st + cs]; }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
+  if (threadIdx.x == 0) {
+    coef[cs] = (float)(s1 / n);
+    coef[C_st + cs] = (float)(s2 / n);
+    const int c = real_channel(cs, split, gap, C_real);
+    if (c >= 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnBwdArgs a) {
+  constexpr int VEC = Traits<T>::VEC;
+  const int CV = a.C / VEC;
+  const size_t total = (size_t)a.N * CV;
+  for (size_t u = (size_t)blockIdx.x * BN_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * BN_THREADS) {
+    const int v = (int)(u % CV), c0 = v * VEC;
+    const size_t p = u / CV;
+    const char* xb = nullptr; int xs = 0;
+    char* gb = nullptr; int gs = 0; bool acc = false;
+#pragma unroll
+    for (int k = 0; k < MDIE_MAX_SEG; ++k)
+      if (k < a.nseg && c0 >= a.x[k].ch_begin && c0 < a.x[k].ch_end) {
+        xb = a.x[k].ptr + (size_t)(c0 - a.x[k].ch_begin) * sizeof(T); xs = a.x[k].stride;
+        gb = a.g[k].ptr + (size_t)(c0 - a.g[k].ch_begin) * sizeof(T); gs = a.g[k].stride;
+        acc = (a.accumulate >> k) & 1u;
+      }
+    float xv[VEC], d[VEC], r[VEC];
+    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + p * xs * sizeof(T)), xv);
+    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.da + p * a.da_stride * sizeof(T) + (size_t)v * 16), d);
+    uint4* dst = reinterpret_cast<uint4*>(gb + p * gs * sizeof(T));
+    if (acc) Vec16<T>::unpack(*dst, r);
+    else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) r[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float sc = a.scale[c0 + i];
+      const float dd = (!a.relu || fmaf(xv[i], sc, a.shift[c0 + i]) > 0.f) ? d[i] : 0.f;
+      const float xh = (xv[i] - a.mean[c0 + i]) * a.invstd[c0 + i];
+      r[i] += sc * (dd - a.coef[c0 + i] - xh * a.coef[a.C + c0 + i]);
+    }
+    *dst = Vec16<T>::pack(r);
+  }
+}
+
+// ---- final sigmoid: dz[NHWC16] = g[NCHW3] * y * (1 - y) -----------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void sigmoid_bwd_nchw3_kernel(int B, int HW, const float* g, const float* y, T* dz, int dz_stride) {
+  const size_t total = (size_t)B * HW;
+  for (size_t u = (size_t)blockIdx.x * BN_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * BN_THREADS) {
+    const size_t img = u / HW, p = u - img * HW;
+    T* o = dz + u * dz_stride;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const size_t i = (img * 3 + c) * HW + p;
+      const float yy = y[i];
+      st(o + c, g[i] * yy * (1.f - yy));
+    }
+#pragma unroll
+    for (int c = 3; c < 16; ++c) st(o + c, 0.f);
+  }
+}
+
+static int bn_grid(size_t total) {
+  size_t g = (total + BN_THREADS - 1) / BN_THREADS;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+// pixel-chunked reduction plan: block count and pixels per block
+struct RedPlan { int blocks; long chunk; int rows; };
+static RedPlan red_plan(long N, int CV) {
+  RedPlan p;
+  p.rows = BN_THREADS / CV;
+  long want = (N + (long)p.rows * 8 - 1) / ((long)p.rows * 8);    // >= 8 pixels per thread
+  if (want < 1) want = 1;
+  if (want > BN_MAX_BLOCKS) want = BN_MAX_BLOCKS;
+  p.chunk = (N + want - 1) / want;
+  p.blocks = (int)((N + p.chunk - 1) / p.chunk);
+  return p;
+}
+
+static int bn_check(const char* what, int dtype, long N, int C) {
+  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "%s: bad dtype %d", what, dtype);
+  MDIE_REQUIRE(N > 0, "%s: empty tensor", what);
+  const int vec = dtype == MDIE_F32 ? 4 : 8;
+  MDIE_REQUIRE(C > 0 && C % 16 == 0 && C / vec <= BN_THREADS, "%s: C = %d must be a multiple of 16 and <= %d", what, C, BN_THREADS * vec);
+  return MDIE_OK;
+}
+
+}  // namespace mdie
+
+using namespace mdie;
+
+extern "C" size_t mdie_bn_workspace_bytes(int C) {
+  if (C <= 0) return 0;
+  return (size_t)BN_MAX_BLOCKS * 2 * C * sizeof(float);
+}
+
+extern "C" int mdie_bn_stats(int dtype, long N, const void* x, int C, int stride, float* mean, float* var, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  if (int e = bn_check("mdie_bn_stats", dtype, N, C)) return e;
+  MDIE_REQUIRE(x && mean && var && workspace && stride >= C, "mdie_bn_stats: null pointer / stride %d < C %d", stride, C);
+  if (workspace_bytes < mdie_bn_workspace_bytes(C)) { set_error("mdie_bn_stats: workspace %zu < %zu", workspace_bytes, mdie_bn_workspace_bytes(C)); return MDIE_ENOSPC; }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int vec = dtype == MDIE_F32 ? 4 : 8;
+  const RedPlan p = red_plan(N, C / vec);
+  const size_t lds = (size_t)p.rows * 2 * C * sizeof(float);
+  float* partial = reinterpret_cast<float*>(workspace);
+  if (dtype == MDIE_F32) hipLaunchKernelGGL((bn_stats_kernel<float>), dim3(p.blocks), dim3(BN_THREADS), lds, s, N, (const char*)x, C, stride, p.chunk, partial);
+  else hipLaunchKernelGGL((bn_stats_kernel<mdie::bf16>), dim3(p.blocks), dim3(BN_THREADS), lds, s, N, (const char*)x, C, stride, p.chunk, partial);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, s, p.blocks, C, (double)N, partial, mean, var);
+  MDIE_LAUNCH_CHECK("mdie_bn_stats");
+  return MDIE_OK;
+}
+
+extern "C" int mdie_bn_fold(int C_stored, int C_real, int split, int gap, const float* mean, const float* var, const float* gamma, const float* beta,
+                            float eps, float momentum, long count, float* running_mean, float* running_var, float* scale, float* shift, float* invstd,
+                            void* stream) {
+  MDIE_REQUIRE(C_stored > 0 && C_real > 0 && mean && var && gamma && beta && scale && shift && invstd, "mdie_bn_fold: bad argument");
+  MDIE_REQUIRE(gap >= 0 && split >= 0 && C_stored >= C_real + (split < C_real ? gap : 0), "mdie_bn_fold: %d stored channels cannot hold %d real + gap %d",
+               C_stored, C_real, gap);
+  MDIE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mdie_bn_fold: running_mean / running_var must both be given or both be null");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C_stored, BN_THREADS)), dim3(BN_THREADS), 0, reinterpret_cast<hipStream_t>(stream), C_stored, C_real, split, gap,
+                     mean, var, gamma, beta, eps, momentum, (double)count, running_mean, running_var, scale, shift, invstd);
+  MDIE_LAUNCH_CHECK("mdie_bn_fold");
+  return MDIE_OK;
+}
+
+extern "C" int mdie_bn_act_pool_fwd(int dtype, int B, int H, int W, int C, const void* y, int y_stride, const float* scale, const float* shift, int pool,
+                                    void* out, int out_stride, void* out_drop, int drop_stride, float p, unsigned seed, void* stream) {
+  if (int e = bn_check("mdie_bn_act_pool_fwd", dtype, (long)B * H * W, C)) return e;
+  MDIE_REQUIRE(y && scale && shift && (out || out_drop), "mdie_bn_act_pool_fwd: null pointer");
+  MDIE_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), "mdie_bn_act_pool_fwd: pooling needs even H, W (got %dx%d)", H, W);
+  MDIE_REQUIRE(p >= 0.f && p < 1.f, "mdie_bn_act_pool_fwd: dropout p = %f", (double)p);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int vec = dtype == MDIE_F32 ? 4 : 8;
+  const size_t total = (size_t)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C / vec);
+  const dim3 grid(bn_grid(total)), blk(BN_THREADS);
+#define MDIE_BN_FWD(T, P) hipLaunchKernelGGL((bn_act_pool_fwd_kernel<T, P>), grid, blk, 0, s, B, H, W, C, (const char*)y, y_stride, scale, shift, (char*)out, \
+                                             out_stride, (char*)out_drop, drop_stride, p, (uint32_t)seed)
+  if (dtype == MDIE_F32) { if (pool) MDIE_BN_FWD(float, true); else MDIE_BN_FWD(float, false); }
+  else { if (pool) MDIE_BN_FWD(mdie::bf16, true); else MDIE_BN_FWD(mdie::bf16, false); }
+#undef MDIE_BN_FWD
+  MDIE_LAUNCH_CHECK("mdie_bn_act_pool_fwd");
+  return MDIE_OK;
+}
+
+// launches the partial-sum fold shared by every backward producer
+static int bn_bwd_finish(const char* what, int nblk, int C, int C_real, int split, int gap, double n, float* partial, float* dgamma, float* dbeta, float* coef,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, s, nblk, C, C_real, split, gap, n, partial, dgamma, dbeta, coef);
+  MDIE_LAUNCH_CHECK(what);
+  return MDIE_OK;
+}
+
+extern "C" int mdie_bn_act_pool_bwd(const mdie_bn_pool_bwd_desc* d, void* stream) {
+  MDIE_REQUIRE(d != nullptr, "mdie_bn_act_pool_bwd: null descriptor");
+  if (int e = bn_check("mdie_bn_act_pool_bwd", d->dtype, (long)d->B * d->H * d->W, d->C)) return e;
+  MDIE_REQUIRE(d->y && d->scale && d->shift && d->mean && d->invstd && d->dz && d->dgamma && d->dbeta && d->coef && d->workspace && (d->d_out || d->d_drop),
+               "mdie_bn_act_pool_bwd: null pointer");
+  MDIE_REQUIRE(!d->pool || (d->H % 2 == 0 && d->W % 2 == 0), "mdie_bn_act_pool_bwd: pooling needs even H, W");
+  if (d->workspace_bytes < mdie_bn_workspace_bytes(d->C)) { set_error("mdie_bn_act_pool_bwd: workspace too small"); return MDIE_ENOSPC; }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int vec = d->dtype == MDIE_F32 ? 4 : 8;
+  const long NO = (long)d->B * (d->pool ? d->H / 2 : d->H) * (d->pool ? d->W / 2 : d->W);
+  const RedPlan p = red_plan(NO, d->C / vec);
+  BnBwdPoolArgs a{};
+  a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C;
+  a.y = (const char*)d->y; a.y_stride = d->y_stride;
+  a.scale = d->scale; a.shift = d->shift; a.mean = d->mean; a.invstd = d->invstd;
+  a.d_o = (const char*)d->d_out; a.do_stride = d->d_out_stride;
+  a.d_t = (const char*)d->d_drop; a.dt_stride = d->d_drop_stride;
+  a.p = d->p; a.seed = d->seed;
+  a.dz = (char*)d->dz; a.dz_stride = d->dz_stride;
+  a.partial = reinterpret_cast<float*>(d->workspace);
+  a.chunk = p.chunk;
+  const size_t lds = (size_t)p.rows * 2 * d->C * sizeof(float);
+#define MDIE_BN_BWD(T, P) hipLaunchKernelGGL((bn_act_pool_bwd_kernel<T, P>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a)
+  if (d->dtype == MDIE_F32) { if (d->pool) MDIE_BN_BWD(float, true); else MDIE_BN_BWD(float, false); }
+  else { if (d->pool) MDIE_BN_BWD(mdie::bf16, true); else MDIE_BN_BWD(mdie::bf16, false); }
+#undef MDIE_BN_BWD
+  return bn_bwd_finish("mdie_bn_act_pool_bwd", p.blocks, d->C, d->c_real, d->C, 0, (double)d->B * d->H * d->W, a.partial, d->dgamma, d->dbeta, d->coef, s);
+}
+
+extern "C" int mdie_bn_act_up_add_fwd(int dtype, int B, int H, int W, int C, const void* y, int y_stride, const float* scale, const float* shift, int up,
+                                      const void* skip, int skip_stride, void* out, int out_stride, void* stream) {
+  if (int e = bn_check("mdie_bn_act_up_add_fwd", dtype, (long)B * H * W, C)) return e;
+  MDIE_REQUIRE(y && scale && shift && out, "mdie_bn_act_up_add_fwd: null pointer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int vec = dtype == MDIE_F32 ? 4 : 8;
+  const size_t total = (size_t)B * H * W * (up ? 4 : 1) * (C / vec);
+  const dim3 grid(bn_grid(total)), blk(BN_THREADS);
+#define MDIE_BN_UP(T, U) hipLaunchKernelGGL((bn_act_up_add_fwd_kernel<T, U>), grid, blk, 0, s, B, H, W, C, (const char*)y, y_stride, scale, shift, \
+                                            (const char*)skip, skip_stride, (char*)out, out_stride)
+  if (dtype == MDIE_F32) { if (up) MDIE_BN_UP(float, true); else MDIE_BN_UP(float, false); }
+  else { if (up) MDIE_BN_UP(mdie::bf16, true); else MDIE_BN_UP(mdie::bf16, false); }
+#undef MDIE_BN_UP
+  MDIE_LAUNCH_CHECK("mdie_bn_act_up_add_fwd");
+  return MDIE_OK;
+}
+
+extern "C" int mdie_bn_act_up_bwd(const mdie_bn_up_bwd_desc* d, void* stream) {
+  MDIE_REQUIRE(d != nullptr, "mdie_bn_act_up_bwd: null descriptor");
+  if (int e = bn_check("mdie_bn_act_up_bwd", d->dtype, (long)d->B * d->H * d->W, d->C)) return e;
+  MDIE_REQUIRE(d->y && d->scale && d->shift && d->mean && d->invstd && d->dz && d->dgamma && d->dbeta && d->coef && d->workspace && d->dout,
+               "mdie_bn_act_up_bwd: null pointer");
+  if (d->workspace_bytes < mdie_bn_workspace_bytes(d->C)) { set_error("mdie_bn_act_up_bwd: workspace too small"); return MDIE_ENOSPC; }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int vec = d->dtype == MDIE_F32 ? 4 : 8;
+  const long N = (long)d->B * d->H * d->W;
+  const RedPlan p = red_plan(N, d->C / vec);
+  BnBwdUpArgs a{};
+  a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C;
+  a.y = (const char*)d->y; a.y_stride = d->y_stride;
+  a.scale = d->scale; a.shift = d->shift; a.mean = d->mean; a.invstd = d->invstd;
+  a.dout = (const char*)d->dout; a.dout_stride = d->dout_stride;
+  a.dz = (char*)d->dz; a.dz_stride = d->dz_stride;
+  a.partial = reinterpret_cast<float*>(d->workspace);
+  a.chunk = p.chunk;
+  const size_t lds = (size_t)p.rows * 2 * d->C * sizeof(float);
+  if (d->dtype == MDIE_F32) hipLaunchKernelGGL((bn_act_up_bwd_kernel<float>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a);
+  else hipLaunchKernelGGL((bn_act_up_bwd_kernel<mdie::bf16>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a);
+  return bn_bwd_finish("mdie_bn_act_up_bwd", p.blocks, d->C, d->c_real, d->C, 0, (double)N, a.partial, d->dgamma, d->dbeta, d->coef, s);
+}
+
+static int fill_bwd_args(const char* what, const mdie_bn_bwd_desc* d, BnBwdArgs& a, bool need_g) {
+  MDIE_REQUIRE(d != nullptr, "%s: null descriptor", what);
+  MDIE_REQUIRE(d->nseg >= 1 && d->nseg <= MDIE_MAX_SEG, "%s: nseg %d", what, d->nseg);
+  int c = 0;
+  for (int k = 0; k < d->nseg; ++k) {
+    MDIE_REQUIRE(d->x[k].ptr && d->x[k].channels > 0 && d->x[k].channels % 16 == 0 && d->x[k].stride >= d->x[k].channels, "%s: x segment %d", what, k);
+    a.x[k].ptr = (const char*)d->x[k].ptr; a.x[k].ch_begin = c; a.x[k].ch_end = c + d->x[k].channels; a.x[k].stride = d->x[k].stride;
+    if (need_g) {
+      MDIE_REQUIRE(d->g[k].ptr && d->g[k].channels == d->x[k].channels && d->g[k].stride >= d->g[k].channels, "%s: gradient segment %d", what, k);
+      a.g[k].ptr = (char*)d->g[k].ptr; a.g[k].ch_begin = c; a.g[k].ch_end = c + d->g[k].channels; a.g[k].stride = d->g[k].stride;
+    }
+    c += d->x[k].channels;
+  }
+  if (int e = bn_check(what, d->dtype, d->N, c)) return e;
+  MDIE_REQUIRE(d->da && d->da_stride >= c && d->mean && d->invstd && d->scale && d->shift && d->coef, "%s: null pointer / da_stride", what);
+  a.N = d->N; a.nseg = d->nseg; a.C = c;
+  a.da = (const char*)d->da; a.da_stride = d->da_stride;
+  a.mean = d->mean; a.invstd = d->invstd; a.scale = d->scale; a.shift = d->shift;
+  a.relu = d->relu; a.coef = d->coef; a.accumulate = d->accumulate;
+  return MDIE_OK;
+}
+
+extern "C" int mdie_bn_bwd_reduce(const mdie_bn_bwd_desc* d, void* stream) {
+  BnBwdArgs a{};
+  if (int e = fill_bwd_args("mdie_bn_bwd_reduce", d, a, false)) return e;
+  MDIE_REQUIRE(d->dgamma && d->dbeta && d->workspace, "mdie_bn_bwd_reduce: null pointer");
+  if (d->workspace_bytes < mdie_bn_workspace_bytes(a.C)) { set_error("mdie_bn_bwd_reduce: workspace too small"); return MDIE_ENOSPC; }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int vec = d->dtype == MDIE_F32 ? 4 : 8;
+  const RedPlan p = red_plan(a.N, a.C / vec);
+  a.partial = reinterpret_cast<float*>(d->workspace);
+  a.chunk = p.chunk;
+  const size_t lds = (size_t)p.rows * 2 * a.C * sizeof(float);
+  if (d->dtype == MDIE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<mdie::bf16>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a);
+  return bn_bwd_finish("mdie_bn_bwd_reduce", p.blocks, a.C, d->c_real, d->split, d->gap, (double)a.N, a.partial, d->dgamma, d->dbeta, d->coef, s);
+}
+
+extern "C" int mdie_bn_bwd_apply(const mdie_bn_bwd_desc* d, void* stream) {
+  BnBwdArgs a{};
+  if (int e = fill_bwd_args("mdie_bn_bwd_apply", d, a, true)) return e;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int vec = d->dtype == MDIE_F32 ? 4 : 8;
+  const size_t total = (size_t)a.N * (a.C / vec);
+  if (d->dtype == MDIE_F32) hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(bn_grid(total)), dim3(BN_THREADS), 0, s, a);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<mdie::bf16>), dim3(bn_grid(total)), dim3(BN_THREADS), 0, s, a);
+  MDIE_LAUNCH_CHECK("mdie_bn_bwd_apply");
+  return MDIE_OK;
+}
+
+extern "C" int mdie_sigmoid_bwd_nchw3(int dtype, int B, int H, int W, const float* grad_nchw, const float* y_nchw, void* dz_nhwc16, int dz_stride, void* stream) {
+  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_sigmoid_bwd_nchw3: bad dtype %d", dtype);
+  MDIE_REQUIRE(B > 0 && H > 0 && W > 0 && grad_nchw && y_nchw && dz_nhwc16 && dz_stride >= 16, "mdie_sigmoid_bwd_nchw3: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t total = (size_t)B * H * W;
+  if (dtype == MDIE_F32) hipLaunchKernelGGL((sigmoid_bwd_nchw3_kernel<float>), dim3(bn_grid(total)), dim3(BN_THREADS), 0, s, B, H * W, grad_nchw, y_nchw, (float*)dz_nhwc16, dz_stride);
+  else hipLaunchKernelGGL((sigmoid_bwd_nchw3_kernel<mdie::bf16>), dim3(bn_grid(total)), dim3(BN_THREADS), 0, s, B, H * W, grad_nchw, y_nchw, (mdie::bf16*)dz_nhwc16, dz_stride);
+  MDIE_LAUNCH_CHECK("mdie_sigmoid_bwd_nchw3");
+  return MDIE_OK;
+}

@@ -60,6 +60,7 @@ struct WgradArgs {
   const char* dy; int dy_stride;
   float* scratch;          // [splits][taps][cin_st][cout_st]
   int splits, groups_per_split;   // pixel groups of 4
+  const float *pre_scale, *pre_shift;   // optional: the conv input was relu(x * pre_scale + pre_shift)
 };
 
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
@@ -92,6 +93,13 @@ __global__ __launch_bounds__(TR_THREADS) void wgrad_kernel(const WgradArgs a) {
       }
   }
   const T* dyb = reinterpret_cast<const T*>(a.dy) + o0 + lp;
+  float psc[4], psh[4];
+#pragma unroll
+  for (int cs = 0; cs < 4; ++cs) {
+    const int c = c0 + cs * 16 + lp;
+    psc[cs] = (a.pre_scale && c < a.cin_st) ? a.pre_scale[c] : 1.f;
+    psh[cs] = (a.pre_scale && c < a.cin_st) ? a.pre_shift[c] : 0.f;
+  }
 
   f32x4 acc[4][NOS];
 #pragma unroll
@@ -119,7 +127,10 @@ __global__ __launch_bounds__(TR_THREADS) void wgrad_kernel(const WgradArgs a) {
         const size_t q = ((size_t)img * a.H + yy) * a.W + xx;
 #pragma unroll
         for (int cs = 0; cs < 4; ++cs)
-          if (xb[cs]) av[cs] = ldf(xb[cs] + q * xs[cs]);
+          if (xb[cs]) {
+            av[cs] = ldf(xb[cs] + q * xs[cs]);
+            if (a.pre_scale) av[cs] = fmaxf(fmaf(av[cs], psc[cs], psh[cs]), 0.f);
+          }
       }
     }
 #pragma unroll
@@ -210,6 +221,7 @@ struct WgradTileArgs {
   float* scratch;
   int tiles_x, tiles_y, total_tiles, tiles_per_split;
   int o_tiles;
+  const float *pre_scale, *pre_shift;
 };
 
 constexpr int WT = 16;  // tile edge
@@ -230,7 +242,7 @@ __device__ __forceinline__ v4s lds_tr16(const char* p) {
 }
 
 // waves are arranged WC x WO; each owns CSW x OSW 16x16 subtiles of every tap
-template <int NTAP, int CSW, int OSW, int WC, int WO>
+template <int NTAP, int CSW, int OSW, int WC, int WO, bool PRE>
 __global__ __launch_bounds__(TR_THREADS, 2) void wgrad_tile_kernel(const WgradTileArgs a) {
   using G = WgGeom<NTAP>;
   constexpr int KS = NTAP == 9 ? 3 : 1;
@@ -265,6 +277,7 @@ __global__ __launch_bounds__(TR_THREADS, 2) void wgrad_tile_kernel(const WgradTi
       }
   }
   const int xdst0 = (xchunk >> 1) * G::XPLANE + (xchunk & 1) * 16;
+  const bool has_pre = PRE && xbase != nullptr;
   const int ychunk = tid % UPY;
   const bool ylive = o0 + ychunk * 8 < a.cout_st;
   const char* ybase = a.dy + (size_t)(o0 + ychunk * 8) * 2;
@@ -302,6 +315,7 @@ __global__ __launch_bounds__(TR_THREADS, 2) void wgrad_tile_kernel(const WgradTi
       for (int b0 = 0; b0 < X_IT; b0 += X_BATCH) {
         uint4 v[X_BATCH];
         int dsts[X_BATCH];
+        bool oks[X_BATCH];
 #pragma unroll
         for (int j = 0; j < X_BATCH; ++j) {
           const int gy = y0 + py - G::PAD, gx = x0 + px - G::PAD;
@@ -309,13 +323,29 @@ __global__ __launch_bounds__(TR_THREADS, 2) void wgrad_tile_kernel(const WgradTi
           const bool ok = in_patch && xbase != nullptr && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
           v[j] = make_uint4(0, 0, 0, 0);
           if (ok) v[j] = *reinterpret_cast<const uint4*>(xbase + (ibase + (size_t)gy * a.W + gx) * xstride);
+          oks[j] = ok;
           dsts[j] = in_patch ? xdst0 + (py * G::PWD + px) * 32 : -1;
           px += X_PPI % G::PWD; py += X_PPI / G::PWD;
           if (px >= G::PWD) { px -= G::PWD; py += 1; }
         }
+        float psc[8], psh[8];      // re-read per batch (L1-resident) rather than held across the MFMA phase
+        if (has_pre) {
+          const float4 s0 = *reinterpret_cast<const float4*>(a.pre_scale + c0 + xchunk * 8), s1 = *reinterpret_cast<const float4*>(a.pre_scale + c0 + xchunk * 8 + 4);
+          const float4 b0 = *reinterpret_cast<const float4*>(a.pre_shift + c0 + xchunk * 8), b1 = *reinterpret_cast<const float4*>(a.pre_shift + c0 + xchunk * 8 + 4);
+          psc[0] = s0.x; psc[1] = s0.y; psc[2] = s0.z; psc[3] = s0.w; psc[4] = s1.x; psc[5] = s1.y; psc[6] = s1.z; psc[7] = s1.w;
+          psh[0] = b0.x; psh[1] = b0.y; psh[2] = b0.z; psh[3] = b0.w; psh[4] = b1.x; psh[5] = b1.y; psh[6] = b1.z; psh[7] = b1.w;
+        }
 #pragma unroll
-        for (int j = 0; j < X_BATCH; ++j)
+        for (int j = 0; j < X_BATCH; ++j) {
+          if (has_pre && oks[j]) {   // pre-activation BN + ReLU of the dense layers; the zero padding stays zero
+            float f[8];
+            Vec16<bf16>::unpack(v[j], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = fmaxf(fmaf(f[i], psc[i], psh[i]), 0.f);
+            v[j] = Vec16<bf16>::pack(f);
+          }
           if (dsts[j] >= 0) *reinterpret_cast<uint4*>(lds_x + dsts[j]) = v[j];
+        }
       }
     }
     // ---- stage dY tile ----
@@ -404,14 +434,22 @@ static WgTilePlan wgrad_tile_plan(int B, int H, int W, int cin_st, int cout_st) 
   return p;
 }
 
-template <int NTAP, int CSW, int OSW, int WC, int WO>
-static void launch_wgrad_tile(const WgradTileArgs& a, const WgTilePlan& p, hipStream_t s) {
+template <int NTAP, int CSW, int OSW, int WC, int WO, bool PRE>
+static void launch_wgrad_tile_t(const WgradTileArgs& a, const WgTilePlan& p, hipStream_t s) {
   using G = WgGeom<NTAP>;
   const size_t lds = (size_t)CSW * WC * G::XPLANE + (size_t)OSW * WO * G::YPLANE;
-  auto kern = wgrad_tile_kernel<NTAP, CSW, OSW, WC, WO>;
+  auto kern = wgrad_tile_kernel<NTAP, CSW, OSW, WC, WO, PRE>;
   static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
   if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   hipLaunchKernelGGL(kern, dim3(p.c_tiles * p.o_tiles, p.splits), dim3(TR_THREADS), lds, s, a);
+}
+
+// the pre-activation prologue is a separate instantiation: its 16 extra live registers would push the
+// 9-tap 64x64 configuration (never used with a prologue by this network: dense 3x3 layers have 16 outputs) into spills
+template <int NTAP, int CSW, int OSW, int WC, int WO>
+static void launch_wgrad_tile(const WgradTileArgs& a, const WgTilePlan& p, hipStream_t s) {
+  if (a.pre_scale) launch_wgrad_tile_t<NTAP, CSW, OSW, WC, WO, true>(a, p, s);
+  else launch_wgrad_tile_t<NTAP, CSW, OSW, WC, WO, false>(a, p, s);
 }
 
 }  // namespace mdie
@@ -479,6 +517,8 @@ extern "C" int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream) {
   a.cin_st = c; a.cout_st = d->cout_stored;
   MDIE_REQUIRE(c >= d->cin + (d->split < d->cin ? d->gap : 0), "mdie_conv_wgrad: segments hold %d channels < cin %d + gap", c, d->cin);
   a.dy = reinterpret_cast<const char*>(d->dy); a.dy_stride = d->dy_stride;
+  a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift;
+  MDIE_REQUIRE((d->pre_scale == nullptr) == (d->pre_shift == nullptr), "mdie_conv_wgrad: pre_scale / pre_shift must both be given or both be null");
   const int taps = d->ksize * d->ksize;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == MDIE_BF16) {
@@ -490,6 +530,7 @@ extern "C" int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream) {
     for (int i = 0; i < a.nseg; ++i) t.seg[i] = a.seg[i];
     t.cin_st = c; t.cout_st = d->cout_stored; t.dy = a.dy; t.dy_stride = a.dy_stride;
     t.scratch = reinterpret_cast<float*>(d->workspace);
+    t.pre_scale = d->pre_scale; t.pre_shift = d->pre_shift;
     t.tiles_x = p.tiles_x; t.tiles_y = p.tiles_y; t.total_tiles = p.total_tiles; t.tiles_per_split = p.tiles_per_split; t.o_tiles = p.o_tiles;
     if (taps == 9) {
       if (p.cfg == 0) launch_wgrad_tile<9, 2, 2, 2, 2>(t, p, s);

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 9
+ABI_VERSION = 10
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 LOSS_KINDS = {"mse": 0, "l1": 1, "charbonnier": 2, "ssim": 3, "gradient_l1": 4}
@@ -42,6 +42,34 @@ class WgradDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("ksize", C.c_int), ("transposed", C.c_int),
                 ("nseg", C.c_int), ("inp", Seg * MAX_SEG), ("cin", C.c_int), ("cout", C.c_int), ("cout_stored", C.c_int),
                 ("split", C.c_int), ("gap", C.c_int), ("dy", C.c_void_p), ("dy_stride", C.c_int), ("dw", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p)]
+
+
+class BnPoolBwdDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("c_real", C.c_int),
+                ("y", C.c_void_p), ("y_stride", C.c_int),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("pool", C.c_int),
+                ("d_out", C.c_void_p), ("d_out_stride", C.c_int), ("d_drop", C.c_void_p), ("d_drop_stride", C.c_int),
+                ("p", C.c_float), ("seed", C.c_uint), ("dz", C.c_void_p), ("dz_stride", C.c_int),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("coef", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class BnUpBwdDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("c_real", C.c_int),
+                ("y", C.c_void_p), ("y_stride", C.c_int),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("dout", C.c_void_p), ("dout_stride", C.c_int), ("dz", C.c_void_p), ("dz_stride", C.c_int),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("coef", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class BnBwdDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("N", C.c_long), ("nseg", C.c_int), ("x", Seg * MAX_SEG), ("g", Seg * MAX_SEG), ("accumulate", C.c_uint),
+                ("da", C.c_void_p), ("da_stride", C.c_int),
+                ("mean", C.c_void_p), ("invstd", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", C.c_int),
+                ("c_real", C.c_int), ("split", C.c_int), ("gap", C.c_int),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("coef", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
@@ -137,6 +165,19 @@ SIGNATURES = {
     "mdie_metrics_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mdie_psnr_ssim": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                  C.c_void_p]),
+    "mdie_bn_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "mdie_bn_stats": (C.c_int, [C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mdie_bn_fold": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_long,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdie_bn_act_pool_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_uint, C.c_void_p]),
+    "mdie_bn_act_pool_bwd": (C.c_int, [C.POINTER(BnPoolBwdDesc), C.c_void_p]),
+    "mdie_bn_act_up_add_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mdie_bn_act_up_bwd": (C.c_int, [C.POINTER(BnUpBwdDesc), C.c_void_p]),
+    "mdie_bn_bwd_reduce": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p]),
+    "mdie_bn_bwd_apply": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p]),
+    "mdie_sigmoid_bwd_nchw3": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mdie_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mdie_loss_fwd_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(LossTerm), C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -1,16 +1,24 @@
-"""Training-mode CDAN (SURVEY.md 8a rows a5, a13, a14; `Model.train_step`, models/model.py:138-227).
+"""Training-mode CDAN (SURVEY.md 8a rows a3, a5, a11, a13, a14; `Model.train_step`, models/model.py:138-227).
 
-First step of the training path: every convolution -- forward, input
-gradient and weight gradient, ~97 % of a step's FLOPs -- runs in libmdie_hip.so through one autograd
-Function; the bandwidth-bound glue between them (batch-statistic BatchNorm, ReLU, max-pool, dropout,
-CBAM gates, bilinear upsampling, the loss) is composed from PyTorch-ROCm device ops and differentiated
-by autograd.  Nothing here touches the CPU or the oracle.  Tensors are `channels_last`, which IS the
-engine's NHWC layout, so the two worlds share buffers without copies.
+Every tensor-sized operation of the network trunk runs in libmdie_hip.so; torch.autograd is only the tape
+that orders three block-level Functions:
 
-Reference semantics kept: BatchNorm uses batch statistics and updates running statistics with momentum
-0.1 (0.01 in CBAM's spatial gate, models/cbam.py:11), eps 1e-5; dropout p=0.2 after each encoder stage
-with the dense blocks fed from the PRE-dropout tensor (models/cdan.py:76-79); ConvTranspose2d weights
-stay in their [Cin, Cout, kh, kw] checkpoint layout.
+  _ConvBnFn   encoder ConvBlock: conv3x3 -> batch-stat BN -> ReLU -> maxpool -> dropout   (models/cdan.py:15-19,74-79)
+  _DenseFn    DenseBlock: 4 x [BN -> ReLU -> conv3x3] -> BN -> ReLU -> conv1x1 [-> sigmoid] (models/cdan.py:32-53,155-157)
+  _DeconvFn   decoder stage: ConvTranspose3x3 -> BN -> ReLU [-> bilinear x2] + skip       (models/cdan.py:127-154)
+
+each of which calls the HIP convolution (forward / dgrad / wgrad, csrc/conv.hip, csrc/train.hip) and the fused
+BatchNorm kernels of csrc/bn.hip in both directions.  The pre-activation BN + ReLU of the dense layers is never
+materialised: it is the staging prologue of the convolution and of its weight-gradient kernel, and a segment's
+batch statistics are computed once, not once per consuming layer.  The four CBAM gates (a few MB of traffic and
+~1 FLOP/byte) are still composed from PyTorch-ROCm device ops and differentiated by autograd.  Nothing here
+touches the CPU or the oracle.  Tensors are `channels_last`, which IS the engine's NHWC layout.
+
+Reference semantics kept: BatchNorm uses batch statistics and updates running statistics with momentum 0.1
+(0.01 in CBAM's spatial gate, models/cbam.py:11), eps 1e-5; dropout p=0.2 after each encoder stage with the
+dense blocks fed from the PRE-dropout tensor (models/cdan.py:76-79); ConvTranspose2d weights stay in their
+[Cin, Cout, kh, kw] checkpoint layout.  A convolution bias that feeds a batch-statistic BatchNorm has an exactly
+zero gradient (the mean subtraction removes it): those gradients are returned as exact zeros.
 """
 import ctypes as C
 
@@ -28,41 +36,361 @@ def _cl(t):
 
 
 def _nhwc(t):
-    """[B,C,H,W] channels_last tensor -> (data_ptr, C, pixel stride in elements)."""
-    assert t.is_contiguous(memory_format=torch.channels_last) or t.shape[1] == 1
-    return t.data_ptr(), t.shape[1], t.stride(3)
+    """[B,C,H,W] tensor whose memory is NHWC (possibly a channel slice of one) -> (data_ptr, C, pixel stride in elements)."""
+    B, Cc, H, W = t.shape
+    ps = t.stride(3) if W > 1 else (t.stride(2) if H > 1 else (t.stride(0) if B > 1 else Cc))
+    assert (Cc == 1 or t.stride(1) == 1) and (H == 1 or W == 1 or t.stride(2) == W * ps) and (B == 1 or t.stride(0) == H * W * ps), \
+        "engine tensors are NHWC"
+    return t.data_ptr(), Cc, ps
 
 
-def _pack(dtype, w, ks, transposed, cout, cin):
-    n = L.lib.mdie_conv_weight_bytes(dtype, ks, cin, cout)
-    dst = torch.empty(n, dtype=torch.uint8, device=w.device)
-    L.check(L.lib.mdie_pack_conv_weight_dev(dtype, ks, int(transposed), w.data_ptr(), cout, cin, cout, cin, cin, 0, dst.data_ptr(),
-                                            E._stream_ptr(w.device)), "mdie_pack_conv_weight_dev")
+def _sp(dev):
+    return E._stream_ptr(dev)
+
+
+def _f32(t):
+    t = t.detach()
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _empty(dt, B, Cc, H, W, dev):
+    return torch.empty(B, Cc, H, W, dtype=E.TORCH_DTYPE[dt], device=dev, memory_format=torch.channels_last)
+
+
+def _pack(dt, w32, ks, transposed, cout, cin, cout_st=None, cin_st=None):
+    cout_st, cin_st = cout_st or cout, cin_st or cin
+    n = L.lib.mdie_conv_weight_bytes(dt, ks, cin_st, cout_st)
+    dst = torch.empty(n, dtype=torch.uint8, device=w32.device)
+    L.check(L.lib.mdie_pack_conv_weight_dev(dt, ks, int(transposed), w32.data_ptr(), cout, cin, cout_st, cin_st, cin, 0, dst.data_ptr(), _sp(w32.device)),
+            "mdie_pack_conv_weight_dev")
     return dst
 
 
-def _launch_conv(dtype, segs, packed, bias_f32, ks, cout, out):
+_ONES = {}
+
+
+def _ones(n, dev):
+    key = (n, dev)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(n, dtype=torch.float32, device=dev)
+    return _ONES[key]
+
+
+def _zeros_like_param(p):
+    return torch.zeros_like(p, dtype=torch.float32)
+
+
+def _conv_raw(dt, segs, packed, bias_st, ks, cout_st, out, pre=None, act=L.ACT_NONE, out_nchw3=None):
+    """out = act(conv_k(relu(cat(segs) * pre_scale + pre_shift)?) + bias); out: NHWC view with >= cout_st channels."""
     B, _, H, W = segs[0].shape
     d = L.ConvDesc()
-    d.dtype, d.B, d.H, d.W, d.ksize = dtype, B, H, W, ks
+    d.dtype, d.B, d.H, d.W, d.ksize = dt, B, H, W, ks
     d.nseg = len(segs)
     cin = 0
     for i, s in enumerate(segs):
-        p, c, st = _nhwc(s)
-        d.inp[i] = L.Seg(p, c, st)
+        ptr, c, st = _nhwc(s)
+        d.inp[i] = L.Seg(ptr, c, st)
         cin += c
-    d.cin, d.cout = cin, cout
-    d.pre_scale = d.pre_shift = None
-    ones = torch.ones(cout, dtype=torch.float32, device=out.device)
-    d.weight, d.post_scale, d.post_shift = packed.data_ptr(), ones.data_ptr(), bias_f32.data_ptr()
-    d.act, d.pool = L.ACT_NONE, 0
+    d.cin, d.cout = cin, cout_st
+    d.pre_scale, d.pre_shift = (pre[0].data_ptr(), pre[1].data_ptr()) if pre is not None else (None, None)
+    d.weight, d.post_scale, d.post_shift = packed.data_ptr(), _ones(cout_st, out.device).data_ptr(), bias_st.data_ptr()
+    d.act, d.pool = act, 0
     d.residual, d.res_stride = None, 0
     d.out, d.out_stride = out.data_ptr(), out.stride(3)
-    d.out_nchw3 = None
-    L.check(L.lib.mdie_conv_fwd(C.byref(d), E._stream_ptr(out.device)), "mdie_conv_fwd")
-    return ones  # keep alive until the launch is enqueued on this stream (same-stream ordering)
+    d.out_nchw3 = out_nchw3.data_ptr() if out_nchw3 is not None else None
+    L.check(L.lib.mdie_conv_fwd(C.byref(d), _sp(out.device)), "mdie_conv_fwd")
 
 
+def _pad_vec(v, n):
+    v = _f32(v)
+    return v if v.numel() == n else F.pad(v, (0, n - v.numel()))
+
+
+def _wgrad(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre=None):
+    """dW in the parameter's layout from the convolution's input segments and dy (stored cout_st channels)."""
+    B, _, H, W = dy.shape
+    dev = dy.device
+    cin_st = sum(s.shape[1] for s in segs)
+    dw = torch.empty(w_shape, dtype=torch.float32, device=dev)
+    nws = L.lib.mdie_conv_wgrad_workspace_bytes(B, H, W, ks, cin_st, cout_st)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    d = L.WgradDesc()
+    d.dtype, d.B, d.H, d.W, d.ksize, d.transposed = dt, B, H, W, ks, int(transposed)
+    d.nseg = len(segs)
+    for i, s in enumerate(segs):
+        ptr, c, st = _nhwc(s)
+        d.inp[i] = L.Seg(ptr, c, st)
+    d.cin, d.cout, d.cout_stored, d.split, d.gap = cin, cout, cout_st, cin, 0
+    ptr, _, st = _nhwc(dy)
+    d.dy, d.dy_stride = ptr, st
+    d.dw, d.workspace, d.workspace_bytes = dw.data_ptr(), ws.data_ptr(), nws
+    d.pre_scale, d.pre_shift = (pre[0].data_ptr(), pre[1].data_ptr()) if pre is not None else (None, None)
+    L.check(L.lib.mdie_conv_wgrad(C.byref(d), _sp(dev)), "mdie_conv_wgrad")
+    return dw
+
+
+class _Bn:
+    """Batch statistics of one NHWC tensor and the folded constants of one BatchNorm over (a prefix of) them."""
+
+    @staticmethod
+    def stats(dt, t, mean, var):
+        ptr, c, st = _nhwc(t)
+        B, _, H, W = t.shape
+        nws = L.lib.mdie_bn_workspace_bytes(c)
+        ws = torch.empty(nws, dtype=torch.uint8, device=t.device)
+        L.check(L.lib.mdie_bn_stats(dt, B * H * W, ptr, c, st, mean.data_ptr(), var.data_ptr(), ws.data_ptr(), nws, _sp(t.device)), "mdie_bn_stats")
+
+    @staticmethod
+    def fold(c_st, c_real, split, gap, mean, var, bn, momentum, count, dev):
+        """-> consts [3, c_st]: scale, shift, invstd; updates bn.running_* in place"""
+        k = torch.empty(3, c_st, dtype=torch.float32, device=dev)
+        L.check(L.lib.mdie_bn_fold(c_st, c_real, split, gap, mean.data_ptr(), var.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), EPS, momentum,
+                                   count, bn.running_mean.data_ptr(), bn.running_var.data_ptr(), k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr(),
+                                   _sp(dev)), "mdie_bn_fold")
+        return k
+
+
+def _bn_apply_inplace(dt, y, dz, k, mean, coef):
+    """dz <- scale * (dz - k2 - xhat * k3)   (dz already masked: relu = 0)"""
+    B, _, H, W = y.shape
+    d = L.BnBwdDesc()
+    d.dtype, d.N, d.nseg = dt, B * H * W, 1
+    ptr, c, st = _nhwc(y)
+    d.x[0] = L.Seg(ptr, c, st)
+    ptr, c, st = _nhwc(dz)
+    d.g[0] = L.Seg(ptr, c, st)
+    d.accumulate = 0
+    d.da, d.da_stride = ptr, st
+    d.mean, d.invstd, d.scale, d.shift, d.relu = mean.data_ptr(), k[2].data_ptr(), k[0].data_ptr(), k[1].data_ptr(), 0
+    d.coef = coef.data_ptr()
+    L.check(L.lib.mdie_bn_bwd_apply(C.byref(d), _sp(y.device)), "mdie_bn_bwd_apply")
+
+
+class _ConvBnFn(torch.autograd.Function):
+    """(o, t) = (pool?(relu(bn(conv3x3(x) + b))), dropout(o)); o or t is None when not requested."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, bn, dt, pool, p, seed, need_o, need_t):
+        B, cin_st, H, W = x.shape
+        dev = x.device
+        cout, cin = weight.shape[0], weight.shape[1]
+        w32 = _f32(weight)
+        y = _empty(dt, B, cout, H, W, dev)
+        _conv_raw(dt, [x], _pack(dt, w32, 3, False, cout, cin, cout, cin_st), _f32(bias), 3, cout, y)
+        mv = torch.empty(2, cout, dtype=torch.float32, device=dev)
+        _Bn.stats(dt, y, mv[0], mv[1])
+        k = _Bn.fold(cout, cout, cout, 0, mv[0], mv[1], bn, 0.1, B * H * W, dev)
+        Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+        o = _empty(dt, B, cout, Ho, Wo, dev) if need_o else None
+        t = _empty(dt, B, cout, Ho, Wo, dev) if need_t else None
+        L.check(L.lib.mdie_bn_act_pool_fwd(dt, B, H, W, cout, y.data_ptr(), cout, k[0].data_ptr(), k[1].data_ptr(), int(pool),
+                                           o.data_ptr() if need_o else None, cout, t.data_ptr() if need_t else None, cout, p, seed, _sp(dev)),
+                "mdie_bn_act_pool_fwd")
+        ctx.save_for_backward(x, w32, y, k, mv)
+        ctx.set_materialize_grads(False)
+        ctx.meta = (dt, pool, p, seed, cin, cout, need_o, need_t)
+        outs = tuple(v for v in (o, t) if v is not None)
+        return outs if len(outs) > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *grads):
+        dt, pool, p, seed, cin, cout, need_o, need_t = ctx.meta
+        x, w32, y, k, mv = ctx.saved_tensors
+        grads = list(grads)
+        d_o = grads.pop(0) if need_o else None
+        d_t = grads.pop(0) if need_t else None
+        B, cin_st, H, W = x.shape
+        dev = x.device
+        td = E.TORCH_DTYPE[dt]
+        d_o = _cl(d_o.to(td)) if d_o is not None else None
+        d_t = _cl(d_t.to(td)) if d_t is not None else None
+        dz = torch.empty_like(y)
+        dgb = torch.empty(2, cout, dtype=torch.float32, device=dev)
+        coef = torch.empty(2, cout, dtype=torch.float32, device=dev)
+        nws = L.lib.mdie_bn_workspace_bytes(cout)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        d = L.BnPoolBwdDesc()
+        d.dtype, d.B, d.H, d.W, d.C, d.c_real = dt, B, H, W, cout, cout
+        d.y, d.y_stride = y.data_ptr(), cout
+        d.scale, d.shift, d.mean, d.invstd, d.pool = k[0].data_ptr(), k[1].data_ptr(), mv[0].data_ptr(), k[2].data_ptr(), int(pool)
+        d.d_out, d.d_out_stride = (d_o.data_ptr(), cout) if d_o is not None else (None, 0)
+        d.d_drop, d.d_drop_stride = (d_t.data_ptr(), cout) if d_t is not None else (None, 0)
+        d.p, d.seed = p, seed
+        d.dz, d.dz_stride = dz.data_ptr(), cout
+        d.dgamma, d.dbeta, d.coef = dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr()
+        d.workspace, d.workspace_bytes = ws.data_ptr(), nws
+        L.check(L.lib.mdie_bn_act_pool_bwd(C.byref(d), _sp(dev)), "mdie_bn_act_pool_bwd")
+        _bn_apply_inplace(dt, y, dz, k, mv[0], coef)          # dz is now dL/dy
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty(dt, B, cin_st, H, W, dev)
+            _conv_raw(dt, [dz], _pack(dt, w32, 3, True, cin, cout, cin_st, cout), torch.zeros(cin_st, dtype=torch.float32, device=dev), 3, cin_st, dx)
+        dw = _wgrad(dt, [x], dz, w32.shape, 3, False, cin, cout, cout)
+        return dx, dw, torch.zeros(cout, dtype=torch.float32, device=dev), dgb[0], dgb[1], None, None, None, None, None, None, None
+
+
+class _DenseFn(torch.autograd.Function):
+    """DenseBlock.forward (models/cdan.py:32-39) [+ torch.sigmoid, :157].  x: NHWC with `c0` stored channels of which
+    `real_c` are real (3 of 16 for final_dense).  params: 4 x (bn.weight, bn.bias, conv.weight, conv.bias) + transition."""
+
+    @staticmethod
+    def forward(ctx, x, blk, dt, real_c, sigmoid, *params):
+        B, c0, H, W = x.shape
+        dev, N = x.device, B * H * W
+        gap = c0 - real_c
+        ct = c0 + 64
+        grow = _empty(dt, B, 64, H, W, dev)
+        mv = torch.zeros(2, ct, dtype=torch.float32, device=dev)
+        _Bn.stats(dt, x, mv[0, :c0], mv[1, :c0])
+        ks_, consts, weights = [], [], []
+        for l in range(5):
+            bn_mod = (getattr(blk.layers, str(l)) if l < 4 else blk.transition_layer)._modules["0"]
+            w = _f32(params[4 * l + 2])
+            if gap:   # real input channels inside their stored positions (zero weights on the padding)
+                w = torch.cat((w[:, :real_c], w.new_zeros(w.shape[0], gap, w.shape[2], w.shape[3]), w[:, real_c:]), 1).contiguous()
+            cin_st = c0 + 16 * l
+            k = _Bn.fold(cin_st, real_c + 16 * l, real_c, gap, mv[0], mv[1], bn_mod, 0.1, N, dev)
+            segs = [x] + ([grow[:, :16 * l]] if l else [])
+            if l < 4:
+                out = grow[:, 16 * l:16 * l + 16]
+                _conv_raw(dt, segs, _pack(dt, w, 3, False, 16, cin_st), _f32(params[4 * l + 3]), 3, 16, out, pre=(k[0], k[1]))
+                _Bn.stats(dt, out, mv[0, cin_st:cin_st + 16], mv[1, cin_st:cin_st + 16])
+            else:
+                cout = w.shape[0]
+                cout_st = (cout + 15) // 16 * 16
+                packed = _pack(dt, w, 1, False, cout, cin_st, cout_st, cin_st)
+                out = _empty(dt, B, cout_st, H, W, dev)
+                y = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev) if sigmoid else None
+                _conv_raw(dt, segs, packed, _pad_vec(params[4 * l + 3], cout_st), 1, cout_st, out, pre=(k[0], k[1]),
+                          act=L.ACT_SIGMOID if sigmoid else L.ACT_NONE, out_nchw3=y)
+            consts.append(k)
+            weights.append(w)
+        ctx.save_for_backward(x, grow, mv, *consts, *weights, *([y] if sigmoid else []))
+        ctx.meta = (dt, real_c, sigmoid, c0)
+        return y if sigmoid else out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        dt, real_c, sigmoid, c0 = ctx.meta
+        saved = ctx.saved_tensors
+        x, grow, mv = saved[:3]
+        consts, weights = saved[3:8], saved[8:13]
+        B, _, H, W = x.shape
+        dev, N, td = x.device, B * H * W, E.TORCH_DTYPE[dt]
+        gap = c0 - real_c
+        if sigmoid:
+            y = saved[13]
+            dz = _empty(dt, B, 16, H, W, dev)
+            L.check(L.lib.mdie_sigmoid_bwd_nchw3(dt, B, H, W, _f32(d_out).data_ptr(), y.data_ptr(), dz.data_ptr(), 16, _sp(dev)), "mdie_sigmoid_bwd_nchw3")
+        else:
+            dz = _cl(d_out.to(td))
+        gx, gg = torch.empty_like(x), torch.empty_like(grow)
+        grads = [None] * 20
+        for l in (4, 3, 2, 1, 0):
+            w, k = weights[l], consts[l]
+            cin_st = c0 + 16 * l
+            cin_real = real_c + 16 * l
+            segs = [x] + ([grow[:, :16 * l]] if l else [])
+            gsegs = [gx] + ([gg[:, :16 * l]] if l else [])
+            if l == 4:
+                cout, cout_st, ks, dy = w.shape[0], dz.shape[1], 1, dz
+                mean_dy = torch.empty(2, cout_st, dtype=torch.float32, device=dev)
+                _Bn.stats(dt, dy, mean_dy[0], mean_dy[1])
+                grads[4 * l + 3] = (mean_dy[0, :cout] * N)                     # the only bias here that is not followed by a BatchNorm
+            else:
+                cout, cout_st, ks, dy = 16, 16, 3, gg[:, 16 * l:16 * l + 16]   # complete: every consumer of this segment has run
+                grads[4 * l + 3] = torch.zeros(16, dtype=torch.float32, device=dev)
+            # gradient w.r.t. the activated input a = relu(bn(cat(segs)))
+            da = _empty(dt, B, cin_st, H, W, dev)
+            _conv_raw(dt, [dy], _pack(dt, w, ks, True, cin_st, cout, cin_st, cout_st), torch.zeros(cin_st, dtype=torch.float32, device=dev), ks, cin_st, da)
+            dw = _wgrad(dt, segs, dy, (cout, cin_st, ks, ks), ks, False, cin_st, cout, cout_st, pre=(k[0], k[1]))
+            grads[4 * l + 2] = torch.cat((dw[:, :real_c], dw[:, c0:]), 1) if gap else dw
+            # BatchNorm + ReLU backward into the segments' gradient buffers
+            dgb = torch.empty(2, cin_real, dtype=torch.float32, device=dev)
+            coef = torch.empty(2, cin_st, dtype=torch.float32, device=dev)
+            nws = L.lib.mdie_bn_workspace_bytes(cin_st)
+            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+            d = L.BnBwdDesc()
+            d.dtype, d.N, d.nseg = dt, N, len(segs)
+            for i, (s, g) in enumerate(zip(segs, gsegs)):
+                ptr, c, st = _nhwc(s)
+                d.x[i] = L.Seg(ptr, c, st)
+                ptr, c, st = _nhwc(g)
+                d.g[i] = L.Seg(ptr, c, st)
+            d.accumulate = 0 if l == 4 else 3
+            d.da, d.da_stride = da.data_ptr(), cin_st
+            d.mean, d.invstd, d.scale, d.shift, d.relu = mv[0].data_ptr(), k[2].data_ptr(), k[0].data_ptr(), k[1].data_ptr(), 1
+            d.c_real, d.split, d.gap = cin_real, real_c, gap
+            d.dgamma, d.dbeta, d.coef = dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr()
+            d.workspace, d.workspace_bytes = ws.data_ptr(), nws
+            L.check(L.lib.mdie_bn_bwd_reduce(C.byref(d), _sp(dev)), "mdie_bn_bwd_reduce")
+            L.check(L.lib.mdie_bn_bwd_apply(C.byref(d), _sp(dev)), "mdie_bn_bwd_apply")
+            grads[4 * l], grads[4 * l + 1] = dgb[0], dgb[1]
+        return (gx if ctx.needs_input_grad[0] else None, None, None, None, None, *grads)
+
+
+class _DeconvFn(torch.autograd.Function):
+    """out = up2x?(relu(bn(conv_transpose3x3(x) + b))) + skip  (models/cdan.py:127-130,134-138,142-146,150-154)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, skip, bn, dt, up):
+        B, cin, H, W = x.shape
+        dev = x.device
+        cout = weight.shape[1]
+        cout_st = (cout + 15) // 16 * 16
+        w32 = _f32(weight)
+        y = _empty(dt, B, cout_st, H, W, dev)
+        _conv_raw(dt, [x], _pack(dt, w32, 3, True, cout, cin, cout_st, cin), _pad_vec(bias, cout_st), 3, cout_st, y)
+        mv = torch.empty(2, cout_st, dtype=torch.float32, device=dev)
+        _Bn.stats(dt, y, mv[0], mv[1])
+        k = _Bn.fold(cout_st, cout, cout_st, 0, mv[0], mv[1], bn, 0.1, B * H * W, dev)
+        Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+        out = _empty(dt, B, cout_st, Ho, Wo, dev)
+        sptr, sc, sst = _nhwc(skip)
+        assert sc == cout_st and skip.shape[2] == Ho
+        L.check(L.lib.mdie_bn_act_up_add_fwd(dt, B, H, W, cout_st, y.data_ptr(), cout_st, k[0].data_ptr(), k[1].data_ptr(), int(up), sptr, sst,
+                                             out.data_ptr(), cout_st, _sp(dev)), "mdie_bn_act_up_add_fwd")
+        ctx.save_for_backward(x, w32, y, k, mv)
+        ctx.meta = (dt, up, cin, cout, cout_st)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        dt, up, cin, cout, cout_st = ctx.meta
+        x, w32, y, k, mv = ctx.saved_tensors
+        B, _, H, W = x.shape
+        dev, td = x.device, E.TORCH_DTYPE[dt]
+        d_out = _cl(d_out.to(td))
+        dz = torch.empty_like(y)
+        dgb = torch.empty(2, cout, dtype=torch.float32, device=dev)
+        coef = torch.empty(2, cout_st, dtype=torch.float32, device=dev)
+        nws = L.lib.mdie_bn_workspace_bytes(cout_st)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        if up:
+            d = L.BnUpBwdDesc()
+            d.dout, d.dout_stride = d_out.data_ptr(), cout_st
+        else:
+            d = L.BnPoolBwdDesc()
+            d.pool, d.d_out, d.d_out_stride, d.d_drop, d.d_drop_stride, d.p, d.seed = 0, d_out.data_ptr(), cout_st, None, 0, 0.0, 0
+        d.dtype, d.B, d.H, d.W, d.C, d.c_real = dt, B, H, W, cout_st, cout
+        d.y, d.y_stride = y.data_ptr(), cout_st
+        d.scale, d.shift, d.mean, d.invstd = k[0].data_ptr(), k[1].data_ptr(), mv[0].data_ptr(), k[2].data_ptr()
+        d.dz, d.dz_stride = dz.data_ptr(), cout_st
+        d.dgamma, d.dbeta, d.coef = dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr()
+        d.workspace, d.workspace_bytes = ws.data_ptr(), nws
+        if up:
+            L.check(L.lib.mdie_bn_act_up_bwd(C.byref(d), _sp(dev)), "mdie_bn_act_up_bwd")
+        else:
+            L.check(L.lib.mdie_bn_act_pool_bwd(C.byref(d), _sp(dev)), "mdie_bn_act_pool_bwd")
+        _bn_apply_inplace(dt, y, dz, k, mv[0], coef)
+        dx = _empty(dt, B, cin, H, W, dev)
+        # input gradient of a transposed convolution = plain convolution with the un-flipped kernel, in/out swapped
+        _conv_raw(dt, [dz], _pack(dt, w32, 3, False, cin, cout, cin, cout_st), torch.zeros(cin, dtype=torch.float32, device=dev), 3, cin, dx)
+        dw = _wgrad(dt, [x], dz, w32.shape, 3, True, cin, cout, cout_st)
+        return dx, dw, torch.zeros(cout, dtype=torch.float32, device=dev), dgb[0], dgb[1], (d_out if ctx.needs_input_grad[5] else None), None, None, None
+
+
+# ---- the generic convolution Function (kept for callers that compose their own blocks and for the operator tests) -------
 class _ConvFn(torch.autograd.Function):
     """y = conv_k(cat(segments), weight) + bias on the HIP engine; stored channel counts are multiples of 16.
     weight: [cout, cin, k, k] (transposed=False) or [cin, cout, k, k] (transposed=True, ConvTranspose2d k3 s1 p1)."""
@@ -72,11 +400,10 @@ class _ConvFn(torch.autograd.Function):
         ks = weight.shape[2]
         cout, cin = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
         assert cin == sum(s.shape[1] for s in segs) and cin % 16 == 0 and cout % 16 == 0
-        w32 = weight.detach().float().contiguous()
-        packed = _pack(dtype, w32, ks, transposed, cout, cin)
+        w32 = _f32(weight)
         B, _, H, W = segs[0].shape
-        out = torch.empty(B, cout, H, W, dtype=E.TORCH_DTYPE[dtype], device=weight.device, memory_format=torch.channels_last)
-        _launch_conv(dtype, segs, packed, bias.detach().float().contiguous(), ks, cout, out)
+        out = _empty(dtype, B, cout, H, W, weight.device)
+        _conv_raw(dtype, list(segs), _pack(dtype, w32, ks, transposed, cout, cin), _f32(bias), ks, cout, out)
         ctx.save_for_backward(w32, *segs)
         ctx.meta = (dtype, transposed, ks, cout, cin)
         return out
@@ -85,28 +412,13 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         dtype, transposed, ks, cout, cin = ctx.meta
         w32, *segs = ctx.saved_tensors
-        dy = dy.to(E.TORCH_DTYPE[dtype]).contiguous(memory_format=torch.channels_last)
+        dy = _cl(dy.to(E.TORCH_DTYPE[dtype]))
         B, _, H, W = dy.shape
         dev = dy.device
-        # ---- input gradient: the same convolution with the in/out-swapped, flipped kernel ----------------
-        packed = _pack(dtype, w32, ks, not transposed, cin, cout)
-        dx = torch.empty(B, cin, H, W, dtype=dy.dtype, device=dev, memory_format=torch.channels_last)
-        zero_bias = torch.zeros(cin, dtype=torch.float32, device=dev)
-        _launch_conv(dtype, [dy], packed, zero_bias, ks, cin, dx)
-        # ---- weight gradient -----------------------------------------------------------------------------------
-        dw = torch.empty_like(w32)
-        nws = L.lib.mdie_conv_wgrad_workspace_bytes(B, H, W, ks, cin, cout)
-        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        d = L.WgradDesc()
-        d.dtype, d.B, d.H, d.W, d.ksize, d.transposed = dtype, B, H, W, ks, int(transposed)
-        d.nseg = len(segs)
-        for i, s in enumerate(segs):
-            p, c, st = _nhwc(s)
-            d.inp[i] = L.Seg(p, c, st)
-        d.cin, d.cout, d.cout_stored, d.split, d.gap = cin, cout, cout, cin, 0
-        d.dy, d.dy_stride = dy.data_ptr(), dy.stride(3)
-        d.dw, d.workspace, d.workspace_bytes = dw.data_ptr(), ws.data_ptr(), nws
-        L.check(L.lib.mdie_conv_wgrad(C.byref(d), E._stream_ptr(dev)), "mdie_conv_wgrad")
+        # input gradient: the same convolution with the in/out-swapped, flipped kernel
+        dx = _empty(dtype, B, cin, H, W, dev)
+        _conv_raw(dtype, [dy], _pack(dtype, w32, ks, not transposed, cin, cout), torch.zeros(cin, dtype=torch.float32, device=dev), ks, cin, dx)
+        dw = _wgrad(dtype, list(segs), dy, w32.shape, ks, transposed, cin, cout, cout)
         db = dy.float().sum(dim=(0, 2, 3))
         grads, c0 = [], 0
         for s in segs:
@@ -119,54 +431,32 @@ def conv(dtype, weight, bias, segs, transposed=False):
     return _ConvFn.apply(dtype, transposed, weight, bias, *[_cl(s) for s in segs])
 
 
-def _pad_c(t, c):
-    return t if t.shape[1] == c else _cl(F.pad(t, (0, 0, 0, 0, 0, c - t.shape[1])))
-
-
-def _bn(node, x, momentum, lo=None, hi=None):
-    """Batch-statistic BatchNorm over channels [lo:hi] of `node`'s parameters (per-channel, so a BN over a
-    concatenation is the BN of each segment with the matching parameter slice)."""
-    sl = slice(lo, hi)
-    return F.batch_norm(x, node.running_mean[sl], node.running_var[sl], node.weight[sl], node.bias[sl], True, momentum, EPS)
-
-
 def _tick(net):
     for name, buf in net.named_buffers():
         if name.endswith("num_batches_tracked"):
             buf += 1
 
 
-def _dense_block(net_dtype, blk, x, real_c):
-    """DenseBlock.forward (models/cdan.py:32-39): x has `real_c` real channels (3 for final_dense, stored in a
-    tensor of its own); growth segments are 16 channels each."""
-    layers = blk.layers
-    segs = [x]
+def _dense_params(blk):
+    ps = []
     for i in range(4):
-        bn, cv = getattr(layers, str(i))._modules["0"], getattr(layers, str(i))._modules["2"]
-        acts, c0 = [], 0
-        for j, s in enumerate(segs):
-            w = s.shape[1]
-            a = F.relu(_bn(bn, s, 0.1, c0, c0 + w))
-            acts.append(_pad_c(a, 16) if w < 16 else a)
-            c0 += w
-        weight = cv.weight
-        if real_c < 16:  # place the 3 real base channels inside their 16 stored ones (zero weights for the padding)
-            weight = torch.cat((weight[:, :real_c], weight.new_zeros(weight.shape[0], 16 - real_c, 3, 3), weight[:, real_c:]), 1)
-        segs.append(conv(net_dtype, weight, cv.bias, acts))
-    bn, cv = blk.transition_layer._modules["0"], blk.transition_layer._modules["2"]
-    acts, c0 = [], 0
-    for s in segs:
-        w = s.shape[1]
-        a = F.relu(_bn(bn, s, 0.1, c0, c0 + w))
-        acts.append(_pad_c(a, 16) if w < 16 else a)
-        c0 += w
-    weight, bias = cv.weight, cv.bias
-    if real_c < 16:
-        weight = torch.cat((weight[:, :real_c], weight.new_zeros(weight.shape[0], 16 - real_c, 1, 1), weight[:, real_c:]), 1)
-        weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, 16 - weight.shape[0]))
-        bias = F.pad(bias, (0, 16 - bias.shape[0]))
-    y = conv(net_dtype, weight, bias, acts)
-    return y[:, :real_c] if real_c < 16 else y
+        seq = getattr(blk.layers, str(i))._modules
+        ps += [seq["0"].weight, seq["0"].bias, seq["2"].weight, seq["2"].bias]
+    seq = blk.transition_layer._modules
+    return ps + [seq["0"].weight, seq["0"].bias, seq["2"].weight, seq["2"].bias]
+
+
+def dense_block(dt, blk, x, real_c, sigmoid=False):
+    return _DenseFn.apply(x, blk, dt, real_c, sigmoid, *_dense_params(blk))
+
+
+def conv_block(dt, blk, x, pool, p, need_o=True, need_t=True):
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0       # CPU generator: no device sync
+    return _ConvBnFn.apply(x, blk.conv.weight, blk.conv.bias, blk.bn.weight, blk.bn.bias, blk.bn, dt, pool, float(p), seed, need_o, need_t)
+
+
+def deconv_stage(dt, cv, bn, x, skip, up):
+    return _DeconvFn.apply(x, cv.weight, cv.bias, bn.weight, bn.bias, skip, bn, dt, up)
 
 
 def _cbam(node, x):
@@ -186,55 +476,37 @@ def _cbam(node, x):
     return xg * torch.sigmoid(m).to(xg.dtype)
 
 
-def _up2(t):
-    return F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
-
-
 def forward_train(net, x, precision="fp32", dropout_p=0.2):
     """CDAN.forward (models/cdan.py:171-176) with the module in training mode.  x: fp32 NCHW on the GPU."""
     if not x.is_cuda:
         raise L.MdieError("forward_train: GPU tensors only (no CPU fallback)")
     dt = E.dtype_id(precision)
-    td = E.TORCH_DTYPE[dt]
     enc, dec = net.encoder, net.decoder
     _tick(net)
-
-    def drop(t):
-        return F.dropout(t, dropout_p, True) if dropout_p > 0 else t
-
-    xin = _cl(x.to(td))
-    t = _pad_c(xin, 16)
+    B, ch, H, W = x.shape
+    if ch != 3 or H % 8 or W % 8:
+        raise L.MdieError(f"forward_train: input must be [B,3,H,W] with H, W multiples of 8, got {tuple(x.shape)}")
+    xin = _empty(dt, B, 16, H, W, x.device)
+    L.check(L.lib.mdie_nchw3_to_nhwc16(dt, B, H, W, _f32(x).data_ptr(), xin.data_ptr(), _sp(x.device)), "mdie_nchw3_to_nhwc16")
+    t = xin
     skips, denses = [], []
     for i in (1, 2, 3):
-        blk = getattr(enc, f"conv{i}")
-        w = blk.conv.weight
-        if i == 1:
-            w = F.pad(w, (0, 0, 0, 0, 0, 13))  # 3 real input channels inside 16 stored ones
-        y = F.relu(_bn(blk.bn, conv(dt, w, blk.conv.bias, [t]), 0.1))
-        o = _cl(F.max_pool2d(y, 2, 2))
-        denses.append(_dense_block(dt, getattr(enc, f"dense{i}"), o, o.shape[1]))
-        t = _cl(drop(o))
+        if dropout_p > 0:
+            o, t = conv_block(dt, getattr(enc, f"conv{i}"), t, True, dropout_p)
+        else:
+            o = t = conv_block(dt, getattr(enc, f"conv{i}"), t, True, 0.0, need_t=False)
+        denses.append(dense_block(dt, getattr(enc, f"dense{i}"), o, o.shape[1]))
         skips.append(t)
-    e = _cl(drop(F.relu(_bn(enc.conv4.bn, conv(dt, enc.conv4.conv.weight, enc.conv4.conv.bias, [t]), 0.1))))
+    e = conv_block(dt, enc.conv4, t, False, dropout_p, need_o=False)
     t = _cl(_cbam(net.bottleneck, e))
-
-    def deconv(i, inp):
-        cv, bn = getattr(dec, f"conv{i}"), getattr(dec, f"bn{i}")
-        w, b = cv.weight, cv.bias
-        if w.shape[1] < 16:  # decoder.conv4: 3 real output channels in 16 stored ones
-            w, b = F.pad(w, (0, 0, 0, 0, 0, 16 - w.shape[1])), F.pad(b, (0, 16 - b.shape[0]))
-        y = conv(dt, w, b, [inp], transposed=True)
-        y = y[:, :cv.weight.shape[1]]
-        return F.relu(_bn(bn, y, 0.1))
-
-    t = deconv(1, t) + skips[2]
+    t = deconv_stage(dt, dec.conv1, dec.bn1, t, skips[2], False)
     t = _cl(_cbam(dec.cbam1, t) * denses[2])
-    t = _up2(deconv(2, t)) + skips[1]
-    t = _cl(_cbam(dec.cbam2, _cl(t)) * denses[1])
-    t = _up2(deconv(3, t)) + skips[0]
-    t = _cl(_cbam(dec.cbam3, _cl(t)) * denses[0])
-    t = _cl(_up2(deconv(4, t)) + xin)
-    return torch.sigmoid(_dense_block(dt, dec.final_dense, t, 3)).float().contiguous()
+    t = deconv_stage(dt, dec.conv2, dec.bn2, t, skips[1], True)
+    t = _cl(_cbam(dec.cbam2, t) * denses[1])
+    t = deconv_stage(dt, dec.conv3, dec.bn3, t, skips[0], True)
+    t = _cl(_cbam(dec.cbam3, t) * denses[0])
+    t = deconv_stage(dt, dec.conv4, dec.bn4, t, xin, True)
+    return dense_block(dt, dec.final_dense, t, 3, sigmoid=True)
 
 
 # ---- data-parallel gradient exchange (SURVEY.md 8e) ---------------------------------------------------------------------

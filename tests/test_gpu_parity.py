@@ -625,3 +625,155 @@ def test_fused_loss_values_only_and_errors(E):
         PL.fused_loss(o[:, :, :8, :8], t[:, :, :8, :8], [("ssim", 1.0, 0.0)])   # smaller than one 11x11 window
     with pytest.raises(Exception):
         PL.fused_loss(o, t, [("mse", 1.0, 0.0), ("mse", 1.0, 0.0)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# native training blocks (csrc/bn.hip + conv fwd/dgrad/wgrad) vs the CPU oracle differentiated by autograd, fp32 vs fp64
+# ---------------------------------------------------------------------------------------------------------------------
+def _train_net(seed=42):
+    from models.cdan import CDAN
+    from oracle import params as P
+    net = CDAN(precision="fp32")
+    sd = P.make_state_dict(seed)
+    net.load_state_dict(sd, strict=True)
+    return net.cuda().train(), {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def _leaf(sd, keys):
+    for k in keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+
+
+def _nhwc_cuda(t, pad_to=None):
+    t = t.float()
+    if pad_to and t.shape[1] < pad_to:
+        t = torch.nn.functional.pad(t, (0, 0, 0, 0, 0, pad_to - t.shape[1]))
+    return t.cuda().contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("stage,hw", [(2, (12, 8)), (3, (6, 10)), (4, (5, 7))])
+def test_conv_block_train_matches_oracle(E, L, stage, hw):
+    """conv -> batch-stat BN -> ReLU (-> maxpool): outputs, running statistics and every gradient."""
+    import mdie_amd.train as T
+    from oracle import cdan_oracle as O
+    net, sd = _train_net()
+    blk = getattr(net.encoder, f"conv{stage}")
+    p = f"encoder.conv{stage}"
+    keys = [p + ".conv.weight", p + ".conv.bias", p + ".bn.weight", p + ".bn.bias"]
+    _leaf(sd, keys)
+    pool = stage < 4
+    g = torch.Generator().manual_seed(stage)
+    cin = blk.conv.weight.shape[1]
+    x = torch.randn(2, cin, *hw, generator=g, dtype=torch.float64)
+    rx = x.clone().requires_grad_(True)
+    stats = {}
+    ro = O.conv_block(sd, p, rx, "train", stats)
+    if pool:
+        ro = torch.nn.functional.max_pool2d(ro, 2, 2)
+    gy = torch.randn(ro.shape, generator=g, dtype=torch.float64)
+    ro.backward(gy)
+    gx = _nhwc_cuda(x).requires_grad_(True)
+    o = T.conv_block(L.F32, blk, gx, pool, 0.0, need_t=False)
+    o.backward(_nhwc_cuda(gy))
+    assert rel_to_max(o, ro) <= 2e-5
+    assert rel_to_max(gx.grad, rx.grad) <= 2e-4
+    assert rel_to_max(blk.conv.weight.grad, sd[keys[0]].grad) <= 2e-4
+    assert blk.conv.bias.grad.abs().max().item() == 0.0 and sd[keys[1]].grad.abs().max().item() < 1e-9 * gy.abs().sum().item()
+    assert rel_to_max(blk.bn.weight.grad, sd[keys[2]].grad) <= 2e-4
+    assert rel_to_max(blk.bn.bias.grad, sd[keys[3]].grad) <= 2e-4
+    assert rel_to_max(blk.bn.running_mean, stats[p + ".bn.running_mean"]) <= 2e-5
+    assert rel_to_max(blk.bn.running_var, stats[p + ".bn.running_var"]) <= 2e-5
+
+
+def test_conv_block_dropout_mask_and_gradient(E, L):
+    """dropout: out_t = out_o * mask / (1 - p) with ~p of the elements dropped, the same mask in backward, a new one per call."""
+    import mdie_amd.train as T
+    net, _ = _train_net()
+    blk = net.encoder.conv2
+    torch.manual_seed(5)
+    x = _nhwc_cuda(torch.randn(2, 64, 16, 16)).requires_grad_(True)
+    o, t = T.conv_block(L.F32, blk, x, True, 0.2)
+    live = o > 0
+    ratio = (t[live] / o[live])
+    assert set(torch.unique(ratio.round(decimals=4)).tolist()) == {0.0, 1.25}
+    assert 0.15 < (ratio == 0).float().mean().item() < 0.25
+    o2, t2 = T.conv_block(L.F32, blk, x, True, 0.2)
+    assert torch.equal(o, o2) and not torch.equal(t, t2)
+    # gradient through t only == gradient through o with the mask applied by hand
+    gt = torch.randn_like(t)
+    (gx_t,) = torch.autograd.grad(t, x, gt, retain_graph=True)
+    (gx_o,) = torch.autograd.grad(o, x, gt * (t != 0) * 1.25 + gt * ((t == 0) & ~live) * 0.0)
+    # (positions where o == 0 carry no gradient either way: ReLU)
+    assert rel_to_max(gx_t, gx_o) <= 1e-5
+
+
+@pytest.mark.parametrize("name,real_c,hw,sigmoid", [("encoder.dense1", 64, (10, 12), False), ("encoder.dense3", 256, (4, 6), False),
+                                                    ("decoder.final_dense", 3, (8, 8), True), ("decoder.final_dense", 3, (9, 20), False)])
+def test_dense_block_train_matches_oracle(E, L, name, real_c, hw, sigmoid):
+    import mdie_amd.train as T
+    from oracle import cdan_oracle as O
+    net, sd = _train_net()
+    blk = net.get_submodule(name)
+    keys = [k for k in sd if k.startswith(name + ".") and sd[k].is_floating_point() and "running" not in k]
+    _leaf(sd, keys)
+    g = torch.Generator().manual_seed(real_c)
+    x = torch.randn(2, real_c, *hw, generator=g, dtype=torch.float64)
+    rx = x.clone().requires_grad_(True)
+    stats = {}
+    ry = O.dense_block(sd, name, rx, "train", stats)
+    if sigmoid:
+        ry = torch.sigmoid(ry)
+    gy = torch.randn(ry.shape, generator=g, dtype=torch.float64)
+    ry.backward(gy)
+    gx = _nhwc_cuda(x, 16).requires_grad_(True)
+    y = T.dense_block(L.F32, blk, gx, real_c, sigmoid=sigmoid)
+    y.backward(gy.float().cuda() if sigmoid else _nhwc_cuda(gy, 16))
+    assert rel_to_max(y[:, :ry.shape[1]], ry) <= 5e-5
+    assert rel_to_max(gx.grad[:, :real_c], rx.grad) <= 5e-4
+    if real_c < 16:
+        assert gx.grad[:, real_c:].abs().max().item() == 0.0
+    named = dict(blk.named_parameters())
+    for k in keys:
+        ref = sd[k].grad
+        got = named[k[len(name) + 1:]].grad
+        if k.endswith(".2.bias") and "transition" not in k:
+            # bias of a conv whose output only ever feeds batch-statistic BatchNorms: exactly zero
+            assert got.abs().max().item() == 0.0 and ref.abs().max().item() < 1e-9 * gy.abs().sum().item()
+        else:
+            assert rel_to_max(got, ref) <= 5e-4, k
+    for k, v in stats.items():
+        assert rel_to_max(net.state_dict()[k], v) <= 5e-5, k
+
+
+@pytest.mark.parametrize("i,hw", [(1, (4, 6)), (2, (6, 5)), (3, (8, 8)), (4, (7, 9))])
+def test_decoder_stage_train_matches_oracle(E, L, i, hw):
+    """ConvTranspose -> batch-stat BN -> ReLU (-> bilinear x2) + skip."""
+    import mdie_amd.train as T
+    from oracle import cdan_oracle as O
+    net, sd = _train_net()
+    cv, bn = getattr(net.decoder, f"conv{i}"), getattr(net.decoder, f"bn{i}")
+    keys = [f"decoder.conv{i}.weight", f"decoder.conv{i}.bias", f"decoder.bn{i}.weight", f"decoder.bn{i}.bias"]
+    _leaf(sd, keys)
+    up = i > 1
+    g = torch.Generator().manual_seed(i)
+    cin, cout = cv.weight.shape[0], cv.weight.shape[1]
+    x = torch.randn(2, cin, *hw, generator=g, dtype=torch.float64)
+    skip = torch.randn(2, cout, hw[0] * (2 if up else 1), hw[1] * (2 if up else 1), generator=g, dtype=torch.float64)
+    rx, rs = x.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+    stats = {}
+    r = O._deconv_bn_relu(sd, i, rx, "train", stats)
+    r = (O.up2(r) if up else r) + rs
+    gy = torch.randn(r.shape, generator=g, dtype=torch.float64)
+    r.backward(gy)
+    gx, gs = _nhwc_cuda(x).requires_grad_(True), _nhwc_cuda(skip, 16).requires_grad_(True)
+    out = T.deconv_stage(L.F32, cv, bn, gx, gs, up)
+    out.backward(_nhwc_cuda(gy, 16))
+    assert rel_to_max(out[:, :cout], r) <= 2e-5
+    assert rel_to_max(gx.grad, rx.grad) <= 2e-4
+    assert rel_to_max(gs.grad[:, :cout], rs.grad) <= 1e-6
+    assert rel_to_max(cv.weight.grad, sd[keys[0]].grad) <= 2e-4
+    assert cv.bias.grad.abs().max().item() == 0.0
+    assert rel_to_max(bn.weight.grad, sd[keys[2]].grad) <= 2e-4
+    assert rel_to_max(bn.bias.grad, sd[keys[3]].grad) <= 2e-4
+    for k, v in stats.items():
+        assert rel_to_max(net.state_dict()[k], v) <= 2e-5, k
