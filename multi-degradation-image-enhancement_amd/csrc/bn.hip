@@ -470,27 +470,36 @@ __global__ __launch_bounds__(64) void bn_bwd_final_kernel(int nblk, int C_st, in
   }
 }
 
+// thread = (channel vector, pixel row) with the channel fixed for the whole kernel: the six per-channel constants
+// live in registers and the pixel loop is pure streaming (da, x in; g in/out)
 template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   constexpr int VEC = Traits<T>::VEC;
   const int CV = a.C / VEC;
-  const size_t total = (size_t)a.N * CV;
-  for (size_t u = (size_t)blockIdx.x * BN_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * BN_THREADS) {
-    const int v = (int)(u % CV), c0 = v * VEC;
-    const size_t p = u / CV;
-    const char* xb = nullptr; int xs = 0;
-    char* gb = nullptr; int gs = 0; bool acc = false;
+  const BlkMap m = blk_map(CV);
+  if (!m.active) return;
+  const int v = m.cv, c0 = v * VEC;
+  const char* xb = nullptr; int xs = 0;
+  char* gb = nullptr; int gs = 0; bool acc = false;
 #pragma unroll
-    for (int k = 0; k < MDIE_MAX_SEG; ++k)
-      if (k < a.nseg && c0 >= a.x[k].ch_begin && c0 < a.x[k].ch_end) {
-        xb = a.x[k].ptr + (size_t)(c0 - a.x[k].ch_begin) * sizeof(T); xs = a.x[k].stride;
-        gb = a.g[k].ptr + (size_t)(c0 - a.g[k].ch_begin) * sizeof(T); gs = a.g[k].stride;
-        acc = (a.accumulate >> k) & 1u;
-      }
+  for (int k = 0; k < MDIE_MAX_SEG; ++k)
+    if (k < a.nseg && c0 >= a.x[k].ch_begin && c0 < a.x[k].ch_end) {
+      xb = a.x[k].ptr + (size_t)(c0 - a.x[k].ch_begin) * sizeof(T); xs = a.x[k].stride;
+      gb = a.g[k].ptr + (size_t)(c0 - a.g[k].ch_begin) * sizeof(T); gs = a.g[k].stride;
+      acc = (a.accumulate >> k) & 1u;
+    }
+  float sc[VEC], sh[VEC], mu[VEC], is[VEC], k2[VEC], k3[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    sc[i] = a.scale[c0 + i]; sh[i] = a.shift[c0 + i]; mu[i] = a.mean[c0 + i]; is[i] = a.invstd[c0 + i];
+    k2[i] = a.coef[c0 + i]; k3[i] = a.coef[a.C + c0 + i];
+  }
+  const long b = (long)blockIdx.x * a.chunk, e = min(a.N, b + a.chunk);
+  for (long p = b + m.row; p < e; p += m.rows) {
     float xv[VEC], d[VEC], r[VEC];
-    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + p * xs * sizeof(T)), xv);
-    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.da + p * a.da_stride * sizeof(T) + (size_t)v * 16), d);
-    uint4* dst = reinterpret_cast<uint4*>(gb + p * gs * sizeof(T));
+    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + (size_t)p * xs * sizeof(T)), xv);
+    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.da + (size_t)p * a.da_stride * sizeof(T) + (size_t)v * 16), d);
+    uint4* dst = reinterpret_cast<uint4*>(gb + (size_t)p * gs * sizeof(T));
     if (acc) Vec16<T>::unpack(*dst, r);
     else {
 #pragma unroll
@@ -498,10 +507,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnBwdArg
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      const float sc = a.scale[c0 + i];
-      const float dd = (!a.relu || fmaf(xv[i], sc, a.shift[c0 + i]) > 0.f) ? d[i] : 0.f;
-      const float xh = (xv[i] - a.mean[c0 + i]) * a.invstd[c0 + i];
-      r[i] += sc * (dd - a.coef[c0 + i] - xh * a.coef[a.C + c0 + i]);
+      const float dd = (!a.relu || fmaf(xv[i], sc[i], sh[i]) > 0.f) ? d[i] : 0.f;
+      r[i] += sc[i] * (dd - k2[i] - (xv[i] - mu[i]) * is[i] * k3[i]);
     }
     *dst = Vec16<T>::pack(r);
   }
@@ -730,9 +737,13 @@ extern "C" int mdie_bn_bwd_apply(const mdie_bn_bwd_desc* d, void* stream) {
   if (int e = fill_bwd_args("mdie_bn_bwd_apply", d, a, true)) return e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int vec = d->dtype == MDIE_F32 ? 4 : 8;
-  const size_t total = (size_t)a.N * (a.C / vec);
-  if (d->dtype == MDIE_F32) hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(bn_grid(total)), dim3(BN_THREADS), 0, s, a);
-  else hipLaunchKernelGGL((bn_bwd_apply_kernel<mdie::bf16>), dim3(bn_grid(total)), dim3(BN_THREADS), 0, s, a);
+  const int rows = BN_THREADS / (a.C / vec);
+  long blocks = (a.N + (long)rows * 4 - 1) / ((long)rows * 4);          // >= 4 pixels per thread
+  if (blocks > 4096) blocks = 4096;
+  a.chunk = (a.N + blocks - 1) / blocks;
+  blocks = (a.N + a.chunk - 1) / a.chunk;
+  if (d->dtype == MDIE_F32) hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3((int)blocks), dim3(BN_THREADS), 0, s, a);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<mdie::bf16>), dim3((int)blocks), dim3(BN_THREADS), 0, s, a);
   MDIE_LAUNCH_CHECK("mdie_bn_bwd_apply");
   return MDIE_OK;
 }

@@ -171,25 +171,38 @@ __global__ __launch_bounds__(TR_THREADS) void wgrad_kernel(const WgradArgs a) {
 //   transposed = 1: dw[c][o][ks-1-kh][ks-1-kw]   (nn.ConvTranspose2d run as a flipped convolution)
 __global__ __launch_bounds__(TR_THREADS) void wgrad_reduce_kernel(int splits, int ks, int transposed, int cout, int cin, int cout_st, int cin_st,
                                                                   int split_c, int gap, const float* scratch, float* dw) {
-  // threads walk the slab in ITS order (output channel fastest): the `splits` reads of every element are
-  // coalesced; only the single write per element is scattered into PyTorch's layout
+  // block = 64 consecutive slab elements (output channel fastest: coalesced) x 4 interleaved groups of splits;
+  // every thread keeps 4 independent partial sums in flight, the groups are folded through LDS in a fixed order;
+  // only the single write per element is scattered into PyTorch's layout
+  __shared__ float red[4][64];
   const int ntap = ks * ks;
   const size_t slab = (size_t)ntap * cin_st * cout_st;
-  for (size_t u = (size_t)blockIdx.x * TR_THREADS + threadIdx.x; u < slab; u += (size_t)gridDim.x * TR_THREADS) {
-    size_t r = u;
-    const int o = (int)(r % cout_st); r /= cout_st;
-    const int cs = (int)(r % cin_st);
-    const int stap = (int)(r / cin_st);                  // tap of the convolution that was run
-    int c = -1;                                          // real input channel of stored channel cs
-    if (cs < split_c) c = cs;
-    else if (cs >= split_c + gap) c = cs - gap;
-    if (o >= cout || c < 0 || c >= cin) continue;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += scratch[(size_t)k * slab + u];
-    const int skh = stap / ks, skw = stap - skh * ks;
-    if (transposed) dw[(((size_t)c * cout + o) * ks + (ks - 1 - skh)) * ks + (ks - 1 - skw)] = s;
-    else dw[(((size_t)o * cin + c) * ks + skh) * ks + skw] = s;
+  const int e = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const size_t u = (size_t)blockIdx.x * 64 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (u < slab) {
+    int k = kg;
+    for (; k + 12 < splits; k += 16) {
+      s0 += scratch[(size_t)k * slab + u]; s1 += scratch[(size_t)(k + 4) * slab + u];
+      s2 += scratch[(size_t)(k + 8) * slab + u]; s3 += scratch[(size_t)(k + 12) * slab + u];
+    }
+    for (; k < splits; k += 4) s0 += scratch[(size_t)k * slab + u];
   }
+  red[kg][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (kg != 0 || u >= slab) return;
+  const float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  size_t r = u;
+  const int o = (int)(r % cout_st); r /= cout_st;
+  const int cs = (int)(r % cin_st);
+  const int stap = (int)(r / cin_st);                  // tap of the convolution that was run
+  int c = -1;                                          // real input channel of stored channel cs
+  if (cs < split_c) c = cs;
+  else if (cs >= split_c + gap) c = cs - gap;
+  if (o >= cout || c < 0 || c >= cin) return;
+  const int skh = stap / ks, skw = stap - skh * ks;
+  if (transposed) dw[(((size_t)c * cout + o) * ks + (ks - 1 - skh)) * ks + (ks - 1 - skw)] = s;
+  else dw[(((size_t)o * cin + c) * ks + skh) * ks + skw] = s;
 }
 
 static int tr_grid(size_t total) {
@@ -543,7 +556,7 @@ extern "C" int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream) {
     }
     MDIE_LAUNCH_CHECK("mdie_conv_wgrad");
     const size_t total = (size_t)taps * c * d->cout_stored;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tr_grid(total)), dim3(TR_THREADS), 0, s, p.splits, d->ksize, d->transposed, d->cout, d->cin,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(TR_THREADS), 0, s, p.splits, d->ksize, d->transposed, d->cout, d->cin,
                        d->cout_stored, c, d->split, d->gap, t.scratch, d->dw);
     MDIE_LAUNCH_CHECK("mdie_conv_wgrad");
     return MDIE_OK;
@@ -566,7 +579,7 @@ extern "C" int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream) {
   }
   MDIE_LAUNCH_CHECK("mdie_conv_wgrad");
   const size_t total = (size_t)taps * c * d->cout_stored;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tr_grid(total)), dim3(TR_THREADS), 0, s, a.splits, d->ksize, d->transposed, d->cout, d->cin, d->cout_stored, c,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(TR_THREADS), 0, s, a.splits, d->ksize, d->transposed, d->cout, d->cin, d->cout_stored, c,
                      d->split, d->gap, a.scratch, d->dw);
   MDIE_LAUNCH_CHECK("mdie_conv_wgrad");
   return MDIE_OK;

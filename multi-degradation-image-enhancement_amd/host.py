@@ -318,7 +318,7 @@ class Model:
             sums, n = {}, 0
             for inputs, targets in self.dataloader:
                 x, y = self._to_device(inputs), self._to_device(targets)
-                opt.zero_grad(set_to_none=False)
+                opt.zero_grad(set_to_none=True)
                 out = self.network(x)
                 total, values = losses(out, y)
                 total.backward()

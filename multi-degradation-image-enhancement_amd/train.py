@@ -76,8 +76,15 @@ def _ones(n, dev):
     return _ONES[key]
 
 
-def _zeros_like_param(p):
-    return torch.zeros_like(p, dtype=torch.float32)
+_ZEROS = {}
+
+
+def _zeros(n, dev):
+    """read-only zero vector (bias of the gradient convolutions)"""
+    key = (n, dev)
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(n, dtype=torch.float32, device=dev)
+    return _ZEROS[key]
 
 
 def _conv_raw(dt, segs, packed, bias_st, ks, cout_st, out, pre=None, act=L.ACT_NONE, out_nchw3=None):
@@ -224,7 +231,7 @@ class _ConvBnFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _empty(dt, B, cin_st, H, W, dev)
-            _conv_raw(dt, [dz], _pack(dt, w32, 3, True, cin, cout, cin_st, cout), torch.zeros(cin_st, dtype=torch.float32, device=dev), 3, cin_st, dx)
+            _conv_raw(dt, [dz], _pack(dt, w32, 3, True, cin, cout, cin_st, cout), _zeros(cin_st, dev), 3, cin_st, dx)
         dw = _wgrad(dt, [x], dz, w32.shape, 3, False, cin, cout, cout)
         return dx, dw, torch.zeros(cout, dtype=torch.float32, device=dev), dgb[0], dgb[1], None, None, None, None, None, None, None
 
@@ -240,7 +247,7 @@ class _DenseFn(torch.autograd.Function):
         gap = c0 - real_c
         ct = c0 + 64
         grow = _empty(dt, B, 64, H, W, dev)
-        mv = torch.zeros(2, ct, dtype=torch.float32, device=dev)
+        mv = torch.empty(2, ct, dtype=torch.float32, device=dev)
         _Bn.stats(dt, x, mv[0, :c0], mv[1, :c0])
         ks_, consts, weights = [], [], []
         for l in range(5):
@@ -302,7 +309,7 @@ class _DenseFn(torch.autograd.Function):
                 grads[4 * l + 3] = torch.zeros(16, dtype=torch.float32, device=dev)
             # gradient w.r.t. the activated input a = relu(bn(cat(segs)))
             da = _empty(dt, B, cin_st, H, W, dev)
-            _conv_raw(dt, [dy], _pack(dt, w, ks, True, cin_st, cout, cin_st, cout_st), torch.zeros(cin_st, dtype=torch.float32, device=dev), ks, cin_st, da)
+            _conv_raw(dt, [dy], _pack(dt, w, ks, True, cin_st, cout, cin_st, cout_st), _zeros(cin_st, dev), ks, cin_st, da)
             dw = _wgrad(dt, segs, dy, (cout, cin_st, ks, ks), ks, False, cin_st, cout, cout_st, pre=(k[0], k[1]))
             grads[4 * l + 2] = torch.cat((dw[:, :real_c], dw[:, c0:]), 1) if gap else dw
             # BatchNorm + ReLU backward into the segments' gradient buffers
@@ -385,7 +392,7 @@ class _DeconvFn(torch.autograd.Function):
         _bn_apply_inplace(dt, y, dz, k, mv[0], coef)
         dx = _empty(dt, B, cin, H, W, dev)
         # input gradient of a transposed convolution = plain convolution with the un-flipped kernel, in/out swapped
-        _conv_raw(dt, [dz], _pack(dt, w32, 3, False, cin, cout, cin, cout_st), torch.zeros(cin, dtype=torch.float32, device=dev), 3, cin, dx)
+        _conv_raw(dt, [dz], _pack(dt, w32, 3, False, cin, cout, cin, cout_st), _zeros(cin, dev), 3, cin, dx)
         dw = _wgrad(dt, [x], dz, w32.shape, 3, True, cin, cout, cout_st)
         return dx, dw, torch.zeros(cout, dtype=torch.float32, device=dev), dgb[0], dgb[1], (d_out if ctx.needs_input_grad[5] else None), None, None, None
 
@@ -417,7 +424,7 @@ class _ConvFn(torch.autograd.Function):
         dev = dy.device
         # input gradient: the same convolution with the in/out-swapped, flipped kernel
         dx = _empty(dtype, B, cin, H, W, dev)
-        _conv_raw(dtype, [dy], _pack(dtype, w32, ks, not transposed, cin, cout), torch.zeros(cin, dtype=torch.float32, device=dev), ks, cin, dx)
+        _conv_raw(dtype, [dy], _pack(dtype, w32, ks, not transposed, cin, cout), _zeros(cin, dev), ks, cin, dx)
         dw = _wgrad(dtype, list(segs), dy, w32.shape, ks, transposed, cin, cout, cout)
         db = dy.float().sum(dim=(0, 2, 3))
         grads, c0 = [], 0

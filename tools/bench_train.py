@@ -29,7 +29,7 @@ opt = torch.optim.Adam(net.parameters(), lr=1e-3)
 buckets = T.GradBuckets(net.parameters()) if dist is not None else None
 
 def step():
-    opt.zero_grad(set_to_none=False)
+    opt.zero_grad(set_to_none=True)
     out = net(x)
     total, _ = losses(out, t)
     total.backward()
