@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 10
+#define MDIE_ABI_VERSION 11
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -407,6 +407,32 @@ int mdie_bn_bwd_apply(const mdie_bn_bwd_desc* d, void* stream);
 /* dz[NHWC16] = grad[NCHW3] * y * (1 - y), padding channels zero (torch.sigmoid, models/cdan.py:157) */
 int mdie_sigmoid_bwd_nchw3(int dtype, int B, int H, int W, const float* grad_nchw, const float* y_nchw, void* dz_nhwc16,
                            int dz_stride, void* stream);
+
+/* CBAM in training mode (models/cbam.py:37-60,68-82,91-95): out = x * g * s (* mul), the spatial gate's
+ * BatchNorm2d(1) on batch statistics (momentum / eps given, running statistics updated when non-NULL), and the full
+ * backward.  The forward fills the saved-state buffers the backward reads (caller-owned, all fp32 / int32):
+ *   gate [B][C], amax_idx [B][C], pooled [B][2][C], comp [B][H][W][2], smap [B][H][W], bnc [4].
+ * arg-max ties go to the first index in scan order (F.max_pool2d / torch.max).  C: power of two in [16, 512]. */
+typedef struct {
+  int dtype, B, H, W, C;
+  const void* x; int x_stride;
+  const void* mul; int mul_stride;          /* optional multiplicand (`out *= dense_k`, models/cdan.py:133,141,149) */
+  void* out; int out_stride;                /* forward only */
+  const float *w1, *b1, *w2, *b2;           /* ChannelGate.mlp: [C/16][C], [C/16], [C][C/16], [C] */
+  const float* w7;                          /* SpatialGate conv [1][2][7][7] */
+  const float *gamma, *beta;                /* SpatialGate BatchNorm2d(1) */
+  float *running_mean, *running_var;        /* forward: updated in place; may be NULL */
+  float momentum, eps;
+  float* gate; int* amax_idx; float* pooled; float* comp; float* smap; float* bnc;   /* saved state */
+  const void* dout; int dout_stride;        /* backward: gradient of out */
+  void* dx; int dx_stride;                  /* backward outputs */
+  void* dmul; int dmul_stride;              /* NULL when mul is NULL */
+  float *dw1, *db1, *dw2, *db2, *dw7, *dgamma, *dbeta;
+  void* workspace; size_t workspace_bytes;  /* >= mdie_cbam_train_workspace_bytes */
+} mdie_cbam_train_desc;
+size_t mdie_cbam_train_workspace_bytes(int B, int H, int W, int C);
+int mdie_cbam_train_fwd(const mdie_cbam_train_desc* d, void* stream);
+int mdie_cbam_train_bwd(const mdie_cbam_train_desc* d, void* stream);
 
 /* Training loss, value and gradient in one call (utils/loss_factory.py:146-230; models/model.py:161-164 evaluates the
  * pipeline and calls backward on it every step).  Terms that need downloaded networks (vgg_perceptual, lpips) are

@@ -1,0 +1,656 @@
+// CBAM in training mode (models/cbam.py:37-60, 68-82, 91-95): forward with the
+// batch-statistic BatchNorm2d(1, momentum 0.01) of the spatial gate, and the complete backward.
+//
+//   out = x * g[b,c] * s[b,h,w] (* mul)     g = sigmoid(MLP(avg_hw x) + MLP(max_hw x))
+//                                           s = sigmoid(BN(conv7x7([max_c xg, mean_c xg]))),  xg = x * g
+// Forward passes over the tensor: pool (+ arg-max), chanpool (cbam.hip, gate in its prologue), apply (cbam.hip's
+// spatial kernel reading the precomputed map); in between, three kernels on the [B,H,W] maps (7x7 convolution, its
+// batch statistics, fold).  Backward passes over the tensor:
+//   bwd1  dmul = dout * xg * s;  ds = sum_c dout * xg * mul  ->  dn = ds * s (1 - s)  (+ partial sums for the BN)
+//   bwd3  dxg = dout * s * mul + dcomp_mean / C + [c == argmax_c xg] dcomp_max;  dx = dxg * g;  dg = sum_hw dxg * x
+//   bwd4  dx += davg / HW + [p == argmax_hw x] dmax          (the two pooled vectors' gradients, from the MLP backward)
+// and on the maps: BN backward constants, transposed 7x7 convolution (+ its weight gradient), the MLP backward.
+// arg-max ties resolve to the first index in scan order (F.max_pool2d / torch.max semantics).  All reductions are
+// ordered two-level sums: bit-reproducible.
+#include "common.hpp"
+
+namespace mdie {
+
+constexpr int CT_THREADS = 256;
+constexpr int CT_MAX_SLABS = 16;
+constexpr int CT_MIN_SLAB = 128;
+constexpr int CT_TS = 16, CT_PW = CT_TS + 6;
+
+struct CbtArgs {
+  int B, H, W, C;
+  const char* x; int x_stride;
+  const char* mul; int mul_stride;
+  const char* dout; int dout_stride;
+  char* dx; int dx_stride;
+  char* dmul; int dmul_stride;
+  const float *w1, *b1, *w2, *b2, *w7;
+  const float *gamma, *beta;
+  float *rmean, *rvar;
+  float momentum, eps;
+  // saved by the forward
+  float* gate;      // [B][C]
+  int* amax_idx;    // [B][C] pixel index of the spatial maximum
+  float* pooled;    // [B][2][C] avg, max
+  float* comp;      // [B][H][W][2] max_c, mean_c of x*g
+  float* smap;      // [B][H][W] conv7 output (before BN)
+  float* bnc;       // [4] scale, shift, mean, invstd
+  // backward
+  float* dn;        // [B][H][W]
+  float* dcomp;     // [B][H][W][2]
+  float* dbn;       // [2] k2, k3
+  float *dw1, *db1, *dw2, *db2, *dw7, *dgamma, *dbeta;
+  float *davg, *dmaxv;  // [B][C]
+  // partials
+  float* psum; float* pmax; int* pidx;   // [B][nslab][C]
+  float* part2;     // [blocks][2]
+  float* part98;    // [tiles*B][98]
+  float* partC;     // [B][gx][C]
+  int nslab, slab, gx;
+};
+
+// ---- forward: pool with arg-max ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(CT_THREADS) void cbt_pool_kernel(const CbtArgs a) {
+  constexpr int VEC = Traits<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  const int CV = a.C / VEC, rows = CT_THREADS / CV;
+  float* rsum = reinterpret_cast<float*>(dyn);
+  float* rmax = rsum + rows * a.C;
+  int* ridx = reinterpret_cast<int*>(rmax + rows * a.C);
+  const int tid = threadIdx.x, slab = blockIdx.x, img = blockIdx.y, npix = a.H * a.W;
+  const int p_begin = slab * a.slab, p_end = min(npix, p_begin + a.slab);
+  const int v = tid % CV, r = tid / CV;
+  float s[VEC], m[VEC];
+  int ix[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s[i] = 0.f; m[i] = -INFINITY; ix[i] = 0x7fffffff; }
+  if (r < rows)
+    for (int p = p_begin + r; p < p_end; p += rows) {
+      float f[VEC];
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.x + ((size_t)img * npix + p) * a.x_stride * sizeof(T) + (size_t)v * 16), f);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { s[i] += f[i]; if (f[i] > m[i]) { m[i] = f[i]; ix[i] = p; } }
+    }
+  if (r < rows) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { rsum[r * a.C + v * VEC + i] = s[i]; rmax[r * a.C + v * VEC + i] = m[i]; ridx[r * a.C + v * VEC + i] = ix[i]; }
+  }
+  __syncthreads();
+  const size_t o = ((size_t)img * a.nslab + slab) * a.C;
+  for (int c = tid; c < a.C; c += CT_THREADS) {
+    float ss = 0.f, mm = -INFINITY;
+    int ii = 0x7fffffff;
+    for (int k = 0; k < rows; ++k) {
+      ss += rsum[k * a.C + c];
+      const float mv = rmax[k * a.C + c];
+      const int iv = ridx[k * a.C + c];
+      if (mv > mm || (mv == mm && iv < ii)) { mm = mv; ii = iv; }
+    }
+    a.psum[o + c] = ss; a.pmax[o + c] = mm; a.pidx[o + c] = ii;
+  }
+}
+
+// one block per image: pooled vectors, arg-max, and the channel gate (MLP)
+__global__ __launch_bounds__(CT_THREADS) void cbt_gate_kernel(const CbtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  const int Hd = a.C / 16, img = blockIdx.x, tid = threadIdx.x;
+  float* avg = reinterpret_cast<float*>(dyn);
+  float* mx = avg + a.C;
+  float* hid = mx + a.C;      // [Hd]
+  const float inv = 1.0f / (float)(a.H * a.W);
+  for (int c = tid; c < a.C; c += CT_THREADS) {
+    float s = 0.f, m = -INFINITY;
+    int ii = 0x7fffffff;
+    for (int k = 0; k < a.nslab; ++k) {
+      const size_t o = ((size_t)img * a.nslab + k) * a.C + c;
+      s += a.psum[o];
+      if (a.pmax[o] > m || (a.pmax[o] == m && a.pidx[o] < ii)) { m = a.pmax[o]; ii = a.pidx[o]; }
+    }
+    avg[c] = s * inv; mx[c] = m;
+    a.pooled[((size_t)img * 2 + 0) * a.C + c] = s * inv;
+    a.pooled[((size_t)img * 2 + 1) * a.C + c] = m;
+    a.amax_idx[(size_t)img * a.C + c] = ii;
+  }
+  __syncthreads();
+  for (int j = tid; j < Hd; j += CT_THREADS) {
+    float sa = a.b1[j], sm = a.b1[j];
+    const float* w = a.w1 + (size_t)j * a.C;
+    for (int c = 0; c < a.C; ++c) { sa = fmaf(w[c], avg[c], sa); sm = fmaf(w[c], mx[c], sm); }
+    hid[j] = fmaxf(sa, 0.f) + fmaxf(sm, 0.f);
+  }
+  __syncthreads();
+  for (int c = tid; c < a.C; c += CT_THREADS) {
+    float s = 2.0f * a.b2[c];
+    const float* w = a.w2 + (size_t)c * Hd;
+    for (int j = 0; j < Hd; ++j) s = fmaf(w[j], hid[j], s);
+    a.gate[(size_t)img * a.C + c] = sigmoidf(s);
+  }
+}
+
+// per-pixel max / mean over channels of x * gate (gate from global memory): LPP lanes share a pixel
+template <typename T, int NV>
+__global__ __launch_bounds__(CT_THREADS) void cbt_chanpool_kernel(const CbtArgs a, const int LPP) {
+  constexpr int VEC = Traits<T>::VEC;
+  const int tid = threadIdx.x, img = blockIdx.y, npix = a.H * a.W;
+  const int sub = tid % LPP, groups = CT_THREADS / LPP;
+  float g[NV][VEC];
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[k][i] = a.gate[(size_t)img * a.C + (k * LPP + sub) * VEC + i];
+  const float invC = 1.0f / (float)a.C;
+  for (int p = blockIdx.x * groups + tid / LPP; p < npix; p += gridDim.x * groups) {
+    const char* px = a.x + ((size_t)img * npix + p) * a.x_stride * sizeof(T);
+    float m = -INFINITY, s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      float f[VEC];
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(px + (size_t)(k * LPP + sub) * 16), f);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { const float y = f[i] * g[k][i]; m = fmaxf(m, y); s += y; }
+    }
+    for (int d = LPP >> 1; d > 0; d >>= 1) { m = fmaxf(m, __shfl_xor(m, d)); s += __shfl_xor(s, d); }
+    if (sub == 0) *reinterpret_cast<float2*>(a.comp + ((size_t)img * npix + p) * 2) = make_float2(m, s * invC);
+  }
+}
+
+__device__ __forceinline__ float ct_block_sum(float v, float* red) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < CT_THREADS / 64; ++i) s += red[i];
+  return s;
+}
+
+// 7x7 convolution (2 -> 1, pad 3, no bias) of the compressed map, 16x16 tiles; + per-block sum / sum of squares
+__global__ __launch_bounds__(CT_THREADS) void cbt_conv7_kernel(const CbtArgs a) {
+  __shared__ float patch[2][CT_PW][CT_PW + 1];
+  __shared__ float w7[98];
+  __shared__ float red[CT_THREADS / 64];
+  const int tid = threadIdx.x;
+  const int tiles_x = cdiv(a.W, CT_TS);
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, img = blockIdx.y;
+  const int y0 = ty * CT_TS, x0 = tx * CT_TS;
+  for (int i = tid; i < CT_PW * CT_PW; i += CT_THREADS) {
+    const int py = i / CT_PW, px = i - py * CT_PW;
+    const int gy = y0 + py - 3, gx = x0 + px - 3;
+    float2 v = make_float2(0.f, 0.f);
+    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const float2*>(a.comp + (((size_t)img * a.H + gy) * a.W + gx) * 2);
+    patch[0][py][px] = v.x; patch[1][py][px] = v.y;
+  }
+  if (tid < 98) w7[tid] = a.w7[tid];
+  __syncthreads();
+  const int py = tid / CT_TS, px = tid % CT_TS;
+  const int gy = y0 + py, gx = x0 + px;
+  float acc = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) acc = fmaf(w7[(ch * 7 + kh) * 7 + kw], patch[ch][py + kh][px + kw], acc);
+  const bool in = gy < a.H && gx < a.W;
+  if (in) a.smap[((size_t)img * a.H + gy) * a.W + gx] = acc;
+  const float v = in ? acc : 0.f;
+  const float s1 = ct_block_sum(v, red), s2 = ct_block_sum(v * v, red);
+  if (tid == 0) { float* o = a.part2 + ((size_t)img * gridDim.x + blockIdx.x) * 2; o[0] = s1; o[1] = s2; }
+}
+
+// batch statistics of the map -> BatchNorm2d(1) constants (+ running statistics)
+__global__ __launch_bounds__(CT_THREADS) void cbt_mstats_kernel(const CbtArgs a, int nparts) {
+  __shared__ double red[2][CT_THREADS];
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += CT_THREADS) { s1 += a.part2[i * 2]; s2 += a.part2[i * 2 + 1]; }
+  red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  s1 = 0.0; s2 = 0.0;
+  for (int i = 0; i < CT_THREADS; ++i) { s1 += red[0][i]; s2 += red[1][i]; }
+  const double n = (double)a.B * a.H * a.W;
+  const double mu = s1 / n, var = fmax(s2 / n - mu * mu, 0.0);
+  const float is = 1.0f / sqrtf((float)var + a.eps);
+  const float sc = a.gamma[0] * is;
+  a.bnc[0] = sc; a.bnc[1] = a.beta[0] - (float)mu * sc; a.bnc[2] = (float)mu; a.bnc[3] = is;
+  if (a.rmean) {
+    a.rmean[0] = (1.f - a.momentum) * a.rmean[0] + a.momentum * (float)mu;
+    a.rvar[0] = (1.f - a.momentum) * a.rvar[0] + a.momentum * (float)(n > 1.0 ? var * n / (n - 1.0) : var);
+  }
+}
+
+// out = x * g * sigmoid(smap * scale + shift) (* mul)
+template <typename T, int NV>
+__global__ __launch_bounds__(CT_THREADS) void cbt_apply_kernel(const CbtArgs a, const int LPP, char* out, int out_stride) {
+  constexpr int VEC = Traits<T>::VEC;
+  const int tid = threadIdx.x, img = blockIdx.y, npix = a.H * a.W;
+  const int sub = tid % LPP, groups = CT_THREADS / LPP;
+  float g[NV][VEC];
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[k][i] = a.gate[(size_t)img * a.C + (k * LPP + sub) * VEC + i];
+  const float sc = a.bnc[0], sh = a.bnc[1];
+  for (int p = blockIdx.x * groups + tid / LPP; p < npix; p += gridDim.x * groups) {
+    const size_t gp = (size_t)img * npix + p;
+    const float s = sigmoidf(fmaf(a.smap[gp], sc, sh));
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const size_t vo = (size_t)(k * LPP + sub) * 16;
+      float f[VEC];
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.x + gp * a.x_stride * sizeof(T) + vo), f);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) f[i] *= g[k][i] * s;
+      if (a.mul) {
+        float m[VEC];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.mul + gp * a.mul_stride * sizeof(T) + vo), m);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) f[i] *= m[i];
+      }
+      *reinterpret_cast<uint4*>(out + gp * out_stride * sizeof(T) + vo) = Vec16<T>::pack(f);
+    }
+  }
+}
+
+// ---- backward 1: dmul, dn (+ partial sums of dn and dn * nhat) ---------------------------------------------------------------
+template <typename T, int NV>
+__global__ __launch_bounds__(CT_THREADS) void cbt_bwd1_kernel(const CbtArgs a, const int LPP) {
+  constexpr int VEC = Traits<T>::VEC;
+  __shared__ float red[CT_THREADS / 64];
+  const int tid = threadIdx.x, img = blockIdx.y, npix = a.H * a.W;
+  const int sub = tid % LPP, groups = CT_THREADS / LPP;
+  float g[NV][VEC];
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[k][i] = a.gate[(size_t)img * a.C + (k * LPP + sub) * VEC + i];
+  const float sc = a.bnc[0], sh = a.bnc[1], mu = a.bnc[2], is = a.bnc[3];
+  float t1 = 0.f, t2 = 0.f;
+  for (int p = blockIdx.x * groups + tid / LPP; p < npix; p += gridDim.x * groups) {
+    const size_t gp = (size_t)img * npix + p;
+    const float mraw = a.smap[gp];
+    const float s = sigmoidf(fmaf(mraw, sc, sh));
+    float ds = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const size_t vo = (size_t)(k * LPP + sub) * 16;
+      float f[VEC], d[VEC], m[VEC], r[VEC];
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.x + gp * a.x_stride * sizeof(T) + vo), f);
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.dout + gp * a.dout_stride * sizeof(T) + vo), d);
+      if (a.mul) Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.mul + gp * a.mul_stride * sizeof(T) + vo), m);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float t = d[i] * f[i] * g[k][i];          // dout * xg
+        r[i] = t * s;                                   // d(mul)
+        ds += a.mul ? t * m[i] : t;
+      }
+      if (a.dmul) *reinterpret_cast<uint4*>(a.dmul + gp * a.dmul_stride * sizeof(T) + vo) = Vec16<T>::pack(r);
+    }
+    for (int d = LPP >> 1; d > 0; d >>= 1) ds += __shfl_xor(ds, d);
+    if (sub == 0) {
+      const float dn = ds * s * (1.f - s);
+      a.dn[gp] = dn;
+      t1 += dn;
+      t2 = fmaf(dn, (mraw - mu) * is, t2);
+    }
+  }
+  t1 = ct_block_sum(t1, red); t2 = ct_block_sum(t2, red);
+  if (tid == 0) { float* o = a.part2 + ((size_t)img * gridDim.x + blockIdx.x) * 2; o[0] = t1; o[1] = t2; }
+}
+
+// BatchNorm2d(1) backward constants: dgamma, dbeta, k2 = dbeta / N, k3 = dgamma / N
+__global__ __launch_bounds__(CT_THREADS) void cbt_bnbwd_kernel(const CbtArgs a, int nparts) {
+  __shared__ double red[2][CT_THREADS];
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += CT_THREADS) { s1 += a.part2[i * 2]; s2 += a.part2[i * 2 + 1]; }
+  red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  s1 = 0.0; s2 = 0.0;
+  for (int i = 0; i < CT_THREADS; ++i) { s1 += red[0][i]; s2 += red[1][i]; }
+  const double n = (double)a.B * a.H * a.W;
+  a.dbeta[0] = (float)s1; a.dgamma[0] = (float)s2;
+  a.dbn[0] = (float)(s1 / n); a.dbn[1] = (float)(s2 / n);
+}
+
+// transposed 7x7 convolution of dm = scale * (dn - k2 - nhat * k3) -> dcomp, and the tile's share of dW7
+__global__ __launch_bounds__(CT_THREADS) void cbt_conv7_bwd_kernel(const CbtArgs a) {
+  __shared__ float pdm[CT_PW][CT_PW + 1];
+  __shared__ float pc[2][CT_PW][CT_PW + 1];
+  __shared__ float w7[98];
+  const int tid = threadIdx.x;
+  const int tiles_x = cdiv(a.W, CT_TS);
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, img = blockIdx.y;
+  const int y0 = ty * CT_TS, x0 = tx * CT_TS;
+  const float sc = a.bnc[0], mu = a.bnc[2], is = a.bnc[3], k2 = a.dbn[0], k3 = a.dbn[1];
+  for (int i = tid; i < CT_PW * CT_PW; i += CT_THREADS) {
+    const int py = i / CT_PW, px = i - py * CT_PW;
+    const int gy = y0 + py - 3, gx = x0 + px - 3;
+    float dm = 0.f;
+    float2 c = make_float2(0.f, 0.f);
+    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+      const size_t gp = ((size_t)img * a.H + gy) * a.W + gx;
+      dm = sc * (a.dn[gp] - k2 - (a.smap[gp] - mu) * is * k3);
+      c = *reinterpret_cast<const float2*>(a.comp + gp * 2);
+    }
+    pdm[py][px] = dm; pc[0][py][px] = c.x; pc[1][py][px] = c.y;
+  }
+  if (tid < 98) w7[tid] = a.w7[tid];
+  __syncthreads();
+  {
+    // dcomp[ch](p) = sum_{kh,kw} w[ch][kh][kw] * dm(p - (kh-3, kw-3)); patch index of p is (py+3, px+3)
+    const int py = tid / CT_TS, px = tid % CT_TS;
+    const int gy = y0 + py, gx = x0 + px;
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) {
+        const float v = pdm[py + 6 - kh][px + 6 - kw];
+        d0 = fmaf(w7[kh * 7 + kw], v, d0);
+        d1 = fmaf(w7[49 + kh * 7 + kw], v, d1);
+      }
+    if (gy < a.H && gx < a.W) *reinterpret_cast<float2*>(a.dcomp + (((size_t)img * a.H + gy) * a.W + gx) * 2) = make_float2(d0, d1);
+  }
+  if (tid < 98) {
+    // dW[ch][kh][kw] = sum over the tile's windows o of dm(o) * comp[ch](o + (kh-3, kw-3))
+    const int ch = tid / 49, kh = (tid % 49) / 7, kw = tid % 7;
+    float s = 0.f;
+    for (int oy = 0; oy < CT_TS; ++oy)
+      for (int ox = 0; ox < CT_TS; ++ox) s = fmaf(pdm[oy + 3][ox + 3], pc[ch][oy + kh][ox + kw], s);
+    a.part98[((size_t)img * gridDim.x + blockIdx.x) * 98 + tid] = s;
+  }
+}
+
+__global__ __launch_bounds__(128) void cbt_w7_final_kernel(const CbtArgs a, int nparts) {
+  const int t = threadIdx.x;
+  if (t >= 98) return;
+  double s = 0.0;
+  for (int i = 0; i < nparts; ++i) s += a.part98[(size_t)i * 98 + t];
+  a.dw7[t] = (float)s;
+}
+
+// ---- backward 3: dx (without the pooled terms) and dg partials -------------------------------------------------------------
+template <typename T, int NV>
+__global__ __launch_bounds__(CT_THREADS) void cbt_bwd3_kernel(const CbtArgs a, const int LPP) {
+  constexpr int VEC = Traits<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  float* lds = reinterpret_cast<float*>(dyn);      // [groups][C]
+  const int tid = threadIdx.x, img = blockIdx.y, npix = a.H * a.W;
+  const int sub = tid % LPP, grp = tid / LPP, groups = CT_THREADS / LPP;
+  float g[NV][VEC], acc[NV][VEC];
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { g[k][i] = a.gate[(size_t)img * a.C + (k * LPP + sub) * VEC + i]; acc[k][i] = 0.f; }
+  const float sc = a.bnc[0], sh = a.bnc[1];
+  const float invC = 1.0f / (float)a.C;
+  for (int p = blockIdx.x * groups + grp; p < npix; p += gridDim.x * groups) {
+    const size_t gp = (size_t)img * npix + p;
+    const float s = sigmoidf(fmaf(a.smap[gp], sc, sh));
+    const float2 dc = *reinterpret_cast<const float2*>(a.dcomp + gp * 2);
+    float f[NV][VEC];
+    // arg-max over channels of x * g (first index on ties)
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.x + gp * a.x_stride * sizeof(T) + (size_t)(k * LPP + sub) * 16), f[k]);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float y = f[k][i] * g[k][i];
+        const int c = (k * LPP + sub) * VEC + i;
+        if (y > best || (y == best && c < arg)) { best = y; arg = c; }
+      }
+    }
+    for (int d = LPP >> 1; d > 0; d >>= 1) {
+      const float ob = __shfl_xor(best, d);
+      const int oa = __shfl_xor(arg, d);
+      if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const size_t vo = (size_t)(k * LPP + sub) * 16;
+      float d[VEC], m[VEC], r[VEC];
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.dout + gp * a.dout_stride * sizeof(T) + vo), d);
+      if (a.mul) Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.mul + gp * a.mul_stride * sizeof(T) + vo), m);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const int c = (k * LPP + sub) * VEC + i;
+        float dxg = d[i] * s * (a.mul ? m[i] : 1.f) + dc.y * invC + (c == arg ? dc.x : 0.f);
+        r[i] = dxg * g[k][i];
+        acc[k][i] = fmaf(dxg, f[k][i], acc[k][i]);
+      }
+      *reinterpret_cast<uint4*>(a.dx + gp * a.dx_stride * sizeof(T) + vo) = Vec16<T>::pack(r);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) lds[grp * a.C + (k * LPP + sub) * VEC + i] = acc[k][i];
+  __syncthreads();
+  for (int c = tid; c < a.C; c += CT_THREADS) {
+    float s = 0.f;
+    for (int q = 0; q < groups; ++q) s += lds[q * a.C + c];
+    a.partC[((size_t)img * gridDim.x + blockIdx.x) * a.C + c] = s;
+  }
+}
+
+// MLP backward, one block, images in sequence (deterministic accumulation into the parameter gradients)
+__global__ __launch_bounds__(CT_THREADS) void cbt_gate_bwd_kernel(const CbtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  const int C = a.C, Hd = C / 16, tid = threadIdx.x;
+  float* datt = reinterpret_cast<float*>(dyn);   // [C]
+  float* avg = datt + C;                          // [C]
+  float* mx = avg + C;                            // [C]
+  float* pa = mx + C;                             // [Hd] pre-activation (avg branch)
+  float* pm = pa + Hd;                            // [Hd]
+  float* dpa = pm + Hd;                           // [Hd]
+  float* dpm = dpa + Hd;                          // [Hd]
+  for (int img = 0; img < a.B; ++img) {
+    for (int c = tid; c < C; c += CT_THREADS) {
+      float dg = 0.f;
+      for (int k = 0; k < a.gx; ++k) dg += a.partC[((size_t)img * a.gx + k) * C + c];
+      const float g = a.gate[(size_t)img * C + c];
+      datt[c] = dg * g * (1.f - g);
+      avg[c] = a.pooled[((size_t)img * 2 + 0) * C + c];
+      mx[c] = a.pooled[((size_t)img * 2 + 1) * C + c];
+    }
+    __syncthreads();
+    for (int j = tid; j < Hd; j += CT_THREADS) {
+      float sa = a.b1[j], sm = a.b1[j], dh = 0.f;
+      const float* w = a.w1 + (size_t)j * C;
+      for (int c = 0; c < C; ++c) { sa = fmaf(w[c], avg[c], sa); sm = fmaf(w[c], mx[c], sm); dh = fmaf(a.w2[(size_t)c * Hd + j], datt[c], dh); }
+      pa[j] = sa; pm[j] = sm;
+      dpa[j] = sa > 0.f ? dh : 0.f;
+      dpm[j] = sm > 0.f ? dh : 0.f;
+      const float v = dpa[j] + dpm[j];
+      a.db1[j] = img == 0 ? v : a.db1[j] + v;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += CT_THREADS) {
+      const float v = 2.f * datt[c];
+      a.db2[c] = img == 0 ? v : a.db2[c] + v;
+      float da = 0.f, dm = 0.f;
+      for (int j = 0; j < Hd; ++j) { const float w = a.w1[(size_t)j * C + c]; da = fmaf(w, dpa[j], da); dm = fmaf(w, dpm[j], dm); }
+      a.davg[(size_t)img * C + c] = da;
+      a.dmaxv[(size_t)img * C + c] = dm;
+    }
+    for (int u = tid; u < C * Hd; u += CT_THREADS) {
+      // dW2[c][j] += datt[c] * (relu(pa[j]) + relu(pm[j]));  dW1[j][c] += dpa[j] * avg[c] + dpm[j] * mx[c]
+      const int c2 = u / Hd, j2 = u - c2 * Hd;
+      const float v2 = datt[c2] * (fmaxf(pa[j2], 0.f) + fmaxf(pm[j2], 0.f));
+      a.dw2[u] = img == 0 ? v2 : a.dw2[u] + v2;
+      const int j1 = u / C, c1 = u - j1 * C;
+      const float v1 = dpa[j1] * avg[c1] + dpm[j1] * mx[c1];
+      a.dw1[u] = img == 0 ? v1 : a.dw1[u] + v1;
+    }
+    __syncthreads();
+  }
+}
+
+// dx += davg / HW + [p == argmax] dmax
+template <typename T>
+__global__ __launch_bounds__(CT_THREADS) void cbt_bwd4_kernel(const CbtArgs a) {
+  constexpr int VEC = Traits<T>::VEC;
+  const int CV = a.C / VEC, npix = a.H * a.W;
+  const int img = blockIdx.y;
+  const int rows = CT_THREADS / CV;
+  const int v = threadIdx.x % CV, r = threadIdx.x / CV;
+  if (r >= rows) return;
+  float da[VEC], dm[VEC];
+  int ix[VEC];
+  const float inv = 1.0f / (float)npix;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const size_t o = (size_t)img * a.C + v * VEC + i;
+    da[i] = a.davg[o] * inv; dm[i] = a.dmaxv[o]; ix[i] = a.amax_idx[o];
+  }
+  for (int p = blockIdx.x * rows + r; p < npix; p += gridDim.x * rows) {
+    uint4* dst = reinterpret_cast<uint4*>(a.dx + ((size_t)img * npix + p) * a.dx_stride * sizeof(T) + (size_t)v * 16);
+    float f[VEC];
+    Vec16<T>::unpack(*dst, f);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] += da[i] + (p == ix[i] ? dm[i] : 0.f);
+    *dst = Vec16<T>::pack(f);
+  }
+}
+
+static size_t ct256(size_t v) { return (v + 255) & ~(size_t)255; }
+static int ct_nslab(int H, int W) { const int n = cdiv(H * W, CT_MIN_SLAB); return n < CT_MAX_SLABS ? n : CT_MAX_SLABS; }
+static int ct_gx(int H, int W, int groups) {
+  int gx = cdiv(H * W, groups * 4);
+  if (gx > 64) gx = 64;
+  return gx < 1 ? 1 : gx;
+}
+
+struct CtWs { size_t psum, pmax, pidx, part2, part98, partC, dn, dcomp, dbn, davg, dmaxv, total; };
+static CtWs ct_ws(int B, int H, int W, int C) {
+  CtWs w{};
+  const size_t tiles = (size_t)cdiv(W, CT_TS) * cdiv(H, CT_TS);
+  const size_t n2 = (size_t)B * (tiles > 64 ? tiles : 64);
+  size_t o = 0;
+  w.psum = o; o += ct256((size_t)B * CT_MAX_SLABS * C * 4);
+  w.pmax = o; o += ct256((size_t)B * CT_MAX_SLABS * C * 4);
+  w.pidx = o; o += ct256((size_t)B * CT_MAX_SLABS * C * 4);
+  w.part2 = o; o += ct256(n2 * 2 * 4);
+  w.part98 = o; o += ct256((size_t)B * tiles * 98 * 4);
+  w.partC = o; o += ct256((size_t)B * 64 * C * 4);
+  w.dn = o; o += ct256((size_t)B * H * W * 4);
+  w.dcomp = o; o += ct256((size_t)B * H * W * 2 * 4);
+  w.dbn = o; o += 256;
+  w.davg = o; o += ct256((size_t)B * C * 4);
+  w.dmaxv = o; o += ct256((size_t)B * C * 4);
+  w.total = o;
+  return w;
+}
+
+static int ct_fill(const char* what, const mdie_cbam_train_desc* d, CbtArgs& a) {
+  MDIE_REQUIRE(d != nullptr, "%s: null descriptor", what);
+  MDIE_REQUIRE(d->dtype == MDIE_F32 || d->dtype == MDIE_BF16, "%s: bad dtype %d", what, d->dtype);
+  MDIE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "%s: empty extent", what);
+  MDIE_REQUIRE(d->C >= 16 && d->C <= 512 && (d->C & (d->C - 1)) == 0, "%s: C = %d must be a power of two in [16, 512]", what, d->C);
+  MDIE_REQUIRE(d->x && d->w1 && d->b1 && d->w2 && d->b2 && d->w7 && d->gamma && d->beta && d->workspace, "%s: null pointer", what);
+  MDIE_REQUIRE(d->gate && d->amax_idx && d->pooled && d->comp && d->smap && d->bnc, "%s: null saved-state pointer", what);
+  MDIE_REQUIRE(d->x_stride % 16 == 0 && (!d->mul || d->mul_stride % 16 == 0), "%s: strides must be multiples of 16", what);
+  const CtWs w = ct_ws(d->B, d->H, d->W, d->C);
+  if (d->workspace_bytes < w.total) { set_error("%s: workspace %zu < %zu", what, d->workspace_bytes, w.total); return MDIE_ENOSPC; }
+  a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C;
+  a.x = (const char*)d->x; a.x_stride = d->x_stride;
+  a.mul = (const char*)d->mul; a.mul_stride = d->mul_stride;
+  a.w1 = d->w1; a.b1 = d->b1; a.w2 = d->w2; a.b2 = d->b2; a.w7 = d->w7; a.gamma = d->gamma; a.beta = d->beta;
+  a.rmean = d->running_mean; a.rvar = d->running_var; a.momentum = d->momentum; a.eps = d->eps;
+  a.gate = d->gate; a.amax_idx = d->amax_idx; a.pooled = d->pooled; a.comp = d->comp; a.smap = d->smap; a.bnc = d->bnc;
+  char* ws = reinterpret_cast<char*>(d->workspace);
+  a.psum = (float*)(ws + w.psum); a.pmax = (float*)(ws + w.pmax); a.pidx = (int*)(ws + w.pidx);
+  a.part2 = (float*)(ws + w.part2); a.part98 = (float*)(ws + w.part98); a.partC = (float*)(ws + w.partC);
+  a.dn = (float*)(ws + w.dn); a.dcomp = (float*)(ws + w.dcomp); a.dbn = (float*)(ws + w.dbn);
+  a.davg = (float*)(ws + w.davg); a.dmaxv = (float*)(ws + w.dmaxv);
+  a.nslab = ct_nslab(d->H, d->W);
+  a.slab = cdiv(d->H * d->W, a.nslab);
+  return MDIE_OK;
+}
+
+template <typename T>
+static int ct_forward(const mdie_cbam_train_desc* d, CbtArgs& a, hipStream_t s) {
+  constexpr int VEC = Traits<T>::VEC;
+  const int CV = d->C / VEC, rows = CT_THREADS / CV;
+  const int LPP = CV < 64 ? CV : 64, NV = CV / LPP, groups = CT_THREADS / LPP;
+  if (NV > 2) { set_error("mdie_cbam_train_fwd: C = %d too wide", d->C); return MDIE_EINVAL; }
+  const int gx = ct_gx(d->H, d->W, groups);
+  const int tiles = cdiv(d->W, CT_TS) * cdiv(d->H, CT_TS);
+  hipLaunchKernelGGL((cbt_pool_kernel<T>), dim3(a.nslab, d->B), dim3(CT_THREADS), (size_t)3 * rows * d->C * 4, s, a);
+  hipLaunchKernelGGL(cbt_gate_kernel, dim3(d->B), dim3(CT_THREADS), (size_t)(2 * d->C + d->C / 16) * 4, s, a);
+  if (NV == 1) hipLaunchKernelGGL((cbt_chanpool_kernel<T, 1>), dim3(gx, d->B), dim3(CT_THREADS), 0, s, a, LPP);
+  else hipLaunchKernelGGL((cbt_chanpool_kernel<T, 2>), dim3(gx, d->B), dim3(CT_THREADS), 0, s, a, LPP);
+  hipLaunchKernelGGL(cbt_conv7_kernel, dim3(tiles, d->B), dim3(CT_THREADS), 0, s, a);
+  hipLaunchKernelGGL(cbt_mstats_kernel, dim3(1), dim3(CT_THREADS), 0, s, a, tiles * d->B);
+  if (NV == 1) hipLaunchKernelGGL((cbt_apply_kernel<T, 1>), dim3(gx, d->B), dim3(CT_THREADS), 0, s, a, LPP, (char*)d->out, d->out_stride);
+  else hipLaunchKernelGGL((cbt_apply_kernel<T, 2>), dim3(gx, d->B), dim3(CT_THREADS), 0, s, a, LPP, (char*)d->out, d->out_stride);
+  MDIE_LAUNCH_CHECK("mdie_cbam_train_fwd");
+  return MDIE_OK;
+}
+
+template <typename T>
+static int ct_backward(const mdie_cbam_train_desc* d, CbtArgs& a, hipStream_t s) {
+  constexpr int VEC = Traits<T>::VEC;
+  const int CV = d->C / VEC, rows = CT_THREADS / CV;
+  const int LPP = CV < 64 ? CV : 64, NV = CV / LPP, groups = CT_THREADS / LPP;
+  if (NV > 2) { set_error("mdie_cbam_train_bwd: C = %d too wide", d->C); return MDIE_EINVAL; }
+  const int gx = ct_gx(d->H, d->W, groups);
+  a.gx = gx;
+  const int tiles = cdiv(d->W, CT_TS) * cdiv(d->H, CT_TS);
+  if (NV == 1) hipLaunchKernelGGL((cbt_bwd1_kernel<T, 1>), dim3(gx, d->B), dim3(CT_THREADS), 0, s, a, LPP);
+  else hipLaunchKernelGGL((cbt_bwd1_kernel<T, 2>), dim3(gx, d->B), dim3(CT_THREADS), 0, s, a, LPP);
+  hipLaunchKernelGGL(cbt_bnbwd_kernel, dim3(1), dim3(CT_THREADS), 0, s, a, gx * d->B);
+  hipLaunchKernelGGL(cbt_conv7_bwd_kernel, dim3(tiles, d->B), dim3(CT_THREADS), 0, s, a);
+  hipLaunchKernelGGL(cbt_w7_final_kernel, dim3(1), dim3(128), 0, s, a, tiles * d->B);
+  const size_t lds3 = (size_t)groups * d->C * 4;
+  if (NV == 1) hipLaunchKernelGGL((cbt_bwd3_kernel<T, 1>), dim3(gx, d->B), dim3(CT_THREADS), lds3, s, a, LPP);
+  else hipLaunchKernelGGL((cbt_bwd3_kernel<T, 2>), dim3(gx, d->B), dim3(CT_THREADS), lds3, s, a, LPP);
+  hipLaunchKernelGGL(cbt_gate_bwd_kernel, dim3(1), dim3(CT_THREADS), (size_t)(3 * d->C + 4 * (d->C / 16)) * 4, s, a);
+  int g4 = cdiv(d->H * d->W, rows * 4);
+  if (g4 > 256) g4 = 256;
+  hipLaunchKernelGGL((cbt_bwd4_kernel<T>), dim3(g4, d->B), dim3(CT_THREADS), 0, s, a);
+  MDIE_LAUNCH_CHECK("mdie_cbam_train_bwd");
+  return MDIE_OK;
+}
+
+}  // namespace mdie
+
+using namespace mdie;
+
+extern "C" size_t mdie_cbam_train_workspace_bytes(int B, int H, int W, int C) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+  return ct_ws(B, H, W, C).total;
+}
+
+extern "C" int mdie_cbam_train_fwd(const mdie_cbam_train_desc* d, void* stream) {
+  CbtArgs a{};
+  if (int e = ct_fill("mdie_cbam_train_fwd", d, a)) return e;
+  MDIE_REQUIRE(d->out && d->out_stride % 16 == 0, "mdie_cbam_train_fwd: out");
+  MDIE_REQUIRE((d->running_mean == nullptr) == (d->running_var == nullptr), "mdie_cbam_train_fwd: running_mean / running_var");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return d->dtype == MDIE_F32 ? ct_forward<float>(d, a, s) : ct_forward<mdie::bf16>(d, a, s);
+}
+
+extern "C" int mdie_cbam_train_bwd(const mdie_cbam_train_desc* d, void* stream) {
+  CbtArgs a{};
+  if (int e = ct_fill("mdie_cbam_train_bwd", d, a)) return e;
+  MDIE_REQUIRE(d->dout && d->dx && d->dw1 && d->db1 && d->dw2 && d->db2 && d->dw7 && d->dgamma && d->dbeta, "mdie_cbam_train_bwd: null gradient pointer");
+  MDIE_REQUIRE(d->dout_stride % 16 == 0 && d->dx_stride % 16 == 0 && (!d->dmul || d->dmul_stride % 16 == 0), "mdie_cbam_train_bwd: strides");
+  MDIE_REQUIRE(!d->dmul || d->mul, "mdie_cbam_train_bwd: dmul without mul");
+  a.dout = (const char*)d->dout; a.dout_stride = d->dout_stride;
+  a.dx = (char*)d->dx; a.dx_stride = d->dx_stride;
+  a.dmul = (char*)d->dmul; a.dmul_stride = d->dmul_stride;
+  a.dw1 = d->dw1; a.db1 = d->db1; a.dw2 = d->dw2; a.db2 = d->db2; a.dw7 = d->dw7; a.dgamma = d->dgamma; a.dbeta = d->dbeta;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return d->dtype == MDIE_F32 ? ct_backward<float>(d, a, s) : ct_backward<mdie::bf16>(d, a, s);
+}

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 10
+ABI_VERSION = 11
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 LOSS_KINDS = {"mse": 0, "l1": 1, "charbonnier": 2, "ssim": 3, "gradient_l1": 4}
@@ -70,6 +70,19 @@ class BnBwdDesc(C.Structure):
                 ("mean", C.c_void_p), ("invstd", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", C.c_int),
                 ("c_real", C.c_int), ("split", C.c_int), ("gap", C.c_int),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("coef", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class CbamTrainDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
+                ("x", C.c_void_p), ("x_stride", C.c_int), ("mul", C.c_void_p), ("mul_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("w7", C.c_void_p),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("momentum", C.c_float), ("eps", C.c_float),
+                ("gate", C.c_void_p), ("amax_idx", C.c_void_p), ("pooled", C.c_void_p), ("comp", C.c_void_p), ("smap", C.c_void_p), ("bnc", C.c_void_p),
+                ("dout", C.c_void_p), ("dout_stride", C.c_int), ("dx", C.c_void_p), ("dx_stride", C.c_int), ("dmul", C.c_void_p), ("dmul_stride", C.c_int),
+                ("dw1", C.c_void_p), ("db1", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p), ("dw7", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
@@ -178,6 +191,9 @@ SIGNATURES = {
     "mdie_bn_bwd_reduce": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p]),
     "mdie_bn_bwd_apply": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p]),
     "mdie_sigmoid_bwd_nchw3": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mdie_cbam_train_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mdie_cbam_train_fwd": (C.c_int, [C.POINTER(CbamTrainDesc), C.c_void_p]),
+    "mdie_cbam_train_bwd": (C.c_int, [C.POINTER(CbamTrainDesc), C.c_void_p]),
     "mdie_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mdie_loss_fwd_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(LossTerm), C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),

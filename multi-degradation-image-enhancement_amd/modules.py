@@ -115,11 +115,16 @@ class CBAM(nn.Module):
         self.precision = precision or os.environ.get("MDIE_PRECISION", "fp32")
 
     def forward(self, x):
-        if self.training:
-            raise NotImplementedError("CBAM.forward in training mode is not built yet; call .eval()")
         if not x.is_cuda:
             raise L.MdieError(f"CBAM.forward: input is on {x.device}; GPU only (no CPU fallback)")
         dt = E.dtype_id(self.precision)
+        if self.training:
+            if self.no_spatial:
+                raise NotImplementedError("CBAM(no_spatial=True) has no training path (the network never builds one)")
+            from . import train as T
+            self.SpatialGate.spatial.bn.num_batches_tracked += 1
+            y = T.cbam(dt, self, x.to(E.TORCH_DTYPE[dt]).contiguous(memory_format=torch.channels_last))
+            return y.float().contiguous()
         sd = self.state_dict()
         dev = x.device
         f = lambda k: sd[k].to(dev, torch.float32).contiguous()

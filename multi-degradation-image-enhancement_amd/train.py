@@ -6,13 +6,14 @@ that orders three block-level Functions:
   _ConvBnFn   encoder ConvBlock: conv3x3 -> batch-stat BN -> ReLU -> maxpool -> dropout   (models/cdan.py:15-19,74-79)
   _DenseFn    DenseBlock: 4 x [BN -> ReLU -> conv3x3] -> BN -> ReLU -> conv1x1 [-> sigmoid] (models/cdan.py:32-53,155-157)
   _DeconvFn   decoder stage: ConvTranspose3x3 -> BN -> ReLU [-> bilinear x2] + skip       (models/cdan.py:127-154)
+  _CbamFn     CBAM (channel gate, spatial gate with batch-stat BN) [* dense_k]            (models/cbam.py:37-95)
 
 each of which calls the HIP convolution (forward / dgrad / wgrad, csrc/conv.hip, csrc/train.hip) and the fused
 BatchNorm kernels of csrc/bn.hip in both directions.  The pre-activation BN + ReLU of the dense layers is never
 materialised: it is the staging prologue of the convolution and of its weight-gradient kernel, and a segment's
-batch statistics are computed once, not once per consuming layer.  The four CBAM gates (a few MB of traffic and
-~1 FLOP/byte) are still composed from PyTorch-ROCm device ops and differentiated by autograd.  Nothing here
-touches the CPU or the oracle.  Tensors are `channels_last`, which IS the engine's NHWC layout.
+batch statistics are computed once, not once per consuming layer.  A fourth Function, _CbamFn, is CBAM (with the
+`out *= dense_k` that follows it) on csrc/cbam_train.hip.  Nothing here touches the CPU or the oracle, and no
+tensor-sized PyTorch operator is left on the path.  Tensors are `channels_last`, which IS the engine's NHWC layout.
 
 Reference semantics kept: BatchNorm uses batch statistics and updates running statistics with momentum 0.1
 (0.01 in CBAM's spatial gate, models/cbam.py:11), eps 1e-5; dropout p=0.2 after each encoder stage with the
@@ -466,21 +467,71 @@ def deconv_stage(dt, cv, bn, x, skip, up):
     return _DeconvFn.apply(x, cv.weight, cv.bias, bn.weight, bn.bias, skip, bn, dt, up)
 
 
-def _cbam(node, x):
-    """CBAM.forward in training mode (models/cbam.py:37-60, 68-82, 91-95)."""
-    mlp = node.ChannelGate.mlp
-    w1, b1, w2, b2 = mlp._modules["1"].weight, mlp._modules["1"].bias, mlp._modules["3"].weight, mlp._modules["3"].bias
+class _CbamFn(torch.autograd.Function):
+    """CBAM.forward (models/cbam.py:91-95) in training mode, optionally times `mul` (the `out *= dense_k` that follows it)."""
 
-    def gate(v):
-        return F.linear(F.relu(F.linear(v, w1.to(v.dtype), b1.to(v.dtype))), w2.to(v.dtype), b2.to(v.dtype))
+    @staticmethod
+    def forward(ctx, x, mul, w1, b1, w2, b2, w7, gamma, beta, bn, dt):
+        B, Cc, H, W = x.shape
+        dev = x.device
+        f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        gate, pooled, comp, smap, bnc = f32(B, Cc), f32(B, 2, Cc), f32(B, H, W, 2), f32(B, H, W), f32(4)
+        amax = torch.empty(B, Cc, dtype=torch.int32, device=dev)
+        out = torch.empty_like(x)
+        params = [_f32(p) for p in (w1, b1, w2, b2, w7, gamma, beta)]
+        d = _CbamFn._desc(dt, x, mul, params, gate, amax, pooled, comp, smap, bnc)
+        d.out, d.out_stride = out.data_ptr(), out.stride(3)
+        d.running_mean, d.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        nws = L.lib.mdie_cbam_train_workspace_bytes(B, H, W, Cc)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), nws
+        L.check(L.lib.mdie_cbam_train_fwd(C.byref(d), _sp(dev)), "mdie_cbam_train_fwd")
+        ctx.save_for_backward(x, mul, gate, amax, pooled, comp, smap, bnc, *params)
+        ctx.dt = dt
+        return out
 
-    att = gate(x.mean(dim=(2, 3))) + gate(x.amax(dim=(2, 3)))
-    xg = x * torch.sigmoid(att)[:, :, None, None]
-    sp = node.SpatialGate.spatial
-    comp = torch.stack((xg.amax(dim=1), xg.mean(dim=1)), dim=1)
-    m = F.conv2d(comp.float(), sp.conv.weight, None, padding=3)
-    m = F.batch_norm(m, sp.bn.running_mean, sp.bn.running_var, sp.bn.weight, sp.bn.bias, True, 0.01, EPS)
-    return xg * torch.sigmoid(m).to(xg.dtype)
+    @staticmethod
+    def _desc(dt, x, mul, params, gate, amax, pooled, comp, smap, bnc):
+        B, Cc, H, W = x.shape
+        d = L.CbamTrainDesc()
+        d.dtype, d.B, d.H, d.W, d.C = dt, B, H, W, Cc
+        ptr, _, st = _nhwc(x)
+        d.x, d.x_stride = ptr, st
+        if mul is not None:
+            ptr, _, st = _nhwc(mul)
+            d.mul, d.mul_stride = ptr, st
+        d.w1, d.b1, d.w2, d.b2, d.w7, d.gamma, d.beta = [p.data_ptr() for p in params]
+        d.momentum, d.eps = 0.01, EPS
+        d.gate, d.amax_idx, d.pooled, d.comp, d.smap, d.bnc = [t.data_ptr() for t in (gate, amax, pooled, comp, smap, bnc)]
+        return d
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, mul, gate, amax, pooled, comp, smap, bnc, *params = ctx.saved_tensors
+        dt = ctx.dt
+        B, Cc, H, W = x.shape
+        dev = x.device
+        d_out = _cl(d_out.to(E.TORCH_DTYPE[dt]))
+        d = _CbamFn._desc(dt, x, mul, params, gate, amax, pooled, comp, smap, bnc)
+        dx = torch.empty_like(x)
+        dmul = torch.empty_like(mul) if mul is not None else None
+        grads = [torch.empty_like(p) for p in params]
+        d.dout, d.dout_stride = d_out.data_ptr(), d_out.stride(3)
+        d.dx, d.dx_stride = dx.data_ptr(), dx.stride(3)
+        if dmul is not None:
+            d.dmul, d.dmul_stride = dmul.data_ptr(), dmul.stride(3)
+        d.dw1, d.db1, d.dw2, d.db2, d.dw7, d.dgamma, d.dbeta = [g.data_ptr() for g in grads]
+        nws = L.lib.mdie_cbam_train_workspace_bytes(B, H, W, Cc)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), nws
+        L.check(L.lib.mdie_cbam_train_bwd(C.byref(d), _sp(dev)), "mdie_cbam_train_bwd")
+        return (dx, dmul, *grads, None, None)
+
+
+def cbam(dt, node, x, mul=None):
+    mlp, sp = node.ChannelGate.mlp._modules, node.SpatialGate.spatial
+    return _CbamFn.apply(_cl(x), None if mul is None else _cl(mul), mlp["1"].weight, mlp["1"].bias, mlp["3"].weight, mlp["3"].bias,
+                         sp.conv.weight, sp.bn.weight, sp.bn.bias, sp.bn, dt)
 
 
 def forward_train(net, x, precision="fp32", dropout_p=0.2):
@@ -505,13 +556,13 @@ def forward_train(net, x, precision="fp32", dropout_p=0.2):
         denses.append(dense_block(dt, getattr(enc, f"dense{i}"), o, o.shape[1]))
         skips.append(t)
     e = conv_block(dt, enc.conv4, t, False, dropout_p, need_o=False)
-    t = _cl(_cbam(net.bottleneck, e))
+    t = cbam(dt, net.bottleneck, e)
     t = deconv_stage(dt, dec.conv1, dec.bn1, t, skips[2], False)
-    t = _cl(_cbam(dec.cbam1, t) * denses[2])
+    t = cbam(dt, dec.cbam1, t, denses[2])
     t = deconv_stage(dt, dec.conv2, dec.bn2, t, skips[1], True)
-    t = _cl(_cbam(dec.cbam2, t) * denses[1])
+    t = cbam(dt, dec.cbam2, t, denses[1])
     t = deconv_stage(dt, dec.conv3, dec.bn3, t, skips[0], True)
-    t = _cl(_cbam(dec.cbam3, t) * denses[0])
+    t = cbam(dt, dec.cbam3, t, denses[0])
     t = deconv_stage(dt, dec.conv4, dec.bn4, t, xin, True)
     return dense_block(dt, dec.final_dense, t, 3, sigmoid=True)
 

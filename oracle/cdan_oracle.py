@@ -59,8 +59,9 @@ def channel_gate(sd, p, x):
     def mlp(v):
         return F.linear(F.relu(F.linear(v, w1, b1)), w2, b2)
 
-    avg = x.mean(dim=(2, 3))
-    mx = x.amax(dim=(2, 3))
+    hw = (x.shape[2], x.shape[3])
+    avg = F.avg_pool2d(x, hw, stride=hw).flatten(1)     # cbam.py:41
+    mx = F.max_pool2d(x, hw, stride=hw).flatten(1)      # cbam.py:44 (its backward routes to ONE arg-max)
     att = mlp(avg) + mlp(mx)
     return x * torch.sigmoid(att)[:, :, None, None]
 
@@ -68,7 +69,7 @@ def channel_gate(sd, p, x):
 def spatial_gate(sd, p, x, bn_mode="eval", stats_out=None):
     """SpatialGate.forward, cbam.py:78-82; ChannelPool order is (max, mean),
     cbam.py:68-70; 7x7 conv without bias, BN(1) momentum 0.01, no ReLU (cbam.py:77)."""
-    comp = torch.stack((x.amax(dim=1), x.mean(dim=1)), dim=1)
+    comp = torch.cat((torch.max(x, 1)[0].unsqueeze(1), torch.mean(x, 1).unsqueeze(1)), dim=1)   # cbam.py:68-70
     m = F.conv2d(comp, sd[p + ".spatial.conv.weight"], None, stride=1, padding=3)
     m = _bn(sd, p + ".spatial.bn", m, bn_mode, 0.01, stats_out)
     return x * torch.sigmoid(m)

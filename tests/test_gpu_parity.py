@@ -777,3 +777,54 @@ def test_decoder_stage_train_matches_oracle(E, L, i, hw):
     assert rel_to_max(bn.bias.grad, sd[keys[3]].grad) <= 2e-4
     for k, v in stats.items():
         assert rel_to_max(net.state_dict()[k], v) <= 2e-5, k
+
+
+@pytest.mark.parametrize("name,C,hw,with_mul", [("bottleneck", 512, (4, 6), False), ("decoder.cbam1", 256, (8, 8), True),
+                                                ("decoder.cbam2", 128, (10, 12), True), ("decoder.cbam3", 64, (24, 17), True)])
+def test_cbam_train_matches_oracle(E, L, name, C, hw, with_mul):
+    """CBAM with the spatial gate's BatchNorm on batch statistics (* dense_k): output, running statistics, every gradient."""
+    import mdie_amd.train as T
+    from oracle import cdan_oracle as O
+    net, sd = _train_net()
+    node = net.get_submodule(name)
+    keys = [k for k in sd if k.startswith(name + ".") and sd[k].is_floating_point() and "running" not in k]
+    _leaf(sd, keys)
+    g = torch.Generator().manual_seed(C)
+    # post-ReLU-like input: non-negative with exact zeros, so the arg-max tie rules matter
+    x = torch.relu(torch.randn(2, C, *hw, generator=g, dtype=torch.float64))
+    mul = torch.randn(2, C, *hw, generator=g, dtype=torch.float64) if with_mul else None
+    rx = x.clone().requires_grad_(True)
+    rm = mul.clone().requires_grad_(True) if with_mul else None
+    stats = {}
+    ry = O.cbam(sd, name, rx, "train", stats)
+    if with_mul:
+        ry = ry * rm
+    gy = torch.randn(ry.shape, generator=g, dtype=torch.float64)
+    ry.backward(gy)
+    gx = _nhwc_cuda(x).requires_grad_(True)
+    gm = _nhwc_cuda(mul).requires_grad_(True) if with_mul else None
+    y = T.cbam(L.F32, node, gx, gm)
+    y.backward(_nhwc_cuda(gy))
+    assert rel_to_max(y, ry) <= 2e-5
+    assert rel_to_max(gx.grad, rx.grad) <= 2e-4
+    if with_mul:
+        assert rel_to_max(gm.grad, rm.grad) <= 2e-5
+    named = dict(node.named_parameters())
+    for k in keys:
+        assert rel_to_max(named[k[len(name) + 1:]].grad, sd[k].grad) <= 5e-4, k
+    for k, v in stats.items():
+        assert rel_to_max(net.state_dict()[k], v) <= 2e-5, k
+
+
+def test_cbam_module_train_mode(E):
+    """the public CBAM module (models.cbam.CBAM) in training mode: NCHW fp32 in / out, differentiable"""
+    from models.cbam import CBAM
+    torch.manual_seed(3)
+    m = CBAM(64).cuda().train()
+    x = torch.rand(2, 64, 12, 12, device="cuda", requires_grad=True)
+    y = m(x)
+    assert y.shape == x.shape and y.dtype == torch.float32
+    y.square().mean().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    assert int(m.SpatialGate.spatial.bn.num_batches_tracked) == 1
