@@ -3,9 +3,8 @@
 //
 //   out = x * g[b,c] * s[b,h,w] (* mul)     g = sigmoid(MLP(avg_hw x) + MLP(max_hw x))
 //                                           s = sigmoid(BN(conv7x7([max_c xg, mean_c xg]))),  xg = x * g
-// Forward passes over the tensor: pool (+ arg-max), chanpool (cbam.hip, gate in its prologue), apply (cbam.hip's
-// spatial kernel reading the precomputed map); in between, three kernels on the [B,H,W] maps (7x7 convolution, its
-// batch statistics, fold).  Backward passes over the tensor:
+// Forward passes over the tensor: pool (+ arg-max), chanpool, apply; in between, the MLP and three kernels on the
+// [B,H,W] maps (7x7 convolution, its batch statistics, fold).  Backward passes over the tensor:
 //   bwd1  dmul = dout * xg * s;  ds = sum_c dout * xg * mul  ->  dn = ds * s (1 - s)  (+ partial sums for the BN)
 //   bwd3  dxg = dout * s * mul + dcomp_mean / C + [c == argmax_c xg] dcomp_max;  dx = dxg * g;  dg = sum_hw dxg * x
 //   bwd4  dx += davg / HW + [p == argmax_hw x] dmax          (the two pooled vectors' gradients, from the MLP backward)
@@ -50,6 +49,7 @@ struct CbtArgs {
   float* part2;     // [blocks][2]
   float* part98;    // [tiles*B][98]
   float* partC;     // [B][gx][C]
+  float* pgrad;     // [B][2*Hd*C + Hd + C] per-image MLP parameter gradients
   int nslab, slab, gx;
 };
 
@@ -369,12 +369,13 @@ __global__ __launch_bounds__(CT_THREADS) void cbt_conv7_bwd_kernel(const CbtArgs
   }
 }
 
-__global__ __launch_bounds__(128) void cbt_w7_final_kernel(const CbtArgs a, int nparts) {
-  const int t = threadIdx.x;
-  if (t >= 98) return;
+__global__ __launch_bounds__(64) void cbt_w7_final_kernel(const CbtArgs a, int nparts) {
+  const int t = blockIdx.x;     // one block per weight
   double s = 0.0;
-  for (int i = 0; i < nparts; ++i) s += a.part98[(size_t)i * 98 + t];
-  a.dw7[t] = (float)s;
+  for (int i = threadIdx.x; i < nparts; i += 64) s += a.part98[(size_t)i * 98 + t];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+  if (threadIdx.x == 0) a.dw7[t] = (float)s;
 }
 
 // ---- backward 3: dx (without the pooled terms) and dg partials -------------------------------------------------------------
@@ -443,10 +444,12 @@ __global__ __launch_bounds__(CT_THREADS) void cbt_bwd3_kernel(const CbtArgs a, c
   }
 }
 
-// MLP backward, one block, images in sequence (deterministic accumulation into the parameter gradients)
+// MLP backward: one block per image writes that image's share of the parameter gradients (pgrad[img][...]) and the
+// gradients of the two pooled vectors; cbt_gate_final_kernel folds the images in order.
+// pgrad layout per image: dw1 [Hd*C] | dw2 [C*Hd] | db1 [Hd] | db2 [C]
 __global__ __launch_bounds__(CT_THREADS) void cbt_gate_bwd_kernel(const CbtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char dyn[];
-  const int C = a.C, Hd = C / 16, tid = threadIdx.x;
+  const int C = a.C, Hd = C / 16, tid = threadIdx.x, img = blockIdx.x;
   float* datt = reinterpret_cast<float*>(dyn);   // [C]
   float* avg = datt + C;                          // [C]
   float* mx = avg + C;                            // [C]
@@ -454,46 +457,70 @@ __global__ __launch_bounds__(CT_THREADS) void cbt_gate_bwd_kernel(const CbtArgs 
   float* pm = pa + Hd;                            // [Hd]
   float* dpa = pm + Hd;                           // [Hd]
   float* dpm = dpa + Hd;                          // [Hd]
-  for (int img = 0; img < a.B; ++img) {
-    for (int c = tid; c < C; c += CT_THREADS) {
-      float dg = 0.f;
-      for (int k = 0; k < a.gx; ++k) dg += a.partC[((size_t)img * a.gx + k) * C + c];
-      const float g = a.gate[(size_t)img * C + c];
-      datt[c] = dg * g * (1.f - g);
-      avg[c] = a.pooled[((size_t)img * 2 + 0) * C + c];
-      mx[c] = a.pooled[((size_t)img * 2 + 1) * C + c];
-    }
-    __syncthreads();
-    for (int j = tid; j < Hd; j += CT_THREADS) {
-      float sa = a.b1[j], sm = a.b1[j], dh = 0.f;
-      const float* w = a.w1 + (size_t)j * C;
-      for (int c = 0; c < C; ++c) { sa = fmaf(w[c], avg[c], sa); sm = fmaf(w[c], mx[c], sm); dh = fmaf(a.w2[(size_t)c * Hd + j], datt[c], dh); }
-      pa[j] = sa; pm[j] = sm;
-      dpa[j] = sa > 0.f ? dh : 0.f;
-      dpm[j] = sm > 0.f ? dh : 0.f;
-      const float v = dpa[j] + dpm[j];
-      a.db1[j] = img == 0 ? v : a.db1[j] + v;
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += CT_THREADS) {
-      const float v = 2.f * datt[c];
-      a.db2[c] = img == 0 ? v : a.db2[c] + v;
-      float da = 0.f, dm = 0.f;
-      for (int j = 0; j < Hd; ++j) { const float w = a.w1[(size_t)j * C + c]; da = fmaf(w, dpa[j], da); dm = fmaf(w, dpm[j], dm); }
-      a.davg[(size_t)img * C + c] = da;
-      a.dmaxv[(size_t)img * C + c] = dm;
-    }
-    for (int u = tid; u < C * Hd; u += CT_THREADS) {
-      // dW2[c][j] += datt[c] * (relu(pa[j]) + relu(pm[j]));  dW1[j][c] += dpa[j] * avg[c] + dpm[j] * mx[c]
-      const int c2 = u / Hd, j2 = u - c2 * Hd;
-      const float v2 = datt[c2] * (fmaxf(pa[j2], 0.f) + fmaxf(pm[j2], 0.f));
-      a.dw2[u] = img == 0 ? v2 : a.dw2[u] + v2;
-      const int j1 = u / C, c1 = u - j1 * C;
-      const float v1 = dpa[j1] * avg[c1] + dpm[j1] * mx[c1];
-      a.dw1[u] = img == 0 ? v1 : a.dw1[u] + v1;
-    }
-    __syncthreads();
+  float* part = dpm + Hd;                         // [3][CT_THREADS]
+  float* pg = a.pgrad + (size_t)img * (2 * (size_t)Hd * C + Hd + C);
+  for (int c = tid; c < C; c += CT_THREADS) {
+    float dg = 0.f;
+    for (int k = 0; k < a.gx; ++k) dg += a.partC[((size_t)img * a.gx + k) * C + c];
+    const float g = a.gate[(size_t)img * C + c];
+    datt[c] = dg * g * (1.f - g);
+    avg[c] = a.pooled[((size_t)img * 2 + 0) * C + c];
+    mx[c] = a.pooled[((size_t)img * 2 + 1) * C + c];
   }
+  __syncthreads();
+  {
+    // hidden unit j is split over `parts` threads, each a contiguous run of channels (all loads in flight at once)
+    const int parts = CT_THREADS / Hd, run = C / parts > 0 ? C / parts : 1;
+    const int j = tid / parts, q = tid - j * parts;
+    float sa = 0.f, sm = 0.f, dh = 0.f;
+    if (j < Hd && q * run < C) {
+      const int c0 = q * run;
+      const float* w = a.w1 + (size_t)j * C + c0;
+      for (int i = 0; i < run; ++i) {
+        sa = fmaf(w[i], avg[c0 + i], sa); sm = fmaf(w[i], mx[c0 + i], sm);
+        dh = fmaf(a.w2[(size_t)(c0 + i) * Hd + j], datt[c0 + i], dh);
+      }
+    }
+    part[tid] = sa; part[CT_THREADS + tid] = sm; part[2 * CT_THREADS + tid] = dh;
+    __syncthreads();
+    if (tid < Hd) {
+      float ta = a.b1[tid], tm = a.b1[tid], th = 0.f;
+      for (int k = 0; k < parts; ++k) { ta += part[tid * parts + k]; tm += part[CT_THREADS + tid * parts + k]; th += part[2 * CT_THREADS + tid * parts + k]; }
+      pa[tid] = ta; pm[tid] = tm;
+      dpa[tid] = ta > 0.f ? th : 0.f;
+      dpm[tid] = tm > 0.f ? th : 0.f;
+      pg[2 * (size_t)Hd * C + tid] = dpa[tid] + dpm[tid];                      // db1
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += CT_THREADS) {
+    pg[2 * (size_t)Hd * C + Hd + c] = 2.f * datt[c];                            // db2 (the MLP bias is applied to both branches)
+    float da = 0.f, dm = 0.f;
+    for (int j = 0; j < Hd; ++j) { const float w = a.w1[(size_t)j * C + c]; da = fmaf(w, dpa[j], da); dm = fmaf(w, dpm[j], dm); }
+    a.davg[(size_t)img * C + c] = da;
+    a.dmaxv[(size_t)img * C + c] = dm;
+  }
+  for (int u = tid; u < C * Hd; u += CT_THREADS) {
+    // dW1[j][c] = dpa[j] * avg[c] + dpm[j] * mx[c];  dW2[c][j] = datt[c] * (relu(pa[j]) + relu(pm[j]))
+    const int j1 = u / C, c1 = u - j1 * C;
+    pg[u] = dpa[j1] * avg[c1] + dpm[j1] * mx[c1];
+    const int c2 = u / Hd, j2 = u - c2 * Hd;
+    pg[(size_t)Hd * C + u] = datt[c2] * (fmaxf(pa[j2], 0.f) + fmaxf(pm[j2], 0.f));
+  }
+}
+
+__global__ __launch_bounds__(CT_THREADS) void cbt_gate_final_kernel(const CbtArgs a) {
+  const int C = a.C, Hd = C / 16;
+  const size_t per = 2 * (size_t)Hd * C + Hd + C;
+  const size_t u = (size_t)blockIdx.x * CT_THREADS + threadIdx.x;
+  if (u >= per) return;
+  float s = 0.f;
+  for (int img = 0; img < a.B; ++img) s += a.pgrad[(size_t)img * per + u];
+  const size_t n1 = (size_t)Hd * C;
+  if (u < n1) a.dw1[u] = s;
+  else if (u < 2 * n1) a.dw2[u - n1] = s;
+  else if (u < 2 * n1 + Hd) a.db1[u - 2 * n1] = s;
+  else a.db2[u - 2 * n1 - Hd] = s;
 }
 
 // dx += davg / HW + [p == argmax] dmax
@@ -531,7 +558,7 @@ static int ct_gx(int H, int W, int groups) {
   return gx < 1 ? 1 : gx;
 }
 
-struct CtWs { size_t psum, pmax, pidx, part2, part98, partC, dn, dcomp, dbn, davg, dmaxv, total; };
+struct CtWs { size_t psum, pmax, pidx, part2, part98, partC, pgrad, dn, dcomp, dbn, davg, dmaxv, total; };
 static CtWs ct_ws(int B, int H, int W, int C) {
   CtWs w{};
   const size_t tiles = (size_t)cdiv(W, CT_TS) * cdiv(H, CT_TS);
@@ -543,6 +570,7 @@ static CtWs ct_ws(int B, int H, int W, int C) {
   w.part2 = o; o += ct256(n2 * 2 * 4);
   w.part98 = o; o += ct256((size_t)B * tiles * 98 * 4);
   w.partC = o; o += ct256((size_t)B * 64 * C * 4);
+  w.pgrad = o; o += ct256((size_t)B * (2 * (size_t)(C / 16) * C + C / 16 + C) * 4);
   w.dn = o; o += ct256((size_t)B * H * W * 4);
   w.dcomp = o; o += ct256((size_t)B * H * W * 2 * 4);
   w.dbn = o; o += 256;
@@ -570,7 +598,7 @@ static int ct_fill(const char* what, const mdie_cbam_train_desc* d, CbtArgs& a) 
   a.gate = d->gate; a.amax_idx = d->amax_idx; a.pooled = d->pooled; a.comp = d->comp; a.smap = d->smap; a.bnc = d->bnc;
   char* ws = reinterpret_cast<char*>(d->workspace);
   a.psum = (float*)(ws + w.psum); a.pmax = (float*)(ws + w.pmax); a.pidx = (int*)(ws + w.pidx);
-  a.part2 = (float*)(ws + w.part2); a.part98 = (float*)(ws + w.part98); a.partC = (float*)(ws + w.partC);
+  a.part2 = (float*)(ws + w.part2); a.part98 = (float*)(ws + w.part98); a.partC = (float*)(ws + w.partC); a.pgrad = (float*)(ws + w.pgrad);
   a.dn = (float*)(ws + w.dn); a.dcomp = (float*)(ws + w.dcomp); a.dbn = (float*)(ws + w.dbn);
   a.davg = (float*)(ws + w.davg); a.dmaxv = (float*)(ws + w.dmaxv);
   a.nslab = ct_nslab(d->H, d->W);
@@ -611,11 +639,13 @@ static int ct_backward(const mdie_cbam_train_desc* d, CbtArgs& a, hipStream_t s)
   else hipLaunchKernelGGL((cbt_bwd1_kernel<T, 2>), dim3(gx, d->B), dim3(CT_THREADS), 0, s, a, LPP);
   hipLaunchKernelGGL(cbt_bnbwd_kernel, dim3(1), dim3(CT_THREADS), 0, s, a, gx * d->B);
   hipLaunchKernelGGL(cbt_conv7_bwd_kernel, dim3(tiles, d->B), dim3(CT_THREADS), 0, s, a);
-  hipLaunchKernelGGL(cbt_w7_final_kernel, dim3(1), dim3(128), 0, s, a, tiles * d->B);
+  hipLaunchKernelGGL(cbt_w7_final_kernel, dim3(98), dim3(64), 0, s, a, tiles * d->B);
   const size_t lds3 = (size_t)groups * d->C * 4;
   if (NV == 1) hipLaunchKernelGGL((cbt_bwd3_kernel<T, 1>), dim3(gx, d->B), dim3(CT_THREADS), lds3, s, a, LPP);
   else hipLaunchKernelGGL((cbt_bwd3_kernel<T, 2>), dim3(gx, d->B), dim3(CT_THREADS), lds3, s, a, LPP);
-  hipLaunchKernelGGL(cbt_gate_bwd_kernel, dim3(1), dim3(CT_THREADS), (size_t)(3 * d->C + 4 * (d->C / 16)) * 4, s, a);
+  hipLaunchKernelGGL(cbt_gate_bwd_kernel, dim3(d->B), dim3(CT_THREADS), (size_t)(3 * d->C + 4 * (d->C / 16) + 3 * CT_THREADS) * 4, s, a);
+  const size_t per = 2 * (size_t)(d->C / 16) * d->C + d->C / 16 + d->C;
+  hipLaunchKernelGGL(cbt_gate_final_kernel, dim3((unsigned)((per + CT_THREADS - 1) / CT_THREADS)), dim3(CT_THREADS), 0, s, a);
   int g4 = cdiv(d->H * d->W, rows * 4);
   if (g4 > 256) g4 = 256;
   hipLaunchKernelGGL((cbt_bwd4_kernel<T>), dim3(g4, d->B), dim3(CT_THREADS), 0, s, a);
