@@ -85,8 +85,9 @@ class CdanEngine:
             n = L.lib.mdie_cdan_workspace_bytes(self.dtype, B, H, W)
             if n == 0:
                 raise L.MdieError(f"unsupported input extent {B}x3x{H}x{W}: H and W must be multiples of 8")
-            self._ws = None  # release before re-allocating
-            self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            if self._ws is None or self._ws.numel() < n:   # a larger buffer serves smaller batches (routed groups) as is
+                self._ws = None  # release before re-allocating
+                self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
             self._ws_key = key
         return self._ws
 
@@ -127,6 +128,79 @@ class CdanEngine:
         out = torch.empty(B, tap.channels, tap.H, tap.W, dtype=torch.float32, device=self.device)
         L.check(L.lib.mdie_nhwc_to_nchw(self.dtype, B, tap.channels, tap.H, tap.W, C.c_void_p(tap.ptr), out.data_ptr(),
                                         _stream_ptr(self.device)), "mdie_nhwc_to_nchw")
+        return out
+
+
+class RoutedEngine:
+    """Classifier-routed inference (BASELINE configs[3]): one weight set per degradation task
+    (the reference trains one CDAN per config/*.json), every image pre-labelled with its task by a router.  Images are
+    grouped by task so each weight set is bound once per batch.  A group of 3-4 images cannot fill 256 CUs, so the
+    groups run CONCURRENTLY: one HIP stream and one workspace slice per group, forked from and joined to the caller's
+    stream with events.  The router itself (ResNet18, classification/train_multilabel_classifier.py) is out of scope:
+    labels come from the caller."""
+
+    def __init__(self, device, precision="bf16"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.MdieError(f"RoutedEngine needs a GPU device, got {self.device} (no CPU fallback)")
+        self.dtype = dtype_id(precision)
+        self.blobs = {}
+        self._streams = []
+        self._ws = None
+
+    def load_task(self, task, state_dict):
+        self.blobs[task] = pack_checkpoint(state_dict, self.dtype).to(self.device)
+        return self
+
+    def forward(self, x, labels):
+        """x: float32 NCHW [B,3,H,W] on the GPU; labels: B task keys (host side).  Returns [B,3,H,W] in input order."""
+        _require_gpu(x, "RoutedEngine.forward")
+        labels = list(labels)
+        if x.dim() != 4 or x.shape[1] != 3 or len(labels) != x.shape[0]:
+            raise L.MdieError(f"RoutedEngine.forward: input {tuple(x.shape)} with {len(labels)} labels")
+        missing = sorted({str(t) for t in labels if t not in self.blobs})
+        if missing:
+            raise L.MdieError(f"RoutedEngine.forward: no weights loaded for task(s) {missing}")
+        B, _, H, W = x.shape
+        order = sorted(range(B), key=lambda i: (str(labels[i]), i))               # stable grouping
+        groups, a = [], 0
+        while a < B:
+            b = a
+            while b < B and labels[order[b]] == labels[order[a]]:
+                b += 1
+            groups.append((a, b, labels[order[a]]))
+            a = b
+        sizes = [L.lib.mdie_cdan_workspace_bytes(self.dtype, b - a, H, W) for a, b, _ in groups]
+        if 0 in sizes:
+            raise L.MdieError(f"unsupported input extent {B}x3x{H}x{W}: H and W must be multiples of 8")
+        sizes = [(n + 255) // 256 * 256 for n in sizes]
+        if self._ws is None or self._ws.numel() < sum(sizes):
+            self._ws = None
+            self._ws = torch.empty(sum(sizes), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            while len(self._streams) < len(groups):
+                self._streams.append(torch.cuda.Stream(self.device))
+            main = torch.cuda.current_stream(self.device)
+            idx = torch.tensor(order, device=self.device)
+            xs = x.to(torch.float32).index_select(0, idx)
+            ys = torch.empty_like(xs)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            off = 0
+            for (a, b, task), n, st in zip(groups, sizes, self._streams):
+                st.wait_event(fork)
+                d = L.CdanFwdDesc()
+                d.dtype, d.B, d.H, d.W = self.dtype, b - a, H, W
+                d.params, d.x, d.y = self.blobs[task].data_ptr(), xs[a:b].data_ptr(), ys[a:b].data_ptr()
+                d.workspace, d.workspace_bytes = self._ws.data_ptr() + off, n
+                d.flags, d.aux = 0, None
+                L.check(L.lib.mdie_cdan_forward(C.byref(d), st.cuda_stream), "mdie_cdan_forward")
+                off += n
+                done = torch.cuda.Event()
+                done.record(st)
+                main.wait_event(done)
+            out = torch.empty_like(ys)
+            out.index_copy_(0, idx, ys)
         return out
 
 

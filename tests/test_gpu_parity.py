@@ -828,3 +828,43 @@ def test_cbam_module_train_mode(E):
     assert x.grad is not None and torch.isfinite(x.grad).all()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
     assert int(m.SpatialGate.spatial.bn.num_batches_tracked) == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] (routed mixed degradations) and configs[4] (1024x1024, batch 1)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_routed_inference_matches_per_task_engines(E):
+    """images grouped by task label run with that task's weights; the result is bitwise what a dedicated engine returns
+    for the same image (batch independence), in the caller's order"""
+    from oracle import params as P
+    tasks = {"noise": 11, "blur": 12, "low_light": 13}
+    routed = E.RoutedEngine("cuda", "bf16")
+    single = {}
+    for t, seed in tasks.items():
+        sd = P.make_state_dict(seed)
+        routed.load_task(t, sd)
+        single[t] = E.CdanEngine("cuda", "bf16").load(sd)
+    x, _ = P.lowlight_batch(9, 7, 32, 40)
+    x = x.cuda()
+    labels = ["blur", "noise", "blur", "low_light", "noise", "noise", "blur"]
+    y = routed.forward(x, labels)
+    for i, t in enumerate(labels):
+        assert torch.equal(y[i], single[t].forward(x[i:i + 1])[0]), (i, t)
+    with pytest.raises(Exception):
+        routed.forward(x, ["jpeg"] * 7)
+    with pytest.raises(Exception):
+        routed.forward(x, labels[:3])
+
+
+def test_large_image_1024_against_oracle(E):
+    """configs[4]: one 1024x1024 image, fp32 and bf16 paths vs the CPU oracle"""
+    from oracle import cdan_oracle as O
+    from oracle import params as P
+    state_dict = P.make_state_dict(42)
+    x, _ = P.lowlight_batch(77, 1, 1024, 1024)
+    with torch.no_grad():
+        ref = O.cdan_forward(state_dict, x)
+    y32 = E.CdanEngine("cuda", "fp32").load(state_dict).forward(x.cuda())
+    assert rel_to_max(y32, ref) <= 1e-3                      # north-star tolerance; measured ~1e-5
+    y16 = E.CdanEngine("cuda", "bf16").load(state_dict).forward(x.cuda())
+    assert rel_to_max(y16, ref) <= 2.5e-2 and psnr(y16, ref) >= 40.0
