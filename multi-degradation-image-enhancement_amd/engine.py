@@ -101,6 +101,11 @@ class CdanEngine:
         x = x.to(torch.float32).contiguous()
         B, _, H, W = x.shape
         ws = self._workspace(B, H, W)
+        if out is None and not want_taps and not profile:
+            # the plain path goes through the registered operator (torch.ops.mdie.cdan_forward, ops.py)
+            from . import ops  # noqa: F401  (registers the library)
+            aux = self._aux.value if (self.use_side_streams and self._aux) else 0
+            return torch.ops.mdie.cdan_forward(x, self.params, ws, self.dtype, aux or 0, L.FWD_FUSED_TAIL if fused_tail else 0)
         y = out if out is not None else torch.empty_like(x)
         d = L.CdanFwdDesc()
         d.dtype, d.B, d.H, d.W = self.dtype, B, H, W

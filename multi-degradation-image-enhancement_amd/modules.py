@@ -136,7 +136,6 @@ class CBAM(nn.Module):
             p = "SpatialGate.spatial.bn."
             s = f(p + "weight") / torch.sqrt(f(p + "running_var") + 1e-5)
             bn = torch.cat((s, f(p + "bias") - f(p + "running_mean") * s))
-        y = E.cbam_fwd(E.to_nhwc(x.float(), dt), f("ChannelGate.mlp.1.weight"), f("ChannelGate.mlp.1.bias"),
-                       f("ChannelGate.mlp.3.weight"), f("ChannelGate.mlp.3.bias"), w7, bn, dtype=dt,
-                       channel_only=self.no_spatial)
-        return E.to_nchw(y, dt)
+        from . import ops  # noqa: F401  (registers torch.ops.mdie.*)
+        return torch.ops.mdie.cbam_forward(x, f("ChannelGate.mlp.1.weight"), f("ChannelGate.mlp.1.bias"), f("ChannelGate.mlp.3.weight"),
+                                           f("ChannelGate.mlp.3.bias"), w7, bn, dt, self.no_spatial)

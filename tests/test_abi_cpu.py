@@ -153,3 +153,19 @@ def test_pack_first_layer_weight(dtype):
         assert np.array_equal(np.concatenate((got[0], got[1]), axis=1), im2col)
     else:
         assert np.array_equal(dst.numpy().view(np.uint16).reshape(64, 32), bf16_bits(im2col))
+
+
+def test_custom_torch_ops_are_registered_and_have_no_cpu_kernel():
+    """torch.ops.mdie.* (ops.py): schema visible, fake implementation traces shapes, a CPU tensor fails in the dispatcher"""
+    import pytest
+    import torch
+    import mdie_amd.ops  # noqa: F401
+    assert "cdan_forward" in str(torch.ops.mdie.cdan_forward.default._schema)
+    with torch._subclasses.fake_tensor.FakeTensorMode():
+        x = torch.empty(2, 3, 64, 64)
+        y = torch.ops.mdie.cdan_forward(x, torch.empty(8, dtype=torch.uint8), torch.empty(8, dtype=torch.uint8), 1, 0, 0)
+        assert y.shape == (2, 3, 64, 64) and y.dtype == torch.float32
+    with pytest.raises(NotImplementedError):
+        torch.ops.mdie.cdan_forward(torch.zeros(1, 3, 8, 8), torch.zeros(8, dtype=torch.uint8), torch.zeros(8, dtype=torch.uint8), 1, 0, 0)
+    with pytest.raises(NotImplementedError):
+        torch.ops.mdie.psnr_ssim(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16))

@@ -109,15 +109,22 @@ def test_e2e_golden(E, net, golden_dir, tag, precision):
         assert psnr(y, g["y"]) >= 40.0
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_e2e_oracle_256(E, net, precision):
-    """BASELINE configs[1] image size (256x256, low-light recipe) against the oracle, B=2."""
+@pytest.fixture(scope="module")
+def oracle_256():
+    """(input, oracle output) at BASELINE configs[1]'s image size, computed once for both precisions"""
     from oracle import cdan_oracle as O
     from oracle import params as P
     x, _ = P.lowlight_batch(5, 2, 256, 256)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     with torch.no_grad():
-        ref = O.cdan_forward(P.make_state_dict(42), x)
+        return x, O.cdan_forward(P.make_state_dict(42), x)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_e2e_oracle_256(E, net, oracle_256, precision):
+    """BASELINE configs[1] image size (256x256, low-light recipe) against the oracle, B=2."""
+    x, ref = oracle_256
+    with torch.no_grad():
         net.precision = precision
         y = net(x.cuda())
     err = rel_to_max(y, ref)
@@ -630,11 +637,16 @@ def test_fused_loss_values_only_and_errors(E):
 # ---------------------------------------------------------------------------------------------------------------------
 # native training blocks (csrc/bn.hip + conv fwd/dgrad/wgrad) vs the CPU oracle differentiated by autograd, fp32 vs fp64
 # ---------------------------------------------------------------------------------------------------------------------
+_SD_CACHE = {}
+
+
 def _train_net(seed=42):
     from models.cdan import CDAN
     from oracle import params as P
     net = CDAN(precision="fp32")
-    sd = P.make_state_dict(seed)
+    if seed not in _SD_CACHE:
+        _SD_CACHE[seed] = P.make_state_dict(seed)
+    sd = {k: v.clone() for k, v in _SD_CACHE[seed].items()}
     net.load_state_dict(sd, strict=True)
     return net.cuda().train(), {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
 
@@ -868,3 +880,18 @@ def test_large_image_1024_against_oracle(E):
     assert rel_to_max(y32, ref) <= 1e-3                      # north-star tolerance; measured ~1e-5
     y16 = E.CdanEngine("cuda", "bf16").load(state_dict).forward(x.cuda())
     assert rel_to_max(y16, ref) <= 2.5e-2 and psnr(y16, ref) >= 40.0
+
+
+def test_registered_torch_ops_match_direct_calls(E, net):
+    """torch.ops.mdie.cdan_forward / cbam_forward / psnr_ssim == the ctypes path they wrap"""
+    import mdie_amd.ops  # noqa: F401
+    from mdie_amd import pipeline as PL
+    from oracle import params as P
+    x, t = P.lowlight_batch(4, 2, 32, 32)
+    x, t = x.cuda(), t.cuda()
+    eng = net._engine(x.device)
+    direct = torch.empty_like(x)
+    eng.forward(x, out=direct)                      # explicit-output path: plain ctypes
+    via_op = torch.ops.mdie.cdan_forward(x, eng.params, eng._workspace(2, 32, 32), eng.dtype, 0, 0)
+    assert torch.equal(via_op, direct) and torch.equal(net(x), direct)
+    assert torch.equal(torch.ops.mdie.psnr_ssim(direct, t), PL.psnr_ssim(direct, t))
