@@ -223,7 +223,13 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
   // order, so the fastest grid index is the XCD slot.  All output-channel tiles (y) of one pixel patch
   // share that slot: the patch is filled into ONE XCD's L2 and re-read there by the other n-tiles
   // (speed only -- nothing depends on the placement).
+#ifdef EXP_XCD_INTERLEAVE
   const int patch = blockIdx.z * 8 + blockIdx.x;
+#else
+  // each XCD slot owns a CONTIGUOUS run of patches (whole images where they divide evenly): neighbouring tiles share
+  // their halo pixels through that XCD's L2 instead of fetching them once per XCD
+  const int patch = blockIdx.x * gridDim.z + blockIdx.z;
+#endif
   if (patch >= a.tiles_x * a.tiles_y * a.B) return;
   const int tpi = a.tiles_x * a.tiles_y;
   const int img = patch / tpi;
