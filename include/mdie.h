@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 11
+#define MDIE_ABI_VERSION 12
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -225,10 +225,15 @@ int mdie_tail_fwd(const mdie_tail_desc* d, void* stream);
 int mdie_upsample2x_add(int dtype, int B, int H, int W, int C, const void* lo, int lo_stride,
                         const void* skip, int skip_stride, void* out, int out_stride, void* stream);
 /* Same, additionally reducing the tensor it writes for the CBAM that consumes it next (models/cdan.py:139,147):
- * pool_partial[B][MDIE_UPSAMPLE_POOL_SLABS][2][C] receives per-slab channel sums and maxima (fp32). */
-#define MDIE_UPSAMPLE_POOL_SLABS 32
+ * pool_partial[B][pool_slabs][2][C] receives per-slab channel sums and maxima (fp32); pool_slabs in [1, 256] is the
+ * number of workgroups per image.  mdie_pool_slabs(H_out, W_out) is what the engine uses: a function of the
+ * resolution ONLY (32, or 128 from 256x256 maps up), never of the batch size, so that the fp32 summation order -- and
+ * with it every output bit -- of an image does not depend on which batch it is in. */
+#define MDIE_POOL_SLABS_MAX 256
+int mdie_pool_slabs(int H_out, int W_out);
 int mdie_upsample2x_add_pool(int dtype, int B, int H, int W, int C, const void* lo, int lo_stride,
-                             const void* skip, int skip_stride, void* out, int out_stride, float* pool_partial, void* stream);
+                             const void* skip, int skip_stride, void* out, int out_stride, float* pool_partial,
+                             int pool_slabs, void* stream);
 
 /* Same, for the last decoder stage where the skip is the network input itself (`torch.add(out, x)`,
  * models/cdan.py:153-154): lo NHWC [B,H,W,lo_stride] (channels 0..2), x fp32 NCHW [B,3,2H,2W],

@@ -12,7 +12,9 @@ namespace mdie {
 
 constexpr int CB_THREADS = 256;
 constexpr int POOL_MIN_SLAB = 128;  // pixels per pool block (at least)
-constexpr int POOL_MAX_SLABS = 16; // partials per image the gate kernel has to fold
+// partials per image the gate has to fold: a function of the resolution only (never of B: an image's fp32 summation
+// order, hence its output bits, must not depend on its batch)
+static int pool_max_slabs(int H, int W) { return (long)H * W >= 16384 ? 64 : 16; }
 
 struct CbamArgs {
   int B, H, W, C;
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_spatial_kernel(const CbamArgs
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static int nslab_for(int H, int W) { const int n = cdiv(H * W, POOL_MIN_SLAB); return n < POOL_MAX_SLABS ? n : POOL_MAX_SLABS; }
+static int nslab_for(int H, int W) { const int n = cdiv(H * W, POOL_MIN_SLAB), m = pool_max_slabs(H, W); return n < m ? n : m; }
 
 template <typename T>
 static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
@@ -290,7 +292,8 @@ static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
     int gx = cdiv(d->H * d->W, groups * 4);
     // every block re-derives the gate: keep the block count per image moderate for the wide tensors, whose MLP
     // weights are 32-128 KB (L2 reads per block)
-    const int cap = d->C >= 256 ? 16 : 64;
+    int cap = d->C >= 256 ? 16 : 64;
+    if (cap < 1024 / d->B) cap = 1024 / d->B;   // small batches: more blocks per image
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     TimedLaunch tl(MDIE_K_CBAM_CHANPOOL);
@@ -320,7 +323,7 @@ static int check_cbam(const mdie_cbam_desc* d) {
   MDIE_REQUIRE(d->x && d->out && d->w1 && d->b1 && d->w2 && d->b2 && d->w7 && d->bn && d->workspace, "mdie_cbam_fwd: null pointer");
   MDIE_REQUIRE(d->x_stride % 16 == 0 && d->out_stride % 16 == 0 && (!d->mul || d->mul_stride % 16 == 0), "mdie_cbam_fwd: strides must be multiples of 16");
   MDIE_REQUIRE(((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->out & 15) == 0 && ((uintptr_t)d->mul & 15) == 0, "mdie_cbam_fwd: alignment");
-  MDIE_REQUIRE(!d->pool_partial || (d->pool_slabs >= 1 && d->pool_slabs <= 64), "mdie_cbam_fwd: pool_slabs %d", d->pool_slabs);
+  MDIE_REQUIRE(!d->pool_partial || (d->pool_slabs >= 1 && d->pool_slabs <= MDIE_POOL_SLABS_MAX), "mdie_cbam_fwd: pool_slabs %d", d->pool_slabs);
   if (d->workspace_bytes < mdie_cbam_workspace_bytes(d->B, d->H, d->W, d->C)) {
     set_error("mdie_cbam_fwd: workspace %zu < %zu", d->workspace_bytes, mdie_cbam_workspace_bytes(d->B, d->H, d->W, d->C));
     return MDIE_ENOSPC;

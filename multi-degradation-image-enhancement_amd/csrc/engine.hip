@@ -206,7 +206,7 @@ struct Buf { size_t off; int C; };  // NHWC, stride == C
 struct Plan {
   Buf x16, o[3], g[3][4], d[3], e, bott, t1, u1, t2lo, t2, u2, t3lo, t3, u3, t4lo, t4, fg[4], out16;
   size_t cbam_ws, cbam_ws_bytes;
-  size_t pool_ws;   // [B][MDIE_UPSAMPLE_POOL_SLABS][2][128] floats: pooled partials written by upsample+skip
+  size_t pool_ws;   // [B][<= 128 slabs][2][128] floats: pooled partials written by upsample+skip
   size_t total;
 };
 
@@ -235,7 +235,7 @@ static Plan make_plan(int dtype, int B, int H, int W) {
   const int ch[4] = {512, 256, 128, 64}, chh[4] = {h3, h3, h2, h1}, cww[4] = {w3, w3, w2, w1};
   for (int i = 0; i < 4; ++i) { size_t b = mdie_cbam_workspace_bytes(B, chh[i], cww[i], ch[i]); cb = b > cb ? b : cb; }
   P.cbam_ws = off; P.cbam_ws_bytes = cb; off += align256(cb);
-  P.pool_ws = off; off += align256((size_t)B * MDIE_UPSAMPLE_POOL_SLABS * 2 * 128 * sizeof(float));
+  P.pool_ws = off; off += align256((size_t)B * 128 * 2 * 128 * sizeof(float));
   P.total = off;
   return P;
 }
@@ -442,14 +442,14 @@ static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, con
   if (mul) { d.mul = c.ws + mul->off; d.mul_stride = mul->C; }
   d.out = c.ws + out.off; d.out_stride = out.C;
   d.workspace = c.ws + P.cbam_ws; d.workspace_bytes = P.cbam_ws_bytes;
-  if (pooled) { d.pool_partial = reinterpret_cast<const float*>(c.ws + P.pool_ws); d.pool_slabs = MDIE_UPSAMPLE_POOL_SLABS; }
+  if (pooled) { d.pool_partial = reinterpret_cast<const float*>(c.ws + P.pool_ws); d.pool_slabs = mdie_pool_slabs(H, W); }
   return mdie_cbam_fwd(&d, c.stream);
 }
 
 static int run_up(const Ctx& c, const Plan& P, int H, int W, const Buf& lo, const Buf& skip, const Buf& out) {
   // the upsampled + skip tensor feeds a CBAM: reduce it for the channel gate while writing it
   return mdie_upsample2x_add_pool(c.dtype, c.B, H, W, lo.C, c.ws + lo.off, lo.C, c.ws + skip.off, skip.C, c.ws + out.off, out.C,
-                                  reinterpret_cast<float*>(c.ws + P.pool_ws), c.stream);
+                                  reinterpret_cast<float*>(c.ws + P.pool_ws), mdie_pool_slabs(2 * H, 2 * W), c.stream);
 }
 
 static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {

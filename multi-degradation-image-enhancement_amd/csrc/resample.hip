@@ -241,10 +241,13 @@ extern "C" int mdie_upsample2x_add(int dtype, int B, int H, int W, int C, const 
   return MDIE_OK;
 }
 
+extern "C" int mdie_pool_slabs(int H_out, int W_out) { return (long)H_out * W_out >= 65536 ? 128 : 32; }
+
 extern "C" int mdie_upsample2x_add_pool(int dtype, int B, int H, int W, int C, const void* lo, int lo_stride, const void* skip,
-                                        int skip_stride, void* out, int out_stride, float* pool_partial, void* stream) {
+                                        int skip_stride, void* out, int out_stride, float* pool_partial, int pool_slabs, void* stream) {
   if (int e = check_layout("mdie_upsample2x_add_pool", dtype, B, C, H, W, lo, out)) return e;
   MDIE_REQUIRE(skip != nullptr && pool_partial != nullptr, "mdie_upsample2x_add_pool: null skip / pool_partial");
+  MDIE_REQUIRE(pool_slabs >= 1 && pool_slabs <= MDIE_POOL_SLABS_MAX, "mdie_upsample2x_add_pool: pool_slabs %d", pool_slabs);
   MDIE_REQUIRE(C % 16 == 0 && C <= 512 && (C & (C - 1)) == 0 && lo_stride % 16 == 0 && skip_stride % 16 == 0 && out_stride % 16 == 0,
                "mdie_upsample2x_add_pool: C must be a power of two <= 512, strides multiples of 16");
   MDIE_REQUIRE((((uintptr_t)lo | (uintptr_t)skip | (uintptr_t)out) & 15) == 0, "mdie_upsample2x_add_pool: alignment");
@@ -253,7 +256,7 @@ extern "C" int mdie_upsample2x_add_pool(int dtype, int B, int H, int W, int C, c
   const int rows = RS_THREADS / (C / vec);
   const size_t lds = (size_t)2 * rows * C * sizeof(float);
   TimedLaunch tl(MDIE_K_UPSAMPLE);
-  const dim3 grid(MDIE_UPSAMPLE_POOL_SLABS, B);
+  const dim3 grid(pool_slabs, B);
   if (dtype == MDIE_F32)
     hipLaunchKernelGGL((upsample2x_add_pool_kernel<float>), grid, dim3(RS_THREADS), lds, s, H, W, C, (const char*)lo, lo_stride, (const char*)skip,
                        skip_stride, (char*)out, out_stride, pool_partial);

@@ -299,9 +299,11 @@ def test_up2_add_with_fused_pool(E, L):
         skip = torch.randn(2, 12, 20, 64, generator=g).cuda().to(td)
         ref = E.upsample2x_add(lo, skip, dtype=dt)
         out = torch.empty_like(skip)
-        part = torch.zeros(2, 32, 2, 64, device="cuda")
+        slabs = L.lib.mdie_pool_slabs(12, 20)
+        assert slabs == 32 and L.lib.mdie_pool_slabs(512, 512) == 128
+        part = torch.zeros(2, slabs, 2, 64, device="cuda")
         L.check(L.lib.mdie_upsample2x_add_pool(dt, 2, 6, 10, 64, lo.data_ptr(), 64, skip.data_ptr(), 64, out.data_ptr(), 64,
-                                               part.data_ptr(), None), "mdie_upsample2x_add_pool")
+                                               part.data_ptr(), slabs, None), "mdie_upsample2x_add_pool")
         # same formula, separately compiled: FMA contraction may differ by an ulp
         assert torch.allclose(out.float(), ref.float(), rtol=1e-2 if dt == L.BF16 else 1e-6, atol=1e-6)
         o = out.float().reshape(2, -1, 64)
