@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 12
+#define MDIE_ABI_VERSION 13
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -87,6 +87,8 @@ typedef struct {
   int out_stride;
   float* out_nchw3;        /* optional: instead of `out`, write output channels 0..2 as fp32 NCHW [B,3,Ho,Wo]
                               (the network's final tensor, models/cdan.py:157); cout must be 16 */
+  int residual_pre_act;    /* 0: out = act(conv*s+b) + residual (CDAN decoder, models/cdan.py:130);
+                              1: out = act(conv*s+b + residual) (ResNet BasicBlock of the router) */
 } mdie_conv_desc;
 
 int mdie_conv_fwd(const mdie_conv_desc* d, void* stream);
@@ -438,6 +440,31 @@ typedef struct {
 size_t mdie_cbam_train_workspace_bytes(int B, int H, int W, int C);
 int mdie_cbam_train_fwd(const mdie_cbam_train_desc* d, void* stream);
 int mdie_cbam_train_bwd(const mdie_cbam_train_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Degradation classifier (router) pieces, classification/train_multilabel_classifier.py:117-131 -- a torchvision
+ * ResNet18 backbone with two nn.Linear heads.  BasicBlock convolutions run on mdie_conv_fwd (BatchNorm folded,
+ * identity branch as `residual` with residual_pre_act = 1); stride-2 convolutions as stride-1 + mdie_subsample2.
+ * --------------------------------------------------------------------------------- */
+/* relu(bn(conv7x7/s2/p3(normalise(x)))): x fp32 NCHW [B,3,H,W]; mean3/std3 HOST float[3] (NULL = no normalisation,
+ * :760 uses the ImageNet constants); weight packed by mdie_pack_stem7_weight from [64][3][7][7]; out NHWC
+ * [B, ceil(H/2), ceil(W/2), 64]. */
+size_t mdie_stem7_weight_bytes(int dtype);
+int mdie_pack_stem7_weight(int dtype, const float* w, void* dst);
+int mdie_stem7_fwd(int dtype, int B, int H, int W, const float* x_nchw, const float* mean3, const float* std3,
+                   const void* weight, const float* post_scale, const float* post_shift, void* out, int out_stride,
+                   void* stream);
+/* nn.MaxPool2d(3, stride 2, padding 1): [B,H,W,C] -> [B,ceil(H/2),ceil(W/2),C] */
+int mdie_maxpool3x3s2(int dtype, int B, int H, int W, int C, const void* in, int in_stride, void* out, int out_stride,
+                      void* stream);
+/* out[b,y,x,:] = in[b,2y,2x,:] */
+int mdie_subsample2(int dtype, int B, int H, int W, int C, const void* in, int in_stride, void* out, int out_stride,
+                    void* stream);
+/* AdaptiveAvgPool2d(1) + head_cls / head_sev (weights [ncls][C] fp32) + sigmoid -> prob_cls, sev: [B][ncls];
+ * feat (nullable): [B][C] pooled features */
+int mdie_avgpool_heads(int dtype, int B, int H, int W, int C, const void* x, int stride, const float* w_cls,
+                       const float* b_cls, const float* w_sev, const float* b_sev, int ncls, float* feat,
+                       float* prob_cls, float* sev, void* stream);
 
 /* Training loss, value and gradient in one call (utils/loss_factory.py:146-230; models/model.py:161-164 evaluates the
  * pipeline and calls backward on it every step).  Terms that need downloaded networks (vgg_perceptual, lpips) are

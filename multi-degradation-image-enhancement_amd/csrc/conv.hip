@@ -22,6 +22,7 @@
 // 4 adjacent lanes (max-pool = two lane swaps in the epilogue).
 // The input is a list of channel segments (mdie_seg): a DenseBlock's torch.cat is never built.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.hpp"
 
@@ -46,6 +47,7 @@ struct EpiArgs {
   char* out;
   int out_stride;
   float* nchw3;  // optional fp32 NCHW [B,3,Ho,Wo] destination for output channels 0..2
+  int res_pre;   // residual is added BEFORE the activation (ResNet BasicBlock) instead of after it (CDAN decoder)
 };
 
 struct ConvArgs {
@@ -116,10 +118,22 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
     for (int cs = 0; cs < NCS; ++cs) {
       const float4 sc = esc[cs], sh = esh[cs];
       float v[4];
-      v[0] = act_fn<ACT>(fmaf(acc[cs][ps][0], sc.x, sh.x));
-      v[1] = act_fn<ACT>(fmaf(acc[cs][ps][1], sc.y, sh.y));
-      v[2] = act_fn<ACT>(fmaf(acc[cs][ps][2], sc.z, sh.z));
-      v[3] = act_fn<ACT>(fmaf(acc[cs][ps][3], sc.w, sh.w));
+      if (e.res_pre) {   // launch-uniform: y = act(conv * scale + shift + residual)
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rrow && inside) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) r[i] = ld(rrow + cs * 16 + i);
+        }
+        v[0] = act_fn<ACT>(fmaf(acc[cs][ps][0], sc.x, sh.x) + r[0]);
+        v[1] = act_fn<ACT>(fmaf(acc[cs][ps][1], sc.y, sh.y) + r[1]);
+        v[2] = act_fn<ACT>(fmaf(acc[cs][ps][2], sc.z, sh.z) + r[2]);
+        v[3] = act_fn<ACT>(fmaf(acc[cs][ps][3], sc.w, sh.w) + r[3]);
+      } else {
+        v[0] = act_fn<ACT>(fmaf(acc[cs][ps][0], sc.x, sh.x));
+        v[1] = act_fn<ACT>(fmaf(acc[cs][ps][1], sc.y, sh.y));
+        v[2] = act_fn<ACT>(fmaf(acc[cs][ps][2], sc.z, sh.z));
+        v[3] = act_fn<ACT>(fmaf(acc[cs][ps][3], sc.w, sh.w));
+      }
       if constexpr (POOL) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = quad_max(v[i]);
@@ -136,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
 #else
       if (writer) {
 #endif
-        if (rrow) {
+        if (rrow && !e.res_pre) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] += ld(rrow + cs * 16 + i);
         }
@@ -835,6 +849,7 @@ static void fill_epi(EpiArgs& e, int H, int W, const float* sc, const float* sh,
   e.residual = reinterpret_cast<const char*>(res); e.res_stride = res_stride;
   e.out = reinterpret_cast<char*>(out); e.out_stride = out_stride;
   e.nchw3 = nchw3;
+  e.res_pre = 0;
 }
 
 template <typename T>
@@ -859,6 +874,7 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift;
   a.weight = reinterpret_cast<const char*>(d->weight);
   fill_epi(a.e, d->H, d->W, d->post_scale, d->post_shift, d->act, d->pool, d->residual, d->res_stride, d->out, d->out_stride, d->out_nchw3);
+  a.e.res_pre = d->residual_pre_act ? 1 : 0;
   const int bn = (d->cout % 64 == 0) ? 64 : 16;
   a.n_tiles = d->cout / bn;
   // Small feature maps (32x32, 64x64 at the network's deep end) do not fill 256 CUs with 16x16 tiles:
@@ -878,6 +894,107 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   }
   if (bn == 64) return small ? launch_conv<T, 1, 64, 8>(a, stream) : launch_conv<T, 1, 64, 16>(a, stream);
   return small ? launch_conv<T, 1, 16, 8>(a, stream) : launch_conv<T, 1, 16, 16>(a, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Router stem: conv7x7 / stride 2 / pad 3 (3 -> 64) + BN + ReLU of the ResNet18 backbone behind the degradation
+// classifier (classification/train_multilabel_classifier.py:117-131), straight from the fp32 NCHW image with the
+// ImageNet normalisation (:760) applied while staging.  Same scheme as conv_first_kernel: the 37x37 input patch of a
+// 16x16 output tile sits in LDS as [pixel][4], K = 147 (tap*3 + c) is im2col'ed into 5 32-deep bf16 MFMA steps
+// (10 16-deep f32 steps), each lane gathering its (tap, channel) operands at stride-2 pixel addresses.
+// ---------------------------------------------------------------------------------------------------------------
+struct StemArgs {
+  int B, H, W;          // input extent; output is ceil(H/2) x ceil(W/2) (e.H, e.W)
+  int tiles_x, tiles_y;
+  const float* x;       // NCHW fp32 [B,3,H,W]
+  const char* weight;   // [step][64][64 B], k = (kh*7 + kw)*3 + c, zero beyond 147
+  float mean[3], inv_std[3];
+  EpiArgs e;
+};
+
+template <typename T>
+__global__ __launch_bounds__(CONV_THREADS) void stem7_kernel(const StemArgs a) {
+  constexpr int TILE = 16, PW = 2 * TILE + 5;   // 37
+  constexpr int E = sizeof(T);
+  constexpr int NCS = 4, NPS = 4;
+  constexpr int KPL = 16 / E;                   // K elements per lane per step
+  constexpr int STEPS = 160 / (4 * KPL);        // 5 (bf16) / 10 (f32)
+  __shared__ __attribute__((aligned(16))) T patch[PW * PW * 4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lp = lane & 15;
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+  const int img = bid;
+  const int y0 = ty * TILE, x0 = tx * TILE;
+
+  float4 esc[NCS], esh[NCS];
+#pragma unroll
+  for (int cs = 0; cs < NCS; ++cs) {
+    esc[cs] = *reinterpret_cast<const float4*>(a.e.post_scale + cs * 16 + lq * 4);
+    esh[cs] = *reinterpret_cast<const float4*>(a.e.post_shift + cs * 16 + lq * 4);
+  }
+  const size_t plane = (size_t)a.H * a.W;
+  for (int p = tid; p < PW * PW; p += CONV_THREADS) {
+    const int py = p / PW, px = p - py * PW;
+    const int gy = 2 * y0 + py - 3, gx = 2 * x0 + px - 3;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;       // zero padding of the NORMALISED image
+    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+      const float* xp = a.x + (size_t)img * 3 * plane + (size_t)gy * a.W + gx;
+      v0 = (xp[0] - a.mean[0]) * a.inv_std[0]; v1 = (xp[plane] - a.mean[1]) * a.inv_std[1]; v2 = (xp[2 * plane] - a.mean[2]) * a.inv_std[2];
+    }
+    T* d = patch + p * 4;
+    if constexpr (E == 2) *reinterpret_cast<uint2*>(d) = make_uint2(bf_pack(v0, v1), bf_pack(v2, 0.f));
+    else *reinterpret_cast<float4*>(d) = make_float4(v0, v1, v2, 0.f);
+  }
+  __syncthreads();
+
+  const T* base[NPS];
+#pragma unroll
+  for (int ps = 0; ps < NPS; ++ps) {
+    int y, x;
+    tile_pixel<TILE>(wave * NPS + ps, lp, y, x);
+    base[ps] = patch + (2 * y * PW + 2 * x) * 4;
+  }
+  f32x4 acc[NCS][NPS];
+#pragma unroll
+  for (int i = 0; i < NCS; ++i)
+#pragma unroll
+    for (int j = 0; j < NPS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    uint4 wf[NCS];
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs)
+      wf[cs] = *reinterpret_cast<const uint4*>(a.weight + ((size_t)s * 64 + cs * 16 + lp) * 64 + lq * 16);
+    int goff[KPL];
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+      const int k = s * 4 * KPL + lq * KPL + i;
+      const int tap = k / 3, c = k - tap * 3;
+      const int kh = tap / 7, kw = tap - kh * 7;
+      goff[i] = k < 147 ? (kh * PW + kw) * 4 + c : 0;    // beyond K the weights are zero: any valid address
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      uint4 xf;
+      if constexpr (E == 2) {
+        uint32_t h[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = *reinterpret_cast<const unsigned short*>(base[ps] + goff[i]);
+        xf = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+      } else {
+        uint32_t h[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = *reinterpret_cast<const uint32_t*>(base[ps] + goff[i]);
+        xf = make_uint4(h[0], h[1], h[2], h[3]);
+      }
+#pragma unroll
+      for (int cs = 0; cs < NCS; ++cs) acc[cs][ps] = mma16<T>(wf[cs], xf, acc[cs][ps]);
+    }
+  }
+  conv_epilogue<T, NCS, NPS, TILE>(a.e, esc, esh, acc, img, y0, x0, 0, wave * NPS, lq, lp);
 }
 
 template <typename T>
@@ -932,4 +1049,50 @@ extern "C" int mdie_conv_first_fwd(const mdie_conv_first_desc* d, void* stream) 
   MDIE_REQUIRE(((uintptr_t)d->out & 15) == 0 && ((uintptr_t)d->weight & 15) == 0, "mdie_conv_first_fwd: out/weight alignment");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return d->dtype == MDIE_F32 ? dispatch_first<float>(d, s) : dispatch_first<mdie::bf16>(d, s);
+}
+
+extern "C" size_t mdie_stem7_weight_bytes(int dtype) { return (dtype == MDIE_F32 || dtype == MDIE_BF16) ? (size_t)(160 / (dtype == MDIE_F32 ? 16 : 32)) * 64 * 64 : 0; }
+
+extern "C" int mdie_pack_stem7_weight(int dtype, const float* w, void* dst) {
+  using namespace mdie;
+  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_pack_stem7_weight: bad dtype %d", dtype);
+  MDIE_REQUIRE(w && dst, "mdie_pack_stem7_weight: null pointer");
+  // w: [64][3][7][7] (torchvision resnet conv1).  dst[step][cout][kl], k = step * KS + kl = (kh*7 + kw)*3 + c
+  const int KS = dtype == MDIE_F32 ? 16 : 32, steps = 160 / KS;
+  for (int s = 0; s < steps; ++s)
+    for (int o = 0; o < 64; ++o)
+      for (int kl = 0; kl < KS; ++kl) {
+        const int k = s * KS + kl;
+        float v = 0.f;
+        if (k < 147) { const int tap = k / 3, c = k % 3; v = w[((o * 3 + c) * 7 + tap / 7) * 7 + tap % 7]; }
+        const size_t idx = ((size_t)s * 64 + o) * KS + kl;
+        if (dtype == MDIE_F32) reinterpret_cast<float*>(dst)[idx] = v;
+        else {   // round to nearest even, as the device conversion does
+          uint32_t u; memcpy(&u, &v, 4);
+          u += 0x7fffu + ((u >> 16) & 1u);
+          reinterpret_cast<uint16_t*>(dst)[idx] = (uint16_t)(u >> 16);
+        }
+      }
+  return MDIE_OK;
+}
+
+extern "C" int mdie_stem7_fwd(int dtype, int B, int H, int W, const float* x_nchw, const float* mean3, const float* std3, const void* weight,
+                              const float* post_scale, const float* post_shift, void* out, int out_stride, void* stream) {
+  using namespace mdie;
+  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_stem7_fwd: bad dtype %d", dtype);
+  MDIE_REQUIRE(B > 0 && H > 0 && W > 0 && x_nchw && weight && post_scale && post_shift && out, "mdie_stem7_fwd: bad argument");
+  MDIE_REQUIRE(out_stride >= 64 && out_stride % 4 == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)weight & 15) == 0, "mdie_stem7_fwd: out_stride / alignment");
+  StemArgs a{};
+  a.B = B; a.H = H; a.W = W;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  a.tiles_x = cdiv(Wo, 16); a.tiles_y = cdiv(Ho, 16);
+  a.x = x_nchw; a.weight = reinterpret_cast<const char*>(weight);
+  for (int c = 0; c < 3; ++c) { a.mean[c] = mean3 ? mean3[c] : 0.f; a.inv_std[c] = std3 ? 1.0f / std3[c] : 1.f; }
+  fill_epi(a.e, Ho, Wo, post_scale, post_shift, MDIE_ACT_RELU, 0, nullptr, 0, out, out_stride);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int grid = a.tiles_x * a.tiles_y * B;
+  if (dtype == MDIE_F32) hipLaunchKernelGGL((stem7_kernel<float>), dim3(grid), dim3(CONV_THREADS), 0, s, a);
+  else hipLaunchKernelGGL((stem7_kernel<mdie::bf16>), dim3(grid), dim3(CONV_THREADS), 0, s, a);
+  MDIE_LAUNCH_CHECK("mdie_stem7_fwd");
+  return MDIE_OK;
 }

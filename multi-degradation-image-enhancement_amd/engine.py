@@ -163,7 +163,7 @@ class RoutedEngine:
         labels = list(labels)
         if x.dim() != 4 or x.shape[1] != 3 or len(labels) != x.shape[0]:
             raise L.MdieError(f"RoutedEngine.forward: input {tuple(x.shape)} with {len(labels)} labels")
-        missing = sorted({str(t) for t in labels if t not in self.blobs})
+        missing = sorted({str(t) for t in labels if t is not None and t not in self.blobs})
         if missing:
             raise L.MdieError(f"RoutedEngine.forward: no weights loaded for task(s) {missing}")
         B, _, H, W = x.shape
@@ -193,6 +193,10 @@ class RoutedEngine:
             fork.record(main)
             off = 0
             for (a, b, task), n, st in zip(groups, sizes, self._streams):
+                if task is None:                     # the router found no degradation: the image passes through unchanged
+                    ys[a:b].copy_(xs[a:b])
+                    off += n
+                    continue
                 st.wait_event(fork)
                 d = L.CdanFwdDesc()
                 d.dtype, d.B, d.H, d.W = self.dtype, b - a, H, W
@@ -242,7 +246,7 @@ def pack_conv_weight(w, dtype, transposed=False, cout_stored=None, cin_stored=No
 
 
 def conv_fwd(segments, weight_packed, post_scale, post_shift, *, dtype, ksize, cout, act=L.ACT_NONE, pool=False,
-             pre_scale=None, pre_shift=None, residual=None, out=None, out_view=None):
+             pre_scale=None, pre_shift=None, residual=None, out=None, out_view=None, residual_pre_act=False):
     """segments: list of NHWC tensors [B,H,W,Ci] (Ci % 16 == 0).  Returns NHWC [B,Ho,Wo,cout]."""
     x0 = segments[0]
     B, H, W, _ = x0.shape
@@ -265,6 +269,7 @@ def conv_fwd(segments, weight_packed, post_scale, post_shift, *, dtype, ksize, c
     target = out_view if out_view is not None else out
     d.out, d.out_stride = target.data_ptr(), target.stride(2)
     d.out_nchw3 = None
+    d.residual_pre_act = int(residual_pre_act)
     L.check(L.lib.mdie_conv_fwd(C.byref(d), _stream_ptr(x0.device)), "mdie_conv_fwd")
     return out
 

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 12
+ABI_VERSION = 13
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 LOSS_KINDS = {"mse": 0, "l1": 1, "charbonnier": 2, "ssim": 3, "gradient_l1": 4}
@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
                 ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("weight", C.c_void_p),
                 ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int), ("pool", C.c_int),
                 ("residual", C.c_void_p), ("res_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int),
-                ("out_nchw3", C.c_void_p)]
+                ("out_nchw3", C.c_void_p), ("residual_pre_act", C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -195,6 +195,14 @@ SIGNATURES = {
     "mdie_cbam_train_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mdie_cbam_train_fwd": (C.c_int, [C.POINTER(CbamTrainDesc), C.c_void_p]),
     "mdie_cbam_train_bwd": (C.c_int, [C.POINTER(CbamTrainDesc), C.c_void_p]),
+    "mdie_stem7_weight_bytes": (C.c_size_t, [C.c_int]),
+    "mdie_pack_stem7_weight": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "mdie_stem7_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int, C.c_void_p]),
+    "mdie_maxpool3x3s2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mdie_subsample2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mdie_avgpool_heads": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdie_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mdie_loss_fwd_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(LossTerm), C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -897,3 +897,66 @@ def test_registered_torch_ops_match_direct_calls(E, net):
     via_op = torch.ops.mdie.cdan_forward(x, eng.params, eng._workspace(2, 32, 32), eng.dtype, 0, 0)
     assert torch.equal(via_op, direct) and torch.equal(net(x), direct)
     assert torch.equal(torch.ops.mdie.psnr_ssim(direct, t), PL.psnr_ssim(direct, t))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# degradation classifier / router: HIP ResNet18 + heads vs the CPU oracle, seeded random parameters
+# ---------------------------------------------------------------------------------------------------------------------
+def _router_state_dict(seed=7):
+    from mdie_amd import router as R
+    from oracle import params as P
+    return P.fill_spec(R.router_param_spec(), seed, randomize_bn=True)
+
+
+@pytest.mark.parametrize("precision,hw,tol", [("fp32", (64, 96), 1e-3), ("fp32", (72, 100), 1e-3), ("bf16", (64, 96), 3e-2)])
+def test_router_forward_matches_oracle(E, precision, hw, tol):
+    from mdie_amd import router as R
+    from oracle import router_oracle as RO
+    sd = _router_state_dict()
+    g = torch.Generator().manual_seed(hw[0])
+    x = torch.rand(3, 3, *hw, generator=g)
+    with torch.no_grad():
+        rp, rs = RO.classifier_forward({k: v.double() for k, v in sd.items() if v.is_floating_point()}, x.double())
+    router = R.DegradationRouter("cuda", precision).load(sd)
+    p, s = router.forward(x.cuda())
+    assert (p.cpu().double() - rp).abs().max().item() <= tol and (s.cpu().double() - rs).abs().max().item() <= tol
+
+
+def test_router_checkpoint_format_thresholds_and_routing(E, tmp_path):
+    """the reference's checkpoint dict (:860-871) and threshold report (:295-304) drive routing; labels feed RoutedEngine"""
+    import json as _json
+    from mdie_amd import router as R
+    from oracle import params as P
+    from oracle import router_oracle as RO
+    sd = _router_state_dict(9)
+    ckpt = {"model_state": sd, "classes": list(R.CLASSES), "default_thresh": 0.5, "normalize": True,
+            "imagenet_mean": list(R.IMAGENET_MEAN), "imagenet_std": list(R.IMAGENET_STD), "epoch": 3}
+    router = R.DegradationRouter("cuda", "fp32").load(ckpt)
+    x, _ = P.lowlight_batch(21, 6, 64, 64)
+    probs, _ = router.forward(x.cuda())
+    # thresholds chosen from the observed probabilities so that some images route and some pass through
+    pc = probs.cpu()
+    thr = {c: float(pc[:, i].median()) + 0.02 for i, c in enumerate(R.CLASSES)}
+    path = os.path.join(str(tmp_path), "thresholds_val.json")
+    with open(path, "w") as fh:
+        _json.dump({"objective": "test", "thresholds": thr}, fh)
+    router.load_thresholds(path)
+    labels, _ = router.route(x.cuda())
+    with torch.no_grad():
+        rp, _ = RO.classifier_forward(sd, x)
+    assert labels == RO.route(rp, [thr[c] for c in R.CLASSES], list(R.CLASSES))
+    # end to end: routed enhancement with pass-through for undetected images
+    routed = E.RoutedEngine("cuda", "bf16")
+    for i, c in enumerate(R.CLASSES):
+        if c in labels:
+            routed.load_task(c, P.make_state_dict(200 + i))
+    y = routed.forward(x.cuda(), labels)
+    for i, t in enumerate(labels):
+        if t is None:
+            assert torch.equal(y[i], x[i].cuda())
+        else:
+            assert not torch.equal(y[i], x[i].cuda())
+    with pytest.raises(Exception):
+        R.DegradationRouter("cuda").load({k: v for k, v in sd.items() if "layer3" not in k})
+    with pytest.raises(Exception):
+        router.forward(x)                        # CPU tensor

@@ -33,6 +33,12 @@ if what == "routed":
     x = x.cuda()
     g = torch.Generator().manual_seed(0)
     labels = [tasks[i] for i in torch.randint(0, len(tasks), (32,), generator=g).tolist()]     # stub router
+    # the classifier itself (seeded random parameters: no ImageNet / trained weights offline); its labels are not used for
+    # the timing below (random weights put every image in one class), only its cost is reported
+    from mdie_amd import router as R
+    router = R.DegradationRouter("cuda", prec).load(P.fill_spec(R.router_param_spec(), 7, randomize_bn=True))
+    dtr = timed(lambda: router.forward(x))
+    print(f"router[{prec}] ResNet18 + 2 heads, B=32 256x256: {dtr*1e3:.2f} ms/batch = {32/dtr:.0f} img/s")
     dt = timed(lambda: eng.forward(x, labels))
     one = E.CdanEngine("cuda", prec).load(P.make_state_dict(100))
     dt1 = timed(lambda: one.forward(x))
