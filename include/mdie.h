@@ -87,8 +87,6 @@ typedef struct {
   int out_stride;
   float* out_nchw3;        /* optional: instead of `out`, write output channels 0..2 as fp32 NCHW [B,3,Ho,Wo]
                               (the network's final tensor, models/cdan.py:157); cout must be 16 */
-  int residual_pre_act;    /* 0: out = act(conv*s+b) + residual (CDAN decoder, models/cdan.py:130);
-                              1: out = act(conv*s+b + residual) (ResNet BasicBlock of the router) */
 } mdie_conv_desc;
 
 int mdie_conv_fwd(const mdie_conv_desc* d, void* stream);
@@ -443,8 +441,9 @@ int mdie_cbam_train_bwd(const mdie_cbam_train_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Degradation classifier (router) pieces, classification/train_multilabel_classifier.py:117-131 -- a torchvision
- * ResNet18 backbone with two nn.Linear heads.  BasicBlock convolutions run on mdie_conv_fwd (BatchNorm folded,
- * identity branch as `residual` with residual_pre_act = 1); stride-2 convolutions as stride-1 + mdie_subsample2.
+ * ResNet18 backbone with two nn.Linear heads.  BasicBlock convolutions run on mdie_conv_fwd (BatchNorm folded, identity
+ * branch as `residual` with act = NONE, then mdie_relu_inplace: the hot epilogue adds its residual AFTER the activation,
+ * which is what the CDAN decoder needs); stride-2 convolutions as stride-1 + mdie_subsample2.
  * --------------------------------------------------------------------------------- */
 /* relu(bn(conv7x7/s2/p3(normalise(x)))): x fp32 NCHW [B,3,H,W]; mean3/std3 HOST float[3] (NULL = no normalisation,
  * :760 uses the ImageNet constants); weight packed by mdie_pack_stem7_weight from [64][3][7][7]; out NHWC
@@ -457,6 +456,8 @@ int mdie_stem7_fwd(int dtype, int B, int H, int W, const float* x_nchw, const fl
 /* nn.MaxPool2d(3, stride 2, padding 1): [B,H,W,C] -> [B,ceil(H/2),ceil(W/2),C] */
 int mdie_maxpool3x3s2(int dtype, int B, int H, int W, int C, const void* in, int in_stride, void* out, int out_stride,
                       void* stream);
+/* x = max(x, 0) in place, NHWC [B,H,W,C] with pixel stride */
+int mdie_relu_inplace(int dtype, long npix, int C, void* x, int stride, void* stream);
 /* out[b,y,x,:] = in[b,2y,2x,:] */
 int mdie_subsample2(int dtype, int B, int H, int W, int C, const void* in, int in_stride, void* out, int out_stride,
                     void* stream);

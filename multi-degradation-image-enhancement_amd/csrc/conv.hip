@@ -47,7 +47,6 @@ struct EpiArgs {
   char* out;
   int out_stride;
   float* nchw3;  // optional fp32 NCHW [B,3,Ho,Wo] destination for output channels 0..2
-  int res_pre;   // residual is added BEFORE the activation (ResNet BasicBlock) instead of after it (CDAN decoder)
 };
 
 struct ConvArgs {
@@ -118,22 +117,10 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
     for (int cs = 0; cs < NCS; ++cs) {
       const float4 sc = esc[cs], sh = esh[cs];
       float v[4];
-      if (e.res_pre) {   // launch-uniform: y = act(conv * scale + shift + residual)
-        float r[4] = {0.f, 0.f, 0.f, 0.f};
-        if (rrow && inside) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) r[i] = ld(rrow + cs * 16 + i);
-        }
-        v[0] = act_fn<ACT>(fmaf(acc[cs][ps][0], sc.x, sh.x) + r[0]);
-        v[1] = act_fn<ACT>(fmaf(acc[cs][ps][1], sc.y, sh.y) + r[1]);
-        v[2] = act_fn<ACT>(fmaf(acc[cs][ps][2], sc.z, sh.z) + r[2]);
-        v[3] = act_fn<ACT>(fmaf(acc[cs][ps][3], sc.w, sh.w) + r[3]);
-      } else {
-        v[0] = act_fn<ACT>(fmaf(acc[cs][ps][0], sc.x, sh.x));
-        v[1] = act_fn<ACT>(fmaf(acc[cs][ps][1], sc.y, sh.y));
-        v[2] = act_fn<ACT>(fmaf(acc[cs][ps][2], sc.z, sh.z));
-        v[3] = act_fn<ACT>(fmaf(acc[cs][ps][3], sc.w, sh.w));
-      }
+      v[0] = act_fn<ACT>(fmaf(acc[cs][ps][0], sc.x, sh.x));
+      v[1] = act_fn<ACT>(fmaf(acc[cs][ps][1], sc.y, sh.y));
+      v[2] = act_fn<ACT>(fmaf(acc[cs][ps][2], sc.z, sh.z));
+      v[3] = act_fn<ACT>(fmaf(acc[cs][ps][3], sc.w, sh.w));
       if constexpr (POOL) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = quad_max(v[i]);
@@ -150,7 +137,7 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
 #else
       if (writer) {
 #endif
-        if (rrow && !e.res_pre) {
+        if (rrow) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] += ld(rrow + cs * 16 + i);
         }
@@ -671,6 +658,138 @@ __global__ __launch_bounds__(WS_THREADS, 2) void conv_ws_kernel(const ConvArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions (DenseBlock transitions, models/cdan.py:48-53; ResNet downsample branches): streaming kernel.
+// A 1x1 convolution has no tap reuse, so its activations never need LDS: the MFMA B operand of a lane IS 16
+// contiguous bytes of one pixel (8 bf16 / 4 f32 channels of NHWC), loaded straight from global memory and
+// transformed (pre-activation BN + ReLU) in registers.  The workgroup's weights (its 16*NCS output channels x all K)
+// are staged into LDS ONCE and stay there while the workgroup walks over many pixel tiles: no barrier in the loop.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int NCS, bool PRE>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv1x1_stream_kernel(const ConvArgs a, const int tiles_total) {
+  constexpr int VEC = Traits<T>::VEC, KC = Traits<T>::KC;
+  constexpr int BN = NCS * 16, NPS = 4, TILE = 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_w = smem;                                                        // [nchunk][4][BN][16 B]
+  float* lds_pre = reinterpret_cast<float*>(smem + (size_t)a.nchunk * 4 * BN * 16);   // [2][nchunk * KC]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane >> 4, lp = lane & 15;
+  const int n0 = blockIdx.y * BN;
+  const int kpad = a.nchunk * KC;
+  for (int u = tid; u < a.nchunk * 4 * BN; u += CONV_THREADS) {
+    const int cq = u / BN, n = u - cq * BN;
+    *reinterpret_cast<uint4*>(lds_w + (size_t)u * 16) = *reinterpret_cast<const uint4*>(a.weight + ((size_t)cq * a.cout + n0 + n) * 16);
+  }
+  if (PRE)
+    for (int c = tid; c < kpad; c += CONV_THREADS) {
+      lds_pre[c] = c < a.cin ? a.pre_scale[c] : 0.f;
+      lds_pre[kpad + c] = c < a.cin ? a.pre_shift[c] : 0.f;
+    }
+  float4 esc[NCS], esh[NCS];
+#pragma unroll
+  for (int cs = 0; cs < NCS; ++cs) {
+    esc[cs] = *reinterpret_cast<const float4*>(a.e.post_scale + n0 + cs * 16 + lq * 4);
+    esh[cs] = *reinterpret_cast<const float4*>(a.e.post_shift + n0 + cs * 16 + lq * 4);
+  }
+  __syncthreads();
+
+  const int tpi = a.tiles_x * a.tiles_y;
+  for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+    const int img = tile / tpi;
+    const int trem = tile - img * tpi;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int y0 = ty * TILE, x0 = tx * TILE;
+    int gpix[NPS];
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      int y, x;
+      tile_pixel<TILE>(wave * NPS + ps, lp, y, x);
+      const int gy = y0 + y, gx = x0 + x;
+      gpix[ps] = (gy < a.H && gx < a.W) ? (img * a.H + gy) * a.W + gx : -1;
+    }
+    f32x4 acc[NCS][NPS];
+#pragma unroll
+    for (int i = 0; i < NCS; ++i)
+#pragma unroll
+      for (int j = 0; j < NPS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // raw operands of one chunk: 16 bytes of each of this lane's 4 pixels (software-pipelined one chunk ahead)
+    auto load_chunk = [&](int chunk, uint4 (&xf)[NPS]) {
+      const int c0 = chunk * KC + lq * VEC;        // this lane's first stored channel of the chunk
+      const char* sbase = nullptr;
+      int sstride = 0;
+#pragma unroll
+      for (int k = 0; k < MDIE_MAX_SEG; ++k)
+        if (k < a.nseg && c0 >= a.seg[k].ch_begin && c0 < a.seg[k].ch_end) {
+          sbase = a.seg[k].ptr + (size_t)(c0 - a.seg[k].ch_begin) * sizeof(T);
+          sstride = a.seg[k].stride * (int)sizeof(T);
+        }
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
+        xf[ps] = make_uint4(0, 0, 0, 0);
+        if (sbase && gpix[ps] >= 0) xf[ps] = *reinterpret_cast<const uint4*>(sbase + (size_t)gpix[ps] * sstride);
+      }
+    };
+    uint4 xf[NPS], xn[NPS];
+    load_chunk(0, xf);
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+      if (chunk + 1 < a.nchunk) load_chunk(chunk + 1, xn);      // in flight during this chunk's MFMAs
+      if (PRE) {
+        const int c0 = chunk * KC + lq * VEC;
+        float psc[VEC], psh[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i += 4) {
+          const float4 s4 = *reinterpret_cast<const float4*>(lds_pre + c0 + i), b4 = *reinterpret_cast<const float4*>(lds_pre + kpad + c0 + i);
+          psc[i] = s4.x; psc[i + 1] = s4.y; psc[i + 2] = s4.z; psc[i + 3] = s4.w;
+          psh[i] = b4.x; psh[i + 1] = b4.y; psh[i + 2] = b4.z; psh[i + 3] = b4.w;
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+          float f[VEC];
+          Vec16<T>::unpack(xf[ps], f);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) f[i] = fmaxf(fmaf(f[i], psc[i], psh[i]), 0.0f);
+          xf[ps] = Vec16<T>::pack(f);   // (channels beyond cin have scale = shift = 0 and zero weights)
+        }
+      }
+      uint4 wf[NCS];
+#pragma unroll
+      for (int cs = 0; cs < NCS; ++cs) wf[cs] = *reinterpret_cast<const uint4*>(lds_w + ((size_t)(chunk * 4 + lq) * BN + cs * 16 + lp) * 16);
+#pragma unroll
+      for (int cs = 0; cs < NCS; ++cs)
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) acc[cs][ps] = mma16<T>(wf[cs], xf[ps], acc[cs][ps]);
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) xf[ps] = xn[ps];
+    }
+    conv_epilogue<T, NCS, NPS, TILE>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp);
+  }
+}
+
+template <typename T, int NCS>
+static int launch_conv1x1_stream(ConvArgs& a, hipStream_t stream) {
+  constexpr int KC = Traits<T>::KC;
+  a.tiles_x = cdiv(a.W, 16); a.tiles_y = cdiv(a.H, 16);
+  const int tiles_total = a.tiles_x * a.tiles_y * a.B;
+  const size_t lds = (size_t)a.nchunk * 4 * (NCS * 16) * 16 + (size_t)2 * a.nchunk * KC * sizeof(float);
+  int gx = 512 / a.n_tiles;                     // ~2 resident workgroups per CU, each walking many tiles
+  if (gx < 64) gx = 64;
+  if (gx > tiles_total) gx = tiles_total;
+  const dim3 grid(gx, a.n_tiles);
+  TimedLaunch tl(MDIE_K_CONV1);
+  if (a.pre_scale) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel<T, NCS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+    hipLaunchKernelGGL((conv1x1_stream_kernel<T, NCS, true>), grid, dim3(CONV_THREADS), lds, stream, a, tiles_total);
+  } else {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel<T, NCS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+    hipLaunchKernelGGL((conv1x1_stream_kernel<T, NCS, false>), grid, dim3(CONV_THREADS), lds, stream, a, tiles_total);
+  }
+  MDIE_LAUNCH_CHECK("mdie_conv_fwd");
+  return MDIE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // First layer: conv3x3(3 -> cout) straight from the fp32 NCHW network input (encoder.conv1,
 // models/cdan.py:58,74).  K = 27 is im2col'ed to one 32-deep bf16 MFMA step (two 16-deep f32 steps):
 // 9x less matrix work than padding 3 channels to a 32-channel chunk, and the NCHW->NHWC layout pass
@@ -849,7 +968,6 @@ static void fill_epi(EpiArgs& e, int H, int W, const float* sc, const float* sh,
   e.residual = reinterpret_cast<const char*>(res); e.res_stride = res_stride;
   e.out = reinterpret_cast<char*>(out); e.out_stride = out_stride;
   e.nchw3 = nchw3;
-  e.res_pre = 0;
 }
 
 template <typename T>
@@ -874,7 +992,6 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift;
   a.weight = reinterpret_cast<const char*>(d->weight);
   fill_epi(a.e, d->H, d->W, d->post_scale, d->post_shift, d->act, d->pool, d->residual, d->res_stride, d->out, d->out_stride, d->out_nchw3);
-  a.e.res_pre = d->residual_pre_act ? 1 : 0;
   const int bn = (d->cout % 64 == 0) ? 64 : 16;
   a.n_tiles = d->cout / bn;
   // Small feature maps (32x32, 64x64 at the network's deep end) do not fill 256 CUs with 16x16 tiles:
@@ -888,6 +1005,12 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
     if (d->ksize == 3) return bn == 64 ? launch_conv_ws<T, 3, 64, 16>(a, stream) : launch_conv_ws<T, 3, 16, 16>(a, stream);
     return bn == 64 ? launch_conv_ws<T, 1, 64, 16>(a, stream) : launch_conv_ws<T, 1, 16, 16>(a, stream);
   }
+  static const int no_stream = getenv("MDIE_CONV1_STREAM") ? !atoi(getenv("MDIE_CONV1_STREAM")) : 0;   // experiments: 0 = staged kernel
+  // (64-wide output tiles only: with 16 outputs there are 4 MFMAs per 4 loads and the staged kernel is faster -- measured
+  //  final.tr 85 us staged vs 92 us streaming, dense1.tr 58 us staged vs 47 us streaming, B=32 256x256 bf16)
+  if (d->ksize == 1 && !d->pool && !no_stream && bn == 64 &&
+      (size_t)a.nchunk * 4 * bn * 16 + (size_t)2 * a.nchunk * KC * sizeof(float) <= 96 * 1024)
+    return launch_conv1x1_stream<T, 4>(a, stream);
   if (d->ksize == 3) {
     if (bn == 64) return small ? launch_conv<T, 3, 64, 8>(a, stream) : launch_conv<T, 3, 64, 16>(a, stream);
     return small ? launch_conv<T, 3, 16, 8>(a, stream) : launch_conv<T, 3, 16, 16>(a, stream);

@@ -1,7 +1,8 @@
 // The pieces of the degradation classifier (ResNet18 backbone + two linear heads,
 // classification/train_multilabel_classifier.py:117-131) that are not convolutions.  The 3x3 / 1x1 convolutions of
 // the BasicBlocks run on mdie_conv_fwd (BatchNorm folded into post_scale / post_shift, the identity branch as
-// `residual` with residual_pre_act = 1), the 7x7 stem on mdie_stem7_fwd (conv.hip); here:
+// `residual`, activation applied afterwards by relu_inplace), the 7x7 stem on mdie_stem7_fwd (conv.hip); here:
+//   relu_inplace     the ReLU after `conv2 + identity` (mdie_conv_fwd adds its residual after the activation)
 //   maxpool3x3s2     nn.MaxPool2d(kernel_size=3, stride=2, padding=1) after the stem
 //   subsample2       x[:, ::2, ::2, :]: a stride-2 convolution == the stride-1 convolution sampled at even pixels
 //                    (3x3, pad 1) / the 1x1 convolution of the sampled input (downsample branch)
@@ -44,6 +45,21 @@ __global__ __launch_bounds__(RT_THREADS) void maxpool3x3s2_kernel(int B, int H, 
       }
     }
     *reinterpret_cast<uint4*>(out + (((size_t)img * Ho + oy) * Wo + ox) * out_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(m);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(RT_THREADS) void relu_inplace_kernel(size_t npix, int C, char* x, int stride) {
+  constexpr int VEC = Traits<T>::VEC;
+  const int CV = C / VEC;
+  const size_t total = npix * CV;
+  for (size_t u = (size_t)blockIdx.x * RT_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * RT_THREADS) {
+    uint4* p = reinterpret_cast<uint4*>(x + (u / CV) * stride * sizeof(T) + (u % CV) * 16);
+    float f[VEC];
+    Vec16<T>::unpack(*p, f);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] = fmaxf(f[i], 0.f);
+    *p = Vec16<T>::pack(f);
   }
 }
 
@@ -115,6 +131,17 @@ extern "C" int mdie_maxpool3x3s2(int dtype, int B, int H, int W, int C, const vo
   if (dtype == MDIE_F32) hipLaunchKernelGGL((maxpool3x3s2_kernel<float>), dim3(rt_grid(total)), dim3(RT_THREADS), 0, s, B, H, W, C, (const char*)in, in_stride, (char*)out, out_stride);
   else hipLaunchKernelGGL((maxpool3x3s2_kernel<mdie::bf16>), dim3(rt_grid(total)), dim3(RT_THREADS), 0, s, B, H, W, C, (const char*)in, in_stride, (char*)out, out_stride);
   MDIE_LAUNCH_CHECK("mdie_maxpool3x3s2");
+  return MDIE_OK;
+}
+
+extern "C" int mdie_relu_inplace(int dtype, long npix, int C, void* x, int stride, void* stream) {
+  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_relu_inplace: bad dtype %d", dtype);
+  MDIE_REQUIRE(npix > 0 && C > 0 && C % 16 == 0 && x && stride >= C && ((uintptr_t)x & 15) == 0 && stride % 4 == 0, "mdie_relu_inplace: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t total = (size_t)npix * (C / (dtype == MDIE_F32 ? 4 : 8));
+  if (dtype == MDIE_F32) hipLaunchKernelGGL((relu_inplace_kernel<float>), dim3(rt_grid(total)), dim3(RT_THREADS), 0, s, (size_t)npix, C, (char*)x, stride);
+  else hipLaunchKernelGGL((relu_inplace_kernel<mdie::bf16>), dim3(rt_grid(total)), dim3(RT_THREADS), 0, s, (size_t)npix, C, (char*)x, stride);
+  MDIE_LAUNCH_CHECK("mdie_relu_inplace");
   return MDIE_OK;
 }
 

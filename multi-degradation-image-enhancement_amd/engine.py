@@ -246,7 +246,7 @@ def pack_conv_weight(w, dtype, transposed=False, cout_stored=None, cin_stored=No
 
 
 def conv_fwd(segments, weight_packed, post_scale, post_shift, *, dtype, ksize, cout, act=L.ACT_NONE, pool=False,
-             pre_scale=None, pre_shift=None, residual=None, out=None, out_view=None, residual_pre_act=False):
+             pre_scale=None, pre_shift=None, residual=None, out=None, out_view=None):
     """segments: list of NHWC tensors [B,H,W,Ci] (Ci % 16 == 0).  Returns NHWC [B,Ho,Wo,cout]."""
     x0 = segments[0]
     B, H, W, _ = x0.shape
@@ -269,7 +269,6 @@ def conv_fwd(segments, weight_packed, post_scale, post_shift, *, dtype, ksize, c
     target = out_view if out_view is not None else out
     d.out, d.out_stride = target.data_ptr(), target.stride(2)
     d.out_nchw3 = None
-    d.residual_pre_act = int(residual_pre_act)
     L.check(L.lib.mdie_conv_fwd(C.byref(d), _stream_ptr(x0.device)), "mdie_conv_fwd")
     return out
 

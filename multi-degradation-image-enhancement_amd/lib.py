@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
                 ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("weight", C.c_void_p),
                 ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int), ("pool", C.c_int),
                 ("residual", C.c_void_p), ("res_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int),
-                ("out_nchw3", C.c_void_p), ("residual_pre_act", C.c_int)]
+                ("out_nchw3", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -200,6 +200,7 @@ SIGNATURES = {
     "mdie_stem7_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int, C.c_void_p]),
     "mdie_maxpool3x3s2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mdie_relu_inplace": (C.c_int, [C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mdie_subsample2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mdie_avgpool_heads": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

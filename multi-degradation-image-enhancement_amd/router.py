@@ -10,8 +10,8 @@ code that USES the classifier to pick an enhancer; the routing policy below is t
     task  = the detected class with the largest margin probs[c] - threshold[c], or None (clean image: pass through)
 
 Inference runs on the HIP engine: 7x7/s2 stem (`mdie_stem7_fwd`), 3x3/s2 max-pool, sixteen 3x3 and three 1x1
-convolutions on `mdie_conv_fwd` (eval BatchNorm folded, identity branch added before the ReLU in the epilogue,
-stride 2 = stride 1 + `mdie_subsample2`), global average pool + both heads + sigmoid in `mdie_avgpool_heads`.
+convolutions on `mdie_conv_fwd` (eval BatchNorm folded, identity branch as the epilogue's residual followed by
+`mdie_relu_inplace`, stride 2 = stride 1 + `mdie_subsample2`), global average pool + both heads + sigmoid in `mdie_avgpool_heads`.
 GPU only, no fallback.  ImageNet weights cannot be downloaded here: tests use seeded random parameters.
 """
 import json
@@ -127,8 +127,14 @@ class DegradationRouter:
 
     # ---- inference -----------------------------------------------------------------------------------------------------
     def _conv(self, x, params, ks, cout, act, residual=None):
+        """act(conv * scale + shift), or relu(conv * scale + shift + residual) when a residual is given"""
         w, s, b = params
-        return E.conv_fwd([x], w, s, b, dtype=self.dtype, ksize=ks, cout=cout, act=act, residual=residual, residual_pre_act=residual is not None)
+        if residual is None:
+            return E.conv_fwd([x], w, s, b, dtype=self.dtype, ksize=ks, cout=cout, act=act)
+        y = E.conv_fwd([x], w, s, b, dtype=self.dtype, ksize=ks, cout=cout, act=L.ACT_NONE, residual=residual)
+        B, H, W, Cc = y.shape
+        L.check(L.lib.mdie_relu_inplace(self.dtype, B * H * W, Cc, y.data_ptr(), Cc, E._stream_ptr(y.device)), "mdie_relu_inplace")
+        return y
 
     def _sub2(self, x):
         B, H, W, Cc = x.shape
