@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 13
+#define MDIE_ABI_VERSION 14
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -50,7 +50,7 @@ enum {
  * models/cdan.py:35,38, is never materialised: each growth layer writes its own segment). */
 typedef struct {
   const void* ptr;  /* first element of pixel (0,0,0) */
-  int channels;     /* multiple of 16 */
+  int channels;     /* whole 16-byte groups: multiple of 8 (bf16) / 4 (f32); multiple of 16 for the training kernels */
   int stride;       /* elements between consecutive pixels */
 } mdie_seg;
 
@@ -237,9 +237,10 @@ int mdie_upsample2x_add_pool(int dtype, int B, int H, int W, int C, const void* 
 
 /* Same, for the last decoder stage where the skip is the network input itself (`torch.add(out, x)`,
  * models/cdan.py:153-154): lo NHWC [B,H,W,lo_stride] (channels 0..2), x fp32 NCHW [B,3,2H,2W],
- * out NHWC [B,2H,2W,16] (channels 3..15 zero). */
+ * out NHWC [B,2H,2W,out_channels] (channels 3.. zero); out_channels = 16, or one 16-byte group per pixel (8 bf16 /
+ * 4 f32): the engine stores this 3-channel tensor -- read five times by decoder.final_dense -- that narrow. */
 int mdie_upsample2x_add_nchw3(int dtype, int B, int H, int W, const void* lo, int lo_stride, const float* x_nchw,
-                              void* out, void* stream);
+                              void* out, int out_channels, void* stream);
 
 /* Boundary layout changes: fp32 NCHW [B,3,H,W] <-> NHWC with 16 stored channels. */
 int mdie_nchw3_to_nhwc16(int dtype, int B, int H, int W, const float* x_nchw, void* out, void* stream);

@@ -52,7 +52,10 @@ enum { CB_BOTT = 0, CB_1, CB_2, CB_3, CB_COUNT };
 struct Arch {
   std::vector<ConvSpec> conv;
   std::vector<CbamSpec> cbam;
-  Arch() {
+  int base3;   // stored channels of the 3-channel input of decoder.final_dense: ONE 16-byte K group per pixel
+               // (8 bf16 / 4 f32), not 16 -- the five layers of the block read it five times at 256x256
+  explicit Arch(int dtype) {
+    base3 = dtype == MDIE_F32 ? 4 : 8;
     conv.resize(CV_COUNT);
     const int enc[5] = {3, 64, 128, 256, 512};
     for (int i = 0; i < 4; ++i) {
@@ -62,7 +65,7 @@ struct Arch {
     const char* dn[4] = {"encoder.dense1", "encoder.dense2", "encoder.dense3", "decoder.final_dense"};
     const int dc[4] = {64, 128, 256, 3};
     for (int b = 0; b < 4; ++b) {
-      const int c0 = dc[b], c0s = st16(c0), gap = c0s - c0;
+      const int c0 = dc[b], c0s = b == 3 ? base3 : st16(c0), gap = c0s - c0;
       for (int l = 0; l <= NLAYERS; ++l) {
         const bool tr = l == NLAYERS;
         const std::string p = std::string(dn[b]) + (tr ? ".transition_layer" : ".layers." + std::to_string(l));
@@ -78,9 +81,9 @@ struct Arch {
     cbam = {{"bottleneck", 512}, {"decoder.cbam1", 256}, {"decoder.cbam2", 128}, {"decoder.cbam3", 64}};
   }
 };
-static const Arch& arch() {
-  static const Arch a;
-  return a;
+static const Arch& arch(int dtype) {
+  static const Arch f32(MDIE_F32), b16(MDIE_BF16);
+  return dtype == MDIE_F32 ? f32 : b16;
 }
 
 // ---- parameter blob layout ----------------------------------------------------------------------------------
@@ -106,7 +109,7 @@ static BlobLayout blob_layout(int dtype) {
   BlobLayout L{};
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
-  const Arch& A = arch();
+  const Arch& A = arch(dtype);
   for (int i = 0; i < CV_COUNT; ++i) {
     const ConvSpec& s = A.conv[i];
     L.conv[i].w = take(i == CV_E1 ? first_weight_bytes(dtype, s.cout_st) : conv_weight_bytes(dtype, s.ks, s.cin_st, s.cout_st));
@@ -228,7 +231,7 @@ static Plan make_plan(int dtype, int B, int H, int W) {
   P.t1 = take(256, h3, w3); P.u1 = take(256, h3, w3);
   P.t2lo = take(128, h3, w3); P.t2 = take(128, h2, w2); P.u2 = take(128, h2, w2);
   P.t3lo = take(64, h2, w2); P.t3 = take(64, h1, w1); P.u3 = take(64, h1, w1);
-  P.t4lo = take(16, h1, w1); P.t4 = take(16, H, W);
+  P.t4lo = take(16, h1, w1); P.t4 = take(arch(dtype).base3, H, W);
   for (int l = 0; l < 4; ++l) P.fg[l] = take(16, H, W);
   P.out16 = take(16, H, W);
   size_t cb = 0;
@@ -257,8 +260,8 @@ extern "C" int mdie_pack_conv_weight(int dtype, int ksize, int transposed, const
   MDIE_REQUIRE(ksize == 1 || ksize == 3, "mdie_pack_conv_weight: ksize %d", ksize);
   MDIE_REQUIRE(w && dst && cout > 0 && cin > 0, "mdie_pack_conv_weight: null/empty");
   MDIE_REQUIRE(cout_stored >= cout && cout_stored % 16 == 0, "mdie_pack_conv_weight: cout_stored %d", cout_stored);
-  MDIE_REQUIRE(cin_stored % 16 == 0 && cin_stored >= cin + (split < cin ? gap : 0) && gap >= 0 && split >= 0,
-               "mdie_pack_conv_weight: cin_stored %d too small for cin %d split %d gap %d", cin_stored, cin, split, gap);
+  MDIE_REQUIRE(cin_stored % (dtype == MDIE_F32 ? 4 : 8) == 0 && cin_stored >= cin + (split < cin ? gap : 0) && gap >= 0 && split >= 0,
+               "mdie_pack_conv_weight: cin_stored %d invalid / too small for cin %d split %d gap %d", cin_stored, cin, split, gap);
   return pack_conv_weight(dtype, ksize, transposed, w, cout, cin, cout_stored, cin_stored, split, gap, dst);
 }
 
@@ -289,7 +292,7 @@ extern "C" int mdie_cdan_pack_params(int dtype, const mdie_tensor* tensors, int 
     if (tensors[i].name) T.m[tensors[i].name] = &tensors[i];
   char* blob = reinterpret_cast<char*>(blob_host);
   memset(blob, 0, L.total);
-  const Arch& A = arch();
+  const Arch& A = arch(dtype);
   for (int i = 0; i < CV_COUNT; ++i) {
     const ConvSpec& s = A.conv[i];
     const float* w = T.get(s.w_key, (int64_t)s.cin * s.cout * s.ks * s.ks);
@@ -397,7 +400,7 @@ static mdie_seg seg(const Ctx& c, const Buf& b) { return mdie_seg{c.ws + b.off, 
 
 static int run_conv(const Ctx& c, int id, int H, int W, std::initializer_list<Buf> in, const Buf& out, int act, int pool,
                     const Buf* residual, float* out_nchw3 = nullptr) {
-  const ConvSpec& s = arch().conv[id];
+  const ConvSpec& s = arch(c.dtype).conv[id];
   mdie_conv_desc d{};
   d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.ksize = s.ks;
   d.nseg = 0; d.cin = 0;
@@ -433,7 +436,7 @@ static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, con
                           bool pooled = false) {
   const CbamBlob& o = c.L.cbam[id];
   mdie_cbam_desc d{};
-  d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.C = arch().cbam[id].C;
+  d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.C = arch(c.dtype).cbam[id].C;
   d.x = c.ws + x.off; d.x_stride = x.C;
   d.w1 = reinterpret_cast<const float*>(c.params + o.w1); d.b1 = reinterpret_cast<const float*>(c.params + o.b1);
   d.w2 = reinterpret_cast<const float*>(c.params + o.w2); d.b2 = reinterpret_cast<const float*>(c.params + o.b2);
@@ -515,7 +518,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   RUN(run_conv(c, CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
   if (!(d->flags & MDIE_FWD_FUSED_TAIL)) {
     // bilinear x2 + x (x read from its fp32 NCHW planes), final_dense, sigmoid written straight to NCHW
-    RUN(mdie_upsample2x_add_nchw3(d->dtype, B, h1, w1, c.ws + P.t4lo.off, P.t4lo.C, d->x, c.ws + P.t4.off, stream));
+    RUN(mdie_upsample2x_add_nchw3(d->dtype, B, h1, w1, c.ws + P.t4lo.off, P.t4lo.C, d->x, c.ws + P.t4.off, P.t4.C, stream));
     RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID, d->y));
   } else {
     mdie_tail_desc t{};

@@ -109,8 +109,8 @@ __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_pool_kernel(int H, 
   }
 }
 
-// last decoder stage: out[B,2H,2W,16] = bilinear_x2(lo)[:, :3] + x (fp32 NCHW), one output pixel per thread
-template <typename T>
+// last decoder stage: out[B,2H,2W,CST] = bilinear_x2(lo)[:, :3] + x (fp32 NCHW), one output pixel per thread
+template <typename T, int CST>
 __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_nchw3_kernel(int B, int H, int W, const T* lo, int lo_stride,
                                                                           const float* x, T* out) {
   const int Ho = 2 * H, Wo = 2 * W;
@@ -127,16 +127,16 @@ __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_nchw3_kernel(int B,
     const T *p00 = lb + ((size_t)y0 * W + x0) * lo_stride, *p01 = lb + ((size_t)y0 * W + x1) * lo_stride;
     const T *p10 = lb + ((size_t)y1 * W + x0) * lo_stride, *p11 = lb + ((size_t)y1 * W + x1) * lo_stride;
     const float* xp = x + img * 3 * plane + hw;
-    float f[16];
+    float f[CST];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) f[i] = 0.f;
+    for (int i = 0; i < CST; ++i) f[i] = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       f[c] = hy0 * (wx0 * ld(p00 + c) + wx1 * ld(p01 + c)) + hy1 * (wx0 * ld(p10 + c) + wx1 * ld(p11 + c)) + xp[c * plane];
-    uint4* o = reinterpret_cast<uint4*>(out + p * 16);
+    uint4* o = reinterpret_cast<uint4*>(out + p * CST);
     constexpr int VEC = Traits<T>::VEC;
 #pragma unroll
-    for (int v = 0; v < 16 / VEC; ++v) o[v] = Vec16<T>::pack(f + v * VEC);
+    for (int v = 0; v < CST / VEC; ++v) o[v] = Vec16<T>::pack(f + v * VEC);
   }
 }
 
@@ -268,18 +268,24 @@ extern "C" int mdie_upsample2x_add_pool(int dtype, int B, int H, int W, int C, c
 }
 
 extern "C" int mdie_upsample2x_add_nchw3(int dtype, int B, int H, int W, const void* lo, int lo_stride, const float* x_nchw, void* out,
-                                         void* stream) {
+                                         int out_channels, void* stream) {
   if (int e = check_layout("mdie_upsample2x_add_nchw3", dtype, B, 3, H, W, lo, out)) return e;
   MDIE_REQUIRE(x_nchw != nullptr && lo_stride >= 3, "mdie_upsample2x_add_nchw3: null x or lo_stride < 3");
   MDIE_REQUIRE(((uintptr_t)out & 15) == 0, "mdie_upsample2x_add_nchw3: alignment");
+  const int vec = dtype == MDIE_F32 ? 4 : 8;
+  MDIE_REQUIRE(out_channels == 16 || out_channels == vec, "mdie_upsample2x_add_nchw3: out_channels %d (16 or %d)", out_channels, vec);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int grid = grid_for((size_t)B * 4 * H * W);
   TimedLaunch tl(MDIE_K_UPSAMPLE);
-  if (dtype == MDIE_F32)
-    hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<float>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const float*)lo, lo_stride, x_nchw, (float*)out);
-  else
-    hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<mdie::bf16>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const mdie::bf16*)lo, lo_stride,
-                       x_nchw, (mdie::bf16*)out);
+  if (dtype == MDIE_F32) {
+    if (out_channels == 16) hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<float, 16>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const float*)lo, lo_stride, x_nchw, (float*)out);
+    else hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<float, 4>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const float*)lo, lo_stride, x_nchw, (float*)out);
+  } else {
+    if (out_channels == 16)
+      hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<mdie::bf16, 16>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const mdie::bf16*)lo, lo_stride, x_nchw, (mdie::bf16*)out);
+    else
+      hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<mdie::bf16, 8>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const mdie::bf16*)lo, lo_stride, x_nchw, (mdie::bf16*)out);
+  }
   MDIE_LAUNCH_CHECK("mdie_upsample2x_add_nchw3");
   return MDIE_OK;
 }

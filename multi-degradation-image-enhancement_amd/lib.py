@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 13
+ABI_VERSION = 14
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 LOSS_KINDS = {"mse": 0, "l1": 1, "charbonnier": 2, "ssim": 3, "gradient_l1": 4}
@@ -158,7 +158,7 @@ SIGNATURES = {
     "mdie_upsample2x_add_pool": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mdie_pool_slabs": (C.c_int, [C.c_int, C.c_int]),
-    "mdie_upsample2x_add_nchw3": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdie_upsample2x_add_nchw3": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mdie_nchw3_to_nhwc16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdie_nhwc16_to_nchw3": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdie_nchw_to_nhwc": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
