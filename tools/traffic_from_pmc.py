@@ -32,7 +32,7 @@ for f in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursi
             split = collections.defaultdict(float)
             for d in disp[a:b]:
                 n = d["name"]
-                key = "conv3x3" if ("conv_kernel" in n and "Li3E" in n) or "conv_first" in n else "conv1x1" if "conv_kernel" in n else \
+                key = "conv3x3" if ("conv_kernel" in n and "Li3E" in n) or "conv_first" in n else "conv1x1" if ("conv_kernel" in n or "conv1x1" in n) else \
                       "cbam" if "cbam" in n else "upsample_add" if "upsample" in n else "tail" if "tail" in n else "layout"
                 if "conv_kernel<" in n:  # demangled template form
                     key = "conv"
