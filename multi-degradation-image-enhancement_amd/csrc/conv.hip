@@ -413,251 +413,6 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Wave-specialised variant: 512-thread persistent workgroups, ONE per CU.  Waves 4-7 ("loaders") own all
-// of the staging -- global loads, pre-activation transform, LDS writes -- and run one stage ahead into a
-// second LDS buffer; waves 0-3 ("consumers") only read LDS fragments, issue MFMAs and write the epilogue.
-// On every SIMD a loader wave (VALU / VMEM / LDS-write work) sits beside a consumer wave (MFMA / LDS-read
-// work), which is the pairing the matrix and vector pipes co-issue on; the stages of consecutive tiles
-// form one continuous stream, so there is no per-tile launch, setup or pipeline drain.
-// One workgroup barrier per stage: the buffer written during stage s is the one read during stage s+1.
-//
-// STATUS: opt-in (MDIE_CONV_WS=1), parity-green, NOT the default.  Measured on MI355X (B=32, 256x256 shapes):
-// within +-7 % of the one-tile-per-workgroup kernel on the 64-wide convs (conv4 86 vs 93 us, conv2 125 vs 122 us)
-// and slower on the cout=16 layers once the second register set lowers occupancy.  Ablations (tools/, EXP_*
-// builds) show why: with every global load and store removed the kernels still take ~75 % of their time, so
-// the limiter is on-chip (LDS fill + fragment reads + MFMA issue + epilogue VALU), not the memory latency
-// that this structure hides.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int WS_THREADS = 512;
-
-struct TileCoord { int img, y0, x0, n0; };
-
-template <typename T, int KS, int BN, int TILE>
-__global__ __launch_bounds__(WS_THREADS, 2) void conv_ws_kernel(const ConvArgs a) {
-  using G = ConvGeom<KS, BN, TILE>;
-  constexpr int VEC = Traits<T>::VEC;
-  constexpr int KC = Traits<T>::KC;
-  constexpr int PAD = G::PAD, PW = G::PW, NTAP = G::NTAP;
-  constexpr int NCS = BN / 16;
-  constexpr int NPS = TILE * TILE / 64;
-  constexpr int LT = 256;                              // loader threads
-  constexpr int PATCH_UNITS = PW * PW * 4;
-  constexpr int W_UNITS = 4 * NTAP * BN;
-  constexpr int PATCH_IT = (PATCH_UNITS + LT - 1) / LT;
-  constexpr int W_IT = (W_UNITS + LT - 1) / LT;
-  constexpr int PATCH_LAST_WAVES = ((PATCH_UNITS - (PATCH_IT - 1) * LT) + 63) / 64;
-  constexpr int W_LAST_WAVES = ((W_UNITS - (W_IT - 1) * LT) + 63) / 64;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool is_loader = wave_all >= 4;
-  const int tid = threadIdx.x & 255;                    // index within the role
-  const int wave = wave_all & 3;
-  const int lane = tid & 63;
-  const int lq = lane >> 4, lp = lane & 15;
-
-  const int total_tiles = a.n_tiles * a.tiles_x * a.tiles_y * a.B;
-  const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int nstages = my_tiles * a.nchunk;
-  auto decode = [&](int k) {
-    int t = blockIdx.x + k * gridDim.x;
-    TileCoord c;
-    c.n0 = (t & (a.n_tiles - 1)) * BN; t >>= a.n_tiles_log2;
-    c.x0 = (t % a.tiles_x) * TILE; t /= a.tiles_x;
-    c.y0 = (t % a.tiles_y) * TILE; t /= a.tiles_y;
-    c.img = t;
-    return c;
-  };
-
-  if (is_loader) {
-    // =================================== loader waves =========================================================
-    const int q = tid & 3;
-    const bool has_pre = a.pre_scale != nullptr;
-    const size_t wchunk_bytes = (size_t)4 * NTAP * a.cout * 16;
-    int gpix[PATCH_IT], pdst[PATCH_IT], wsrc_off[W_IT];
-    auto set_tile = [&](const TileCoord& c) {
-      int pix = tid >> 2;
-      int py = pix / PW, px = pix - py * PW;
-      const int base = c.img * a.H * a.W;
-#pragma unroll
-      for (int it = 0; it < PATCH_IT; ++it) {
-        const int gy = c.y0 + py - PAD, gx = c.x0 + px - PAD;
-        const bool in_patch = (it < PATCH_IT - 1) || (tid + it * LT < PATCH_UNITS);
-        const bool ok = in_patch && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        gpix[it] = ok ? base + gy * a.W + gx : -1;
-        pdst[it] = in_patch ? q * G::PLANE + (py * PWP + px) * 16 : -1;
-        px += 64 % PW; py += 64 / PW;
-        if (px >= PW) { px -= PW; py += 1; }
-      }
-#pragma unroll
-      for (int it = 0; it < W_IT; ++it) {
-        const int u = tid + it * LT;
-        const int qt = u / BN, n = u - qt * BN;
-        wsrc_off[it] = (qt * a.cout + c.n0 + n) * 16;
-      }
-    };
-    // Two register sets: the loads of stage s+3 are issued while stage s+1 is being written to LDS, so a
-    // request has two full stage times (~2 x 2.3k cycles of MFMA work) to come back.  Measured load-to-use
-    // latency of these 64-byte-segment gathers under load is ~6k cycles: one stage of lookahead was not enough.
-    struct StageRegs {
-      uint4 pv[PATCH_IT];
-      uint4 wv[W_IT];
-      float ps[VEC], pb[VEC];
-      unsigned inside;   // bit it: patch unit `it` lies inside the picture
-      bool live;
-    };
-    StageRegs R0, R1;
-    auto issue = [&](StageRegs& R, int chunk) {
-      const int c0 = chunk * KC + q * VEC;
-      const char* sbase = nullptr;
-      int sstride = 0;
-#pragma unroll
-      for (int sg = 0; sg < MDIE_MAX_SEG; ++sg) {
-        if (sg < a.nseg && c0 >= a.seg[sg].ch_begin && c0 < a.seg[sg].ch_end) {
-          sbase = a.seg[sg].ptr + (size_t)(c0 - a.seg[sg].ch_begin) * sizeof(T);
-          sstride = a.seg[sg].stride * (int)sizeof(T);
-        }
-      }
-      R.live = sbase != nullptr;
-      R.inside = 0;
-#pragma unroll
-      for (int it = 0; it < PATCH_IT; ++it) {
-        R.pv[it] = make_uint4(0, 0, 0, 0);
-        if (it < PATCH_IT - 1 || wave < PATCH_LAST_WAVES)
-          if (R.live && gpix[it] >= 0) {
-            R.pv[it] = *reinterpret_cast<const uint4*>(sbase + (size_t)gpix[it] * sstride);
-            R.inside |= 1u << it;
-          }
-      }
-      const char* wsrc = a.weight + chunk * wchunk_bytes;
-#pragma unroll
-      for (int it = 0; it < W_IT; ++it) {
-        R.wv[it] = make_uint4(0, 0, 0, 0);
-        if (it < W_IT - 1 || wave < W_LAST_WAVES)
-          if (tid + it * LT < W_UNITS) R.wv[it] = *reinterpret_cast<const uint4*>(wsrc + wsrc_off[it]);
-      }
-      if (has_pre && R.live) {
-        if constexpr (VEC == 8) {
-          const float4 s0 = *reinterpret_cast<const float4*>(a.pre_scale + c0), s1 = *reinterpret_cast<const float4*>(a.pre_scale + c0 + 4);
-          const float4 b0 = *reinterpret_cast<const float4*>(a.pre_shift + c0), b1 = *reinterpret_cast<const float4*>(a.pre_shift + c0 + 4);
-          R.ps[0] = s0.x; R.ps[1] = s0.y; R.ps[2] = s0.z; R.ps[3] = s0.w; R.ps[4] = s1.x; R.ps[5] = s1.y; R.ps[6] = s1.z; R.ps[7] = s1.w;
-          R.pb[0] = b0.x; R.pb[1] = b0.y; R.pb[2] = b0.z; R.pb[3] = b0.w; R.pb[4] = b1.x; R.pb[5] = b1.y; R.pb[6] = b1.z; R.pb[7] = b1.w;
-        } else {
-          const float4 s0 = *reinterpret_cast<const float4*>(a.pre_scale + c0);
-          const float4 b0 = *reinterpret_cast<const float4*>(a.pre_shift + c0);
-          R.ps[0] = s0.x; R.ps[1] = s0.y; R.ps[2] = s0.z; R.ps[3] = s0.w;
-          R.pb[0] = b0.x; R.pb[1] = b0.y; R.pb[2] = b0.z; R.pb[3] = b0.w;
-        }
-      }
-    };
-    auto store = [&](const StageRegs& R, char* buf) {
-#pragma unroll
-      for (int it = 0; it < PATCH_IT; ++it) {
-        if (it < PATCH_IT - 1 || wave < PATCH_LAST_WAVES) {
-          if (pdst[it] >= 0) {
-            uint4 v = R.pv[it];
-            if (has_pre && ((R.inside >> it) & 1u)) {
-              float f[VEC];
-              Vec16<T>::unpack(v, f);
-#pragma unroll
-              for (int i = 0; i < VEC; ++i) f[i] = fmaxf(fmaf(f[i], R.ps[i], R.pb[i]), 0.0f);
-              v = Vec16<T>::pack(f);
-            }
-            *reinterpret_cast<uint4*>(buf + pdst[it]) = v;
-          }
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < W_IT; ++it) {
-        if (it < W_IT - 1 || wave < W_LAST_WAVES) {
-          const int u = tid + it * LT;
-          if (u < W_UNITS) *reinterpret_cast<uint4*>(buf + 4 * G::PLANE + u * 16) = R.wv[it];
-        }
-      }
-    };
-    int ld_tile = 0, ld_chunk = 0, issued = 0;   // `issued` = number of stages whose loads have been issued
-    auto issue_next = [&](StageRegs& R) {
-      if (issued >= nstages) return;
-      if (issued > 0 && ++ld_chunk == a.nchunk) { ld_chunk = 0; ++ld_tile; set_tile(decode(ld_tile)); }
-      issue(R, ld_chunk);
-      ++issued;
-    };
-    set_tile(decode(0));
-    issue_next(R0);                               // stage 0
-    issue_next(R1);                               // stage 1
-    store(R0, smem);                              // stage 0 -> buffer 0
-    issue_next(R0);                               // stage 2
-    __syncthreads();
-    // iteration s writes stage s+1 (register set (s+1)&1) into buffer (s+1)&1, then refills that set with stage s+3
-    int s = 0;
-    for (; s + 1 < nstages; s += 2) {
-      store(R1, smem + G::BUF_BYTES);             // stage s+1 (odd)
-      issue_next(R1);                             // stage s+3
-      __syncthreads();
-      if (s + 2 < nstages) { store(R0, smem); issue_next(R0); }   // stage s+2 (even), then stage s+4
-      __syncthreads();
-    }
-    if (s < nstages) __syncthreads();             // odd stage count: the consumers' last barrier
-  } else {
-    // =================================== consumer waves =======================================================
-    f32x4 acc[NCS][NPS];
-#pragma unroll
-    for (int i = 0; i < NCS; ++i)
-#pragma unroll
-      for (int j = 0; j < NPS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int xoff[NPS];
-#pragma unroll
-    for (int ps = 0; ps < NPS; ++ps) {
-      int y, x;
-      tile_pixel<TILE>(wave * NPS + ps, lp, y, x);
-      xoff[ps] = lq * G::PLANE + (y * PWP + x) * 16;
-    }
-    const int woff = 4 * G::PLANE + lq * G::WPLANE + lp * 16;
-    int cp_tile = 0, cp_chunk = 0;
-    TileCoord cc = decode(0);
-    float4 esc[NCS], esh[NCS];
-    auto load_epi = [&]() {
-#pragma unroll
-      for (int cs = 0; cs < NCS; ++cs) {
-        esc[cs] = *reinterpret_cast<const float4*>(a.e.post_scale + cc.n0 + cs * 16 + lq * 4);
-        esh[cs] = *reinterpret_cast<const float4*>(a.e.post_shift + cc.n0 + cs * 16 + lq * 4);
-      }
-    };
-    load_epi();
-    __syncthreads();                              // stage 0 is in buffer 0
-    for (int s = 0; s < nstages; ++s) {
-      const char* buf = smem + (s & 1) * G::BUF_BYTES;
-#pragma unroll
-      for (int tap = 0; tap < NTAP; ++tap) {
-        const int kh = tap / KS, kw = tap - kh * KS;
-        uint4 wf[NCS], xf[NPS];
-#pragma unroll
-        for (int cs = 0; cs < NCS; ++cs)
-          wf[cs] = *reinterpret_cast<const uint4*>(buf + (tap * BN + cs * 16) * 16 + woff);
-#pragma unroll
-        for (int ps = 0; ps < NPS; ++ps)
-          xf[ps] = *reinterpret_cast<const uint4*>(buf + (kh * PWP + kw) * 16 + xoff[ps]);
-#pragma unroll
-        for (int cs = 0; cs < NCS; ++cs)
-#pragma unroll
-          for (int ps = 0; ps < NPS; ++ps) acc[cs][ps] = mma16<T>(wf[cs], xf[ps], acc[cs][ps]);
-      }
-      if (++cp_chunk == a.nchunk) {
-        conv_epilogue<T, NCS, NPS, TILE>(a.e, esc, esh, acc, cc.img, cc.y0, cc.x0, cc.n0, wave * NPS, lq, lp);
-#pragma unroll
-        for (int i = 0; i < NCS; ++i)
-#pragma unroll
-          for (int j = 0; j < NPS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        cp_chunk = 0;
-        if (++cp_tile < my_tiles) { cc = decode(cp_tile); load_epi(); }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // 1x1 convolutions (DenseBlock transitions, models/cdan.py:48-53; ResNet downsample branches): streaming kernel.
 // A 1x1 convolution has no tap reuse, so its activations never need LDS: the MFMA B operand of a lane IS 16
 // contiguous bytes of one pixel (8 bf16 / 4 f32 channels of NHWC), loaded straight from global memory and
@@ -913,7 +668,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   // (tile, chunk) stages with two LDS stage buffers were 5-25 % SLOWER on every layer shape --
   // the doubled LDS/VGPR footprint halves the resident workgroups, and resident workgroups are what
   // hides the staging latency here.)
-  a.n_tiles_log2 = 0;   // only the wave-specialised kernel needs a power-of-two tile count
+  a.n_tiles_log2 = 0;
   const dim3 grid(8, a.n_tiles, cdiv(a.tiles_x * a.tiles_y * a.B, 8));
   static bool attr_set = false;
   if (!attr_set) {
@@ -927,40 +682,6 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   return MDIE_OK;
 }
 
-static int num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
-
-template <typename T, int KS, int BN, int TILE>
-static int launch_conv_ws(ConvArgs& a, hipStream_t stream) {
-  using G = ConvGeom<KS, BN, TILE>;
-  constexpr int LDS = 2 * G::BUF_BYTES;
-  a.tiles_x = cdiv(a.W, TILE); a.tiles_y = cdiv(a.H, TILE);
-  int lg = 0;
-  while ((1 << lg) < a.n_tiles) ++lg;
-  if ((1 << lg) != a.n_tiles) { set_error("mdie_conv_fwd: cout / %d = %d output tiles, must be a power of two", BN, a.n_tiles); return MDIE_EINVAL; }
-  a.n_tiles_log2 = lg;
-  const long total = (long)a.n_tiles * a.tiles_x * a.tiles_y * a.B;
-  const int per_cu = (160 * 1024) / LDS >= 2 ? 2 : 1;   // two persistent workgroups per CU when both stage rings fit
-  const long slots = (long)num_cus() * per_cu;
-  const int grid = (int)(total < slots ? total : slots);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, KS, BN, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
-  TimedLaunch tl(KS == 3 ? MDIE_K_CONV3 : MDIE_K_CONV1);
-  hipLaunchKernelGGL((conv_ws_kernel<T, KS, BN, TILE>), dim3(grid), dim3(WS_THREADS), LDS, stream, a);
-  MDIE_LAUNCH_CHECK("mdie_conv_fwd");
-  return MDIE_OK;
-}
 
 static void fill_epi(EpiArgs& e, int H, int W, const float* sc, const float* sh, int act, int pool, const void* res, int res_stride,
                      void* out, int out_stride, float* nchw3 = nullptr) {
@@ -1000,12 +721,6 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   const long wgs16 = (long)cdiv(d->H, 16) * cdiv(d->W, 16) * d->B * a.n_tiles;
   static const int force8 = getenv("MDIE_CONV_TILE8") ? atoi(getenv("MDIE_CONV_TILE8")) : 0;  // experiments: 1 = thin, 2 = all
   const bool small = wgs16 < (bn == 16 ? 1024 : 512) || (force8 == 1 && bn == 16) || force8 == 2;
-  // MDIE_CONV_WS: 0 = one tile per 256-thread workgroup, 1 = wave-specialised persistent kernel for the 16x16-tile shapes
-  static const int ws = getenv("MDIE_CONV_WS") ? atoi(getenv("MDIE_CONV_WS")) : 0;
-  if (ws && !small && (a.n_tiles & (a.n_tiles - 1)) == 0) {
-    if (d->ksize == 3) return bn == 64 ? launch_conv_ws<T, 3, 64, 16>(a, stream) : launch_conv_ws<T, 3, 16, 16>(a, stream);
-    return bn == 64 ? launch_conv_ws<T, 1, 64, 16>(a, stream) : launch_conv_ws<T, 1, 16, 16>(a, stream);
-  }
   static const int no_stream = getenv("MDIE_CONV1_STREAM") ? !atoi(getenv("MDIE_CONV1_STREAM")) : 0;   // experiments: 0 = staged kernel
   // (64-wide output tiles only: with 16 outputs there are 4 MFMAs per 4 loads and the staged kernel is faster -- measured
   //  final.tr 85 us staged vs 92 us streaming, dense1.tr 58 us staged vs 47 us streaming, B=32 256x256 bf16)
