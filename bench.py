@@ -132,7 +132,7 @@ def main():
 
     from mdie_amd import lib as L
     from models.cdan import CDAN
-    from oracle import params as P  # synthetic-input recipe + seeded checkpoint (test infrastructure)
+    from mdie_amd import synthetic as P  # synthetic-input recipe + seeded checkpoint (bit-identical to the oracle's generator)
 
     B, S = args.batch, args.size
     sd = P.make_state_dict(42)

@@ -64,3 +64,17 @@ def test_example_config_parses():
     cfg = H.load_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "example_noise_64.json"), "test")
     assert cfg["model"]["networks"][0]["name"] == ["models.cdan", "CDAN"]
     assert cfg["test"]["dataloader"]["args"]["batch_size"] == 4
+
+
+def test_package_synthetic_workload_equals_the_oracle_generators():
+    """bench.py / tools use mdie_amd.synthetic; the oracle and the tests use oracle.params: one dataset, bit for bit"""
+    import torch
+    from mdie_amd import router as R
+    from mdie_amd import synthetic as S
+    from oracle import params as P
+    a, b = S.make_state_dict(42), P.make_state_dict(42)
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    (d1, c1), (d2, c2) = S.lowlight_batch(1000, 2, 32, 40), P.lowlight_batch(1000, 2, 32, 40)
+    assert torch.equal(d1, d2) and torch.equal(c1, c2)
+    r1, r2 = S.make_state_dict(7, R.router_param_spec()), P.fill_spec(R.router_param_spec(), 7, randomize_bn=True)
+    assert all(torch.equal(r1[k], r2[k]) for k in r1)

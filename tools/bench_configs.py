@@ -7,7 +7,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mdie_amd import engine as E
-from oracle import params as P
+from mdie_amd import synthetic as P
 
 what = sys.argv[1] if len(sys.argv) > 1 else "routed"
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
@@ -36,7 +36,7 @@ if what == "routed":
     # the classifier itself (seeded random parameters: no ImageNet / trained weights offline); its labels are not used for
     # the timing below (random weights put every image in one class), only its cost is reported
     from mdie_amd import router as R
-    router = R.DegradationRouter("cuda", prec).load(P.fill_spec(R.router_param_spec(), 7, randomize_bn=True))
+    router = R.DegradationRouter("cuda", prec).load(P.make_state_dict(7, R.router_param_spec()))
     dtr = timed(lambda: router.forward(x))
     print(f"router[{prec}] ResNet18 + 2 heads, B=32 256x256: {dtr*1e3:.2f} ms/batch = {32/dtr:.0f} img/s")
     dt = timed(lambda: eng.forward(x, labels))

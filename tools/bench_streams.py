@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mdie_amd.engine as E
-from oracle import params as P
+from mdie_amd import synthetic as P
 
 B, S = 32, 256
 sd = P.make_state_dict(42)

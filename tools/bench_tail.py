@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mdie_amd.engine as E
-from oracle import params as P
+from mdie_amd import synthetic as P
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 B, S = 32, 256

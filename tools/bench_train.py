@@ -7,7 +7,7 @@ import torch
 from models.cdan import CDAN
 from mdie_amd import host as H
 from mdie_amd import train as T
-from oracle import params as P
+from mdie_amd import synthetic as P
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from models.cdan import CDAN
-from oracle import params as P
+from mdie_amd import synthetic as P
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
