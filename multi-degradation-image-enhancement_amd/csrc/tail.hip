@@ -74,7 +74,7 @@ template <typename T> struct TailLds {
   static constexpr int ACT_BYTES = cmax(cmax(tl_np(1) * tl_act_pitch(2, E), tl_np(2) * tl_act_pitch(3, E)),
                                         cmax(tl_np(3) * tl_act_pitch(4, E), tl_np(4) * tl_act_pitch(5, E)));
   static constexpr int WGT = ACT + ACT_BYTES;
-  static constexpr int WGT_BYTES = tl_steps(4, E) * 16 * TL_WROW;
+  static constexpr int WGT_BYTES = E == 2 ? 0 : tl_steps(4, E) * 16 * TL_WROW;   // bf16 keeps its weights in registers
   static constexpr int TOTAL = WGT + WGT_BYTES;
   __device__ static constexpr int raw(int j) { return j == 1 ? RAW1 : j == 2 ? RAW2 : j == 3 ? RAW3 : RAW4; }
 };
@@ -116,10 +116,19 @@ __device__ __forceinline__ void tail_layer(const TailArgs& a, char* smem, int im
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lp = lane & 15;
 
   // ---- (a) operand images --------------------------------------------------------------------------------
-  // weights of this layer -> LDS (1 KiB steps, 64-byte rows re-pitched to 80)
-  for (int u = tid; u < STEPS * 64; u += TL_THREADS) {
-    const uint4 v = *reinterpret_cast<const uint4*>(a.p.w[L - 1] + (size_t)u * 16);
-    *reinterpret_cast<uint4*>(smem + LD::WGT + (u >> 2) * TL_WROW + (u & 3) * 16) = v;
+  // bf16: this lane's weight fragments of EVERY step of the layer go straight from global memory (L2-resident,
+  // <= 15 KiB per layer) into registers, issued first so they land during the activation passes; each MFMA of the
+  // pass below then costs one LDS read (its pixel operand) instead of two.  f32 (29 steps) keeps the LDS image.
+  constexpr bool WREG = (E == 2);
+  uint4 wreg[WREG ? STEPS : 1];
+  if constexpr (WREG) {
+#pragma unroll
+    for (int st_ = 0; st_ < STEPS; ++st_) wreg[st_] = *reinterpret_cast<const uint4*>(a.p.w[L - 1] + ((size_t)st_ * 16 + lp) * 64 + lq * 16);
+  } else {
+    for (int u = tid; u < STEPS * 64; u += TL_THREADS) {
+      const uint4 v = *reinterpret_cast<const uint4*>(a.p.w[L - 1] + (size_t)u * 16);
+      *reinterpret_cast<uint4*>(smem + LD::WGT + (u >> 2) * TL_WROW + (u & 3) * 16) = v;
+    }
   }
   // activated base (3 channels + zero) over the input region, common-frame coordinates
   {
@@ -189,22 +198,33 @@ __device__ __forceinline__ void tail_layer(const TailArgs& a, char* smem, int im
   const char* wl = smem + LD::WGT + lp * TL_WROW + lq * 16;
 
   constexpr int NS = (NPO + 15) / 16;
-  for (int s = wave; s < NS; s += TL_THREADS / 64) {
-    const int pi = s * 16 + lp;
-    const bool valid = pi < NPO;
-    const int pc = valid ? pi : NPO - 1;
-    const int oy = pc / RWO, ox = pc - oy * RWO;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // NSW pixel subtiles in flight per wave: with ONE accumulator every MFMA waits for the previous one (a chain of up to
+  // 15 dependent 16x16x32 MFMAs per subtile); independent accumulators let the matrix pipe and the LDS reads overlap
+  constexpr int NSW = 4, WAVES = TL_THREADS / 64;
+  for (int s0 = wave; s0 < NS; s0 += NSW * WAVES) {
+    bool valid[NSW];
+    int pcv[NSW], oyv[NSW], oxv[NSW];
+    f32x4 acc[NSW];
+#pragma unroll
+    for (int u = 0; u < NSW; ++u) {
+      const int sub = s0 + u * WAVES;
+      const int pi = sub * 16 + lp;
+      valid[u] = sub < NS && pi < NPO;
+      pcv[u] = valid[u] ? pi : NPO - 1;
+      oyv[u] = pcv[u] / RWO; oxv[u] = pcv[u] - oyv[u] * RWO;
+      acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // base: top-left tap of this output pixel in frame coordinates
-    {
-      const char* bb = smem + LD::ACTBASE + (((oy + KOUT - PADK) * TL_FW) + (ox + KOUT - PADK)) * 4 * E;
+#pragma unroll
+    for (int u = 0; u < NSW; ++u) {
+      const char* bb = smem + LD::ACTBASE + (((oyv[u] + KOUT - PADK) * TL_FW) + (oxv[u] + KOUT - PADK)) * 4 * E;
       if constexpr (E == 2) {
         unsigned short h[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) h[i] = *reinterpret_cast<const unsigned short*>(bb + boff[i]);
         const uint4 xf = make_uint4(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16), h[4] | ((uint32_t)h[5] << 16),
                                     h[6] | ((uint32_t)h[7] << 16));
-        acc = tl_mma<T>(*reinterpret_cast<const uint4*>(wl), xf, acc);
+        acc[u] = tl_mma<T>(wreg[0], xf, acc[u]);
       } else {
         // f32: two steps of 16 k; lane group lq covers k = 16*m + 4*lq .. +3
 #pragma unroll
@@ -218,12 +238,14 @@ __device__ __forceinline__ void tail_layer(const TailArgs& a, char* smem, int im
             const int off = (tap < KS * KS) ? ((dy * TL_FW + dx) * 4 + c) * E : 0;
             h[i] = *reinterpret_cast<const uint32_t*>(bb + off);
           }
-          acc = tl_mma<T>(*reinterpret_cast<const uint4*>(wl + m * 16 * TL_WROW), make_uint4(h[0], h[1], h[2], h[3]), acc);
+          acc[u] = tl_mma<T>(*reinterpret_cast<const uint4*>(wl + m * 16 * TL_WROW), make_uint4(h[0], h[1], h[2], h[3]), acc[u]);
         }
       }
     }
     if constexpr (NG > 0) {
-      const char* ab = smem + LD::ACT + ((oy + KOUT - KIN - PADK) * RWI + (ox + KOUT - KIN - PADK)) * AP;
+      const char* ab[NSW];
+#pragma unroll
+      for (int u = 0; u < NSW; ++u) ab[u] = smem + LD::ACT + ((oyv[u] + KOUT - KIN - PADK) * RWI + (oxv[u] + KOUT - KIN - PADK)) * AP;
 #pragma unroll
       for (int g = 0; g < GS; ++g) {
         int off;
@@ -237,26 +259,35 @@ __device__ __forceinline__ void tail_layer(const TailArgs& a, char* smem, int im
           const int t = g / NG, j = g - t * NG;
           off = (((t / KS) * RWI + (t % KS)) * AP + j * 16 * E) + lq * 16;
         }
-        const uint4 xf = *reinterpret_cast<const uint4*>(ab + off);
-        acc = tl_mma<T>(*reinterpret_cast<const uint4*>(wl + (BS + g) * 16 * TL_WROW), xf, acc);
+        uint4 xf[NSW];
+#pragma unroll
+        for (int u = 0; u < NSW; ++u) xf[u] = *reinterpret_cast<const uint4*>(ab[u] + off);
+        uint4 wg;
+        if constexpr (WREG) wg = wreg[BS + g];
+        else wg = *reinterpret_cast<const uint4*>(wl + (BS + g) * 16 * TL_WROW);
+#pragma unroll
+        for (int u = 0; u < NSW; ++u) acc[u] = tl_mma<T>(wg, xf[u], acc[u]);
       }
     }
     // epilogue: lane holds couts 4*lq .. 4*lq+3 of pixel pc
-    const float v0 = acc[0] + bias.x, v1 = acc[1] + bias.y, v2 = acc[2] + bias.z, v3 = acc[3] + bias.w;
-    if constexpr (L < 5) {
-      if (valid) {
-        T* dst = reinterpret_cast<T*>(smem + LD::raw(L)) + pc * 16 + lq * 4;
-        if constexpr (E == 4) *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
-        else *reinterpret_cast<uint2*>(dst) = make_uint2(bf_pack(v0, v1), bf_pack(v2, v3));
-      }
-    } else {
-      const int gy = ty0 + oy, gx = tx0 + ox;
-      if (valid && lq == 0 && gy < a.H && gx < a.W) {
-        const size_t plane = (size_t)a.H * a.W;
-        float* o = a.y + (size_t)img * 3 * plane + (size_t)gy * a.W + gx;
-        o[0] = sigmoidf(v0);
-        o[plane] = sigmoidf(v1);
-        o[2 * plane] = sigmoidf(v2);
+#pragma unroll
+    for (int u = 0; u < NSW; ++u) {
+      const float v0 = acc[u][0] + bias.x, v1 = acc[u][1] + bias.y, v2 = acc[u][2] + bias.z, v3 = acc[u][3] + bias.w;
+      if constexpr (L < 5) {
+        if (valid[u]) {
+          T* dst = reinterpret_cast<T*>(smem + LD::raw(L)) + pcv[u] * 16 + lq * 4;
+          if constexpr (E == 4) *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
+          else *reinterpret_cast<uint2*>(dst) = make_uint2(bf_pack(v0, v1), bf_pack(v2, v3));
+        }
+      } else {
+        const int gy = ty0 + oyv[u], gx = tx0 + oxv[u];
+        if (valid[u] && lq == 0 && gy < a.H && gx < a.W) {
+          const size_t plane = (size_t)a.H * a.W;
+          float* o = a.y + (size_t)img * 3 * plane + (size_t)gy * a.W + gx;
+          o[0] = sigmoidf(v0);
+          o[plane] = sigmoidf(v1);
+          o[2 * plane] = sigmoidf(v2);
+        }
       }
     }
   }
