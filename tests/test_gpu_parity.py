@@ -115,7 +115,6 @@ def oracle_256():
     from oracle import cdan_oracle as O
     from oracle import params as P
     x, _ = P.lowlight_batch(5, 1, 256, 256)       # one image: the CPU oracle dominates this suite's run time
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     with torch.no_grad():
         return x, O.cdan_forward(P.make_state_dict(42), x)
 
