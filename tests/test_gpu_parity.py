@@ -959,3 +959,44 @@ def test_router_checkpoint_format_thresholds_and_routing(E, tmp_path):
         R.DegradationRouter("cuda").load({k: v for k, v in sd.items() if "layer3" not in k})
     with pytest.raises(Exception):
         router.forward(x)                        # CPU tensor
+
+
+@pytest.mark.parametrize("precision,min_cos,med_cos,out_tol", [("fp32", 0.9999, 0.99999, 2e-4), ("bf16", 0.85, 0.97, 3e-2)])
+def test_whole_network_training_step_vs_oracle(E, precision, min_cos, med_cos, out_tol):
+    """forward + backward of the whole network in training mode (batch-stat BN, dropout off) at 2x3x64x64 against the CPU
+    oracle differentiated by autograd: output, loss, and the direction of EVERY parameter gradient (cosine similarity;
+    bf16 stores activations AND gradient tensors in bf16 -- like autocast training -- and at this size the deep layers
+    normalise over 128 samples, so its gradients are compared by direction: measured median 0.98, worst 0.89 at the
+    bottleneck's gate MLP, whose arg-max / ReLU routing can flip under bf16 rounding)."""
+    from models.cdan import CDAN
+    from oracle import cdan_oracle as O
+    from oracle import params as P
+    sd = P.make_state_dict(42)
+    x, t = P.lowlight_batch(77, 2, 64, 64)
+    ref_sd = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v))
+              for k, v in sd.items()}
+    ry = O.cdan_forward(ref_sd, x.double(), "train", {})
+    rloss = torch.sqrt((ry - t.double()) ** 2 + 1e-6).mean()
+    rloss.backward()
+    net = CDAN(precision=precision)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    net.dropout_p = 0.0
+    y = net(x.cuda())
+    loss = torch.sqrt((y - t.cuda()) ** 2 + 1e-6).mean()
+    loss.backward()
+    assert rel_to_max(y, ry) <= out_tol
+    assert loss.item() == pytest.approx(rloss.item(), rel=out_tol)
+    worst, allcos = (1.0, None), []
+    for k, p in net.named_parameters():
+        g, r = p.grad.detach().double().cpu().reshape(-1), ref_sd[k].grad.reshape(-1)
+        if r.norm().item() < 1e-9 * max(1.0, float(r.numel()) ** 0.5):   # biases in front of a batch-stat BatchNorm: exact zeros
+            assert g.abs().max().item() <= 1e-6, k
+            continue
+        cos = float(torch.dot(g, r) / (g.norm() * r.norm()).clamp_min(1e-30))
+        allcos.append(cos)
+        if cos < worst[0]:
+            worst = (cos, k)
+    median = sorted(allcos)[len(allcos) // 2]
+    print(f"[{precision}] gradient cosine: median {median:.5f}, worst {worst[0]:.5f} at {worst[1]}")
+    assert worst[0] >= min_cos and median >= med_cos, (worst, median)
