@@ -169,9 +169,41 @@ class ImageFolder(Dataset):
         return self.tf(Image.open(self.files[i]))[0]
 
 
+# ---- one process per GPU: `python -m torch.distributed.run --nproc-per-node N run.py -c ... -p train` ------------
+def dist_env():
+    """(rank, world, local_rank) from torchrun's environment; (0, 1, 0) for a plain `python run.py`."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init_distributed(backend=None):
+    """Under torchrun: bind this process to its GPU and join the process group (RCCL over xGMI = backend "nccl";
+    "gloo" on a CPU-only host, which only the plumbing tests use).  No-op for a single process."""
+    import torch.distributed as dist
+    rank, world, local = dist_env()
+    if world <= 1 or (dist.is_available() and dist.is_initialized()):
+        return rank, world, local
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend or "nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend or "gloo")
+    return rank, world, local
+
+
 def make_dataloader(dataset, args):
+    """DataLoader of the reference (utils/parser.py:98-104); under torchrun every rank reads its own shard of the dataset
+    (DistributedSampler: same shuffle seed on all ranks, disjoint indices), batch_size stays the PER-GPU batch."""
     workers = int(args.get("num_workers", 0) or 0)
-    return DataLoader(dataset, batch_size=args["batch_size"], shuffle=bool(args.get("shuffle", False)), num_workers=workers,
+    rank, world, _ = dist_env()
+    shuffle = bool(args.get("shuffle", False))
+    sampler = None
+    if world > 1:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=shuffle, drop_last=False)
+        shuffle = False
+    return DataLoader(dataset, batch_size=args["batch_size"], shuffle=shuffle, sampler=sampler, num_workers=workers,
                       pin_memory=torch.cuda.is_available())
 
 
@@ -267,7 +299,10 @@ class Model:
     def __init__(self, network, *, config, dataloader, logger=None):
         self.config, self.phase = config, config["phase"]
         sect = config[self.phase]
+        self.rank, self.world, local = init_distributed()
         self.device = torch.device(sect["device"])
+        if self.world > 1 and self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", local)          # one process per GPU
         self.model_path, self.model_name = sect["model_path"], sect["model_name"]
         test = config.get("test") or {}
         self.is_dataset_paired = bool((test.get("dataset") or {}).get("is_paired", True))
@@ -309,12 +344,19 @@ class Model:
         if len(losses) == 0:
             raise ValueError("training needs at least one usable loss term")
         opt = torch.optim.Adam(self.network.parameters(), lr=lr)
-        buckets = T.GradBuckets(self.network.parameters()) if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if distributed:
+            # identical replicas: rank 0's parameters and buffers (the seed already makes them equal; this makes it certain)
+            for t in list(self.network.parameters()) + list(self.network.buffers()):
+                dist.broadcast(t.data, src=0)
+        buckets = T.GradBuckets(self.network.parameters()) if distributed else None
         best = float("inf")
         self.history = []
         for epoch in range(n_epoch):
             t0 = time.time()
             self.network.train()
+            if hasattr(getattr(self.dataloader, "sampler", None), "set_epoch"):
+                self.dataloader.sampler.set_epoch(epoch)       # a different shard shuffle every epoch
             sums, n = {}, 0
             for inputs, targets in self.dataloader:
                 x, y = self._to_device(inputs), self._to_device(targets)
@@ -329,15 +371,22 @@ class Model:
                 for k, v in zip(losses.names + ["total"], vals):
                     sums[k] = sums.get(k, 0.0) + v
                 n += 1
+            if distributed:   # epoch means over ALL ranks' batches, so every rank takes the same checkpoint decision
+                keys = sorted(sums)
+                tot = torch.tensor([sums[k] for k in keys] + [float(n)], dtype=torch.float64, device=self.device)
+                dist.all_reduce(tot)
+                sums, n = {k: float(v) for k, v in zip(keys, tot[:-1].tolist())}, int(tot[-1].item())
             avg = {k: v / max(1, n) for k, v in sums.items()}
+            main_rank = not distributed or dist.get_rank() == 0
             if avg["total"] < best:
                 best = avg["total"]
-                if not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0:
+                if main_rank:
                     self.save_model(self.network)
             self.history.append(avg)
-            print(f"Epoch [{epoch + 1}/{n_epoch}] Train total: {avg['total']:.4f} | " +
-                  ", ".join(f"{k}: {v:.4f}" for k, v in avg.items() if k != "total") + f" | best: {best:.4f}")
-            if self.logger is not None:
+            if main_rank:
+                print(f"Epoch [{epoch + 1}/{n_epoch}] Train total: {avg['total']:.4f} | " +
+                      ", ".join(f"{k}: {v:.4f}" for k, v in avg.items() if k != "total") + f" | best: {best:.4f}")
+            if self.logger is not None and main_rank:
                 row = {"type": "epoch", "epoch": epoch + 1, "epoch_time_sec": time.time() - t0, "lr": lr, "best_loss_so_far": best}
                 row.update({f"loss_{k}": v for k, v in avg.items()})
                 self.logger.log("train", row)

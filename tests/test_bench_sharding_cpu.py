@@ -82,3 +82,33 @@ def test_bucketed_gradient_allreduce_two_ranks():
         assert p.exitcode == 0
     for rank, ok, nb in res:
         assert ok and nb >= 2
+
+
+def _loader_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from mdie_amd import host as H
+    r, w, _ = H.init_distributed("gloo")          # what Model.__init__ does under torchrun (RCCL on a GPU node)
+    assert (r, w) == (rank, world) and dist.is_initialized()
+    data = torch.arange(10).float().reshape(10, 1)
+    loader = H.make_dataloader(torch.utils.data.TensorDataset(data), {"batch_size": 2, "shuffle": True, "num_workers": 0})
+    loader.sampler.set_epoch(0)
+    seen = sorted(int(v) for (b,) in loader for v in b.reshape(-1))
+    q.put((rank, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_driver_shards_the_dataset_under_torchrun_env():
+    """`run.py` under torchrun: every rank joins the group and reads a disjoint shard; together they cover the dataset"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_loader_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert len(res[0]) == len(res[1]) == 5 and sorted(res[0] + res[1]) == list(range(10))
