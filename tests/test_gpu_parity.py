@@ -1000,3 +1000,24 @@ def test_whole_network_training_step_vs_oracle(E, precision, min_cos, med_cos, o
     median = sorted(allcos)[len(allcos) // 2]
     print(f"[{precision}] gradient cosine: median {median:.5f}, worst {worst[0]:.5f} at {worst[1]}")
     assert worst[0] >= min_cos and median >= med_cos, (worst, median)
+
+
+def test_training_step_is_bitwise_reproducible(E):
+    """same seed, same batch -> bit-identical loss and gradients (ordered reductions everywhere, counter-based dropout)"""
+    from models.cdan import CDAN
+    from oracle import params as P
+    sd = P.make_state_dict(42)
+    x, t = P.lowlight_batch(5, 4, 64, 64)
+    x, t = x.cuda(), t.cuda()
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(123)
+        net = CDAN(precision="bf16")
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().train()
+        loss = torch.sqrt((net(x) - t) ** 2 + 1e-6).mean()
+        loss.backward()
+        runs.append((loss.detach().clone(), [p.grad.clone() for p in net.parameters()], [b.clone() for b in net.buffers()]))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
