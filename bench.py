@@ -235,7 +235,7 @@ def main():
                       "launch": "eager" if graph is None else "hipGraph replay"},
            "roofline": roofline}
 
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:   # the CPU leg is a single-GPU-run feature (rank 0 at N=1 only)
         nb = min(args.cpu_batch, B)
         ref, cb = cpu_baseline(sd, x_cpu[:nb])
         yc = y[:nb].float().cpu()
