@@ -961,8 +961,10 @@ def test_router_checkpoint_format_thresholds_and_routing(E, tmp_path):
         router.forward(x)                        # CPU tensor
 
 
-@pytest.mark.parametrize("precision,min_cos,med_cos,out_tol", [("fp32", 0.9999, 0.99999, 2e-4), ("bf16", 0.85, 0.97, 3e-2)])
-def test_whole_network_training_step_vs_oracle(E, precision, min_cos, med_cos, out_tol):
+@pytest.mark.parametrize("precision,shape,min_cos,med_cos,out_tol", [("fp32", (2, 64, 64), 0.9999, 0.99999, 2e-4),
+                                                                     ("fp32", (1, 40, 56), 0.9999, 0.99999, 2e-4),    # one image, ragged tiles
+                                                                     ("bf16", (2, 64, 64), 0.85, 0.97, 3e-2)])
+def test_whole_network_training_step_vs_oracle(E, precision, shape, min_cos, med_cos, out_tol):
     """forward + backward of the whole network in training mode (batch-stat BN, dropout off) at 2x3x64x64 against the CPU
     oracle differentiated by autograd: output, loss, and the direction of EVERY parameter gradient (cosine similarity;
     bf16 stores activations AND gradient tensors in bf16 -- like autocast training -- and at this size the deep layers
@@ -972,7 +974,7 @@ def test_whole_network_training_step_vs_oracle(E, precision, min_cos, med_cos, o
     from oracle import cdan_oracle as O
     from oracle import params as P
     sd = P.make_state_dict(42)
-    x, t = P.lowlight_batch(77, 2, 64, 64)
+    x, t = P.lowlight_batch(77, *shape)
     ref_sd = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v))
               for k, v in sd.items()}
     ry = O.cdan_forward(ref_sd, x.double(), "train", {})
