@@ -1023,3 +1023,19 @@ def test_training_step_is_bitwise_reproducible(E):
     assert torch.equal(runs[0][0], runs[1][0])
     assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
     assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 8), (3, 8, 16), (2, 16, 8), (5, 24, 40), (1, 72, 8), (2, 8, 136)])
+def test_small_and_ragged_extents_against_oracle(E, net, shape):
+    """smallest legal extents (the bottleneck is 1x1 at 8x8 input), odd batch sizes, strongly non-square pictures"""
+    from oracle import cdan_oracle as O
+    from oracle import params as P
+    x, _ = P.lowlight_batch(sum(shape), *shape)
+    with torch.no_grad():
+        ref = O.cdan_forward(P.make_state_dict(42), x)
+        net.precision = "fp32"
+        y = net(x.cuda())
+        assert rel_to_max(y, ref) <= CONTRACT_TOL
+        net.precision = "bf16"
+        yb = net(x.cuda())
+    assert rel_to_max(yb, ref) <= BF16_TOL
