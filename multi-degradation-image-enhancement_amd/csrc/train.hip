@@ -4,12 +4,15 @@
 //          convolution of dY with the flipped, in/out-transposed weights, i.e. mdie_conv_fwd on weights
 //          packed with the opposite `transposed` flag (mdie_pack_conv_weight_dev below repacks on the GPU
 //          every step, since the weights change every step).
-//   wgrad  dW[tap][c][o] = sum over pixels X[p + tap][c] * dY[p][o]: a GEMM whose K dimension is the
-//          pixel index.  In NHWC both operands have the CHANNEL contiguous, which is exactly the
-//          operand shape of the exact-f32 MFMA v_mfma_f32_16x16x4_f32 (lane l holds row l&15 = channel,
-//          k = l>>4 = one of 4 consecutive pixels): no transposes, fp32 accumulation, bf16 inputs are
-//          widened on load.  Pixels are split over workgroups; partial sums go to a scratch slab per
-//          split and a second kernel folds them in a fixed order (deterministic, no float atomics).
+//   wgrad  dW[tap][c][o] = sum over pixels X[p + tap][c] * dY[p][o]: a GEMM whose K dimension is the pixel index.
+//          A workgroup owns a (channel tile x output tile) of all 9 taps and walks a run of 16x16-pixel tiles: the X
+//          patch (with halo) and the dY tile are staged once per tile in their natural NHWC layout (planes of 16
+//          channels, one row per pixel) and serve every tap at an immediate byte offset.  bf16 reads its operands with
+//          the transposing ds_read_b64_tr_b16 into v_mfma_f32_16x16x32_bf16; fp32 reads one float per lane into the
+//          exact-f32 v_mfma_f32_16x16x4_f32.  Accumulators stay in registers over the whole run; each pixel split
+//          writes a scratch slab and a second kernel folds the splits in a fixed order (no float atomics).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mdie {
@@ -52,120 +55,6 @@ __global__ __launch_bounds__(TR_THREADS) void pack_weight_kernel(int ks, int tra
 }
 
 // ---- wgrad ------------------------------------------------------------------------------------------------------------
-struct WgradArgs {
-  int B, H, W, ks;
-  int nseg;
-  SegT seg[MDIE_MAX_SEG];
-  int cin_st, cout_st;
-  const char* dy; int dy_stride;
-  float* scratch;          // [splits][taps][cin_st][cout_st]
-  int splits, groups_per_split;   // pixel groups of 4
-  const float *pre_scale, *pre_shift;   // optional: the conv input was relu(x * pre_scale + pre_shift)
-};
-
-__device__ __forceinline__ float ldf(const float* p) { return *p; }
-__device__ __forceinline__ float ldf(const bf16* p) { return (float)*p; }
-
-// grid (o_tiles * c_tiles, taps, splits); workgroup = 64 stored input channels x (16*NOS) output channels of one tap
-template <typename T, int NOS>
-__global__ __launch_bounds__(TR_THREADS) void wgrad_kernel(const WgradArgs a) {
-  __shared__ float red[TR_THREADS / 64 - 1][4][NOS][64][4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lp = lane & 15;
-  const int o_tiles = a.cout_st / (16 * NOS);
-  const int ot = blockIdx.x % o_tiles, ct = blockIdx.x / o_tiles;
-  const int tap = blockIdx.y, split = blockIdx.z;
-  const int pad = a.ks / 2;
-  const int dyk = tap / a.ks - pad, dxk = tap % a.ks - pad;
-  const int c0 = ct * 64, o0 = ot * 16 * NOS;
-
-  // channel group cs of this lane: segment base pointer (or null beyond cin_st)
-  const T* xb[4];
-  int xs[4];
-#pragma unroll
-  for (int cs = 0; cs < 4; ++cs) {
-    const int c = c0 + cs * 16 + lp;
-    xb[cs] = nullptr; xs[cs] = 0;
-#pragma unroll
-    for (int s = 0; s < MDIE_MAX_SEG; ++s)
-      if (s < a.nseg && c >= a.seg[s].ch_begin && c < a.seg[s].ch_end) {
-        xb[cs] = reinterpret_cast<const T*>(a.seg[s].ptr) + (c - a.seg[s].ch_begin);
-        xs[cs] = a.seg[s].stride;
-      }
-  }
-  const T* dyb = reinterpret_cast<const T*>(a.dy) + o0 + lp;
-  float psc[4], psh[4];
-#pragma unroll
-  for (int cs = 0; cs < 4; ++cs) {
-    const int c = c0 + cs * 16 + lp;
-    psc[cs] = (a.pre_scale && c < a.cin_st) ? a.pre_scale[c] : 1.f;
-    psh[cs] = (a.pre_scale && c < a.cin_st) ? a.pre_shift[c] : 0.f;
-  }
-
-  f32x4 acc[4][NOS];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NOS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int npix = a.B * a.H * a.W;
-  const int g_begin = split * a.groups_per_split, g_end = min(g_begin + a.groups_per_split, (npix + 3) / 4);
-  for (int g = g_begin + wave; g < g_end; g += TR_THREADS / 64) {
-    const int p = g * 4 + lq;                  // this lane's pixel (k index of the MFMA)
-    float av[4], bv[NOS];
-#pragma unroll
-    for (int cs = 0; cs < 4; ++cs) av[cs] = 0.f;
-#pragma unroll
-    for (int os = 0; os < NOS; ++os) bv[os] = 0.f;
-    if (p < npix) {
-      const int img = p / (a.H * a.W);
-      const int rem = p - img * a.H * a.W;
-      const int y = rem / a.W, x = rem - y * a.W;
-      const int yy = y + dyk, xx = x + dxk;
-#pragma unroll
-      for (int os = 0; os < NOS; ++os) bv[os] = ldf(dyb + (size_t)p * a.dy_stride + os * 16);
-      if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-        const size_t q = ((size_t)img * a.H + yy) * a.W + xx;
-#pragma unroll
-        for (int cs = 0; cs < 4; ++cs)
-          if (xb[cs]) {
-            av[cs] = ldf(xb[cs] + q * xs[cs]);
-            if (a.pre_scale) av[cs] = fmaxf(fmaf(av[cs], psc[cs], psh[cs]), 0.f);
-          }
-      }
-    }
-#pragma unroll
-    for (int cs = 0; cs < 4; ++cs)
-#pragma unroll
-      for (int os = 0; os < NOS; ++os)
-        acc[cs][os] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cs], bv[os], acc[cs][os], 0, 0, 0);
-  }
-  // fold the 4 waves (fixed order), then write this split's slab
-  if (wave > 0) {
-#pragma unroll
-    for (int cs = 0; cs < 4; ++cs)
-#pragma unroll
-      for (int os = 0; os < NOS; ++os)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave - 1][cs][os][lane][r] = acc[cs][os][r];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float* out = a.scratch + (((size_t)split * gridDim.y + tap) * a.cin_st) * a.cout_st;
-#pragma unroll
-    for (int cs = 0; cs < 4; ++cs)
-#pragma unroll
-      for (int os = 0; os < NOS; ++os)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[cs][os][r];
-          for (int w = 0; w < TR_THREADS / 64 - 1; ++w) v += red[w][cs][os][lane][r];
-          // D[row = 4*lq + r = channel within the 16-group][col = lp = output channel]
-          const int c = c0 + cs * 16 + lq * 4 + r, o = o0 + os * 16 + lp;
-          if (c < a.cin_st) out[(size_t)c * a.cout_st + o] = v;
-        }
-  }
-}
-
 // fold the splits and scatter into PyTorch's layout (dropping padded channels):
 //   transposed = 0: dw[o][c][kh][kw]             (nn.Conv2d)
 //   transposed = 1: dw[c][o][ks-1-kh][ks-1-kw]   (nn.ConvTranspose2d run as a flipped convolution)
@@ -427,6 +316,179 @@ __global__ __launch_bounds__(TR_THREADS, 2) void wgrad_tile_kernel(const WgradTi
   }
 }
 
+// ---- wgrad, fp32: the same tiling on the exact-f32 MFMA v_mfma_f32_16x16x4_f32 ------------------------------------------------
+// Operand of lane l: row (l & 15) = channel, k = (l >> 4) = one of 4 consecutive pixels -- one float, read with a plain
+// ds_read_b32 from the same planar image (planes of 16 channels, 64-byte rows): 16 lanes x 4 rows = 256 contiguous bytes
+// per read, a tap is an immediate offset.  The MFMA is 16x slower than the bf16 one, so this kernel is matrix-pipe bound
+// (2304 MFMAs of 32 cycles per wave per 16x16-pixel tile) and one workgroup per CU (148 KiB of LDS) is enough.
+template <int NTAP> struct WgGeomF {
+  static constexpr int PAD = NTAP == 9 ? 1 : 0;
+  static constexpr int PWD = WT + 2 * PAD;
+  static constexpr int PROWS = PWD * PWD;
+  static constexpr int XPLANE = PROWS * 64 + 64;
+  static constexpr int YPLANE = WT * WT * 64;
+};
+
+template <int NTAP, int CSW, int OSW, int WC, int WO, bool PRE>
+__global__ __launch_bounds__(TR_THREADS, 1) void wgrad_tile_f32_kernel(const WgradTileArgs a) {
+  using G = WgGeomF<NTAP>;
+  constexpr int KS = NTAP == 9 ? 3 : 1;
+  constexpr int NCS_T = CSW * WC, NOS_T = OSW * WO;
+  constexpr int UPX = NCS_T * 4, UPY = NOS_T * 4;             // 16-byte units (4 floats) per pixel
+  constexpr int X_UNITS = G::PROWS * UPX, Y_UNITS = WT * WT * UPY;
+  constexpr int X_IT = (X_UNITS + TR_THREADS - 1) / TR_THREADS, Y_IT = (Y_UNITS + TR_THREADS - 1) / TR_THREADS;
+  constexpr int XB = X_IT > 8 ? 8 : X_IT, YB = Y_IT > 8 ? 8 : Y_IT;
+  constexpr int X_PPI = TR_THREADS / UPX, Y_PPI = TR_THREADS / UPY;
+  static_assert(WC * WO == TR_THREADS / 64, "wave grid");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_x = smem;
+  char* lds_y = smem + NCS_T * G::XPLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave % WC, wo = wave / WC;
+  const int ot = blockIdx.x % a.o_tiles, ct = blockIdx.x / a.o_tiles;
+  const int c0 = ct * NCS_T * 16, o0 = ot * NOS_T * 16;
+  const int split = blockIdx.y;
+
+  const int xchunk = tid % UPX;                      // this thread's 4-channel column of the c-tile
+  const char* xbase = nullptr; int xstride = 0;
+  {
+    const int c = c0 + xchunk * 4;
+#pragma unroll
+    for (int s = 0; s < MDIE_MAX_SEG; ++s)
+      if (s < a.nseg && c >= a.seg[s].ch_begin && c < a.seg[s].ch_end) {
+        xbase = a.seg[s].ptr + (size_t)(c - a.seg[s].ch_begin) * 4;
+        xstride = a.seg[s].stride * 4;
+      }
+  }
+  const int xdst0 = (xchunk >> 2) * G::XPLANE + (xchunk & 3) * 16;
+  const bool has_pre = PRE && xbase != nullptr;
+  const int ychunk = tid % UPY;
+  const bool ylive = o0 + ychunk * 4 < a.cout_st;
+  const char* ybase = a.dy + (size_t)(o0 + ychunk * 4) * 4;
+  const int ydst0 = (ychunk >> 2) * G::YPLANE + (ychunk & 3) * 16;
+
+  const int kq = lane >> 4, m = lane & 15;
+  const char* xrd = lds_x + (wc * CSW) * G::XPLANE + kq * 64 + m * 4;
+  const char* yrd = lds_y + (wo * OSW) * G::YPLANE + kq * 64 + m * 4;
+  const bool wave_live = c0 + wc * CSW * 16 < a.cin_st && o0 + wo * OSW * 16 < a.cout_st;
+
+  f32x4 acc[NTAP][CSW][OSW];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int i = 0; i < CSW; ++i)
+#pragma unroll
+      for (int j = 0; j < OSW; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int t_begin = split * a.tiles_per_split, t_end = min(t_begin + a.tiles_per_split, a.total_tiles);
+  const int tpi = a.tiles_x * a.tiles_y;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int img = tile / tpi;
+    const int trem = tile - img * tpi;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int y0 = ty * WT, x0 = tx * WT;
+    const size_t ibase = (size_t)img * a.H * a.W;
+    if (tile > t_begin) __syncthreads();
+    {
+      int pix = tid / UPX;
+      int py = pix / G::PWD, px = pix - py * G::PWD;
+      float psc[4] = {1.f, 1.f, 1.f, 1.f}, psh[4] = {0.f, 0.f, 0.f, 0.f};
+      if (has_pre) {
+        const float4 s4 = *reinterpret_cast<const float4*>(a.pre_scale + c0 + xchunk * 4), b4 = *reinterpret_cast<const float4*>(a.pre_shift + c0 + xchunk * 4);
+        psc[0] = s4.x; psc[1] = s4.y; psc[2] = s4.z; psc[3] = s4.w; psh[0] = b4.x; psh[1] = b4.y; psh[2] = b4.z; psh[3] = b4.w;
+      }
+#pragma unroll 1
+      for (int b0 = 0; b0 < X_IT; b0 += XB) {
+        float4 v[XB];
+        int dsts[XB];
+#pragma unroll
+        for (int j = 0; j < XB; ++j) {
+          const int gy = y0 + py - G::PAD, gx = x0 + px - G::PAD;
+          const bool in_patch = b0 + j < X_IT && py < G::PWD;
+          const bool ok = in_patch && xbase != nullptr && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+          v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) {
+            v[j] = *reinterpret_cast<const float4*>(xbase + (ibase + (size_t)gy * a.W + gx) * xstride);
+            if (has_pre) {   // pre-activation BN + ReLU of the dense layers; the zero padding stays zero
+              v[j].x = fmaxf(fmaf(v[j].x, psc[0], psh[0]), 0.f); v[j].y = fmaxf(fmaf(v[j].y, psc[1], psh[1]), 0.f);
+              v[j].z = fmaxf(fmaf(v[j].z, psc[2], psh[2]), 0.f); v[j].w = fmaxf(fmaf(v[j].w, psc[3], psh[3]), 0.f);
+            }
+          }
+          dsts[j] = in_patch ? xdst0 + (py * G::PWD + px) * 64 : -1;
+          px += X_PPI % G::PWD; py += X_PPI / G::PWD;
+          if (px >= G::PWD) { px -= G::PWD; py += 1; }
+        }
+#pragma unroll
+        for (int j = 0; j < XB; ++j)
+          if (dsts[j] >= 0) *reinterpret_cast<float4*>(lds_x + dsts[j]) = v[j];
+      }
+    }
+    {
+      int pix = tid / UPY;
+#pragma unroll 1
+      for (int b0 = 0; b0 < Y_IT; b0 += YB) {
+        float4 v[YB];
+        int pp[YB];
+#pragma unroll
+        for (int j = 0; j < YB; ++j) {
+          const int py = pix >> 4, px = pix & 15;
+          const int gy = y0 + py, gx = x0 + px;
+          v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          pp[j] = (b0 + j < Y_IT && pix < WT * WT) ? pix : -1;
+          if (pp[j] >= 0 && ylive && gy < a.H && gx < a.W)
+            v[j] = *reinterpret_cast<const float4*>(ybase + (ibase + (size_t)gy * a.W + gx) * a.dy_stride * 4);
+          pix += Y_PPI;
+        }
+#pragma unroll
+        for (int j = 0; j < YB; ++j)
+          if (pp[j] >= 0) *reinterpret_cast<float4*>(lds_y + ydst0 + pp[j] * 64) = v[j];
+      }
+    }
+    __syncthreads();
+
+    if (wave_live) {
+#pragma unroll 1
+      for (int ky = 0; ky < WT; ++ky) {
+        const char* xr = xrd + ky * G::PWD * 64;
+        const char* yr = yrd + ky * WT * 64;
+#pragma unroll
+        for (int kx = 0; kx < WT / 4; ++kx) {
+          float bfv[OSW];
+#pragma unroll
+          for (int os = 0; os < OSW; ++os) bfv[os] = *reinterpret_cast<const float*>(yr + os * G::YPLANE + kx * 4 * 64);
+#pragma unroll
+          for (int t = 0; t < NTAP; ++t) {
+            const int kh = t / KS, kw = t - kh * KS;
+#pragma unroll
+            for (int cs = 0; cs < CSW; ++cs) {
+              const float af = *reinterpret_cast<const float*>(xr + cs * G::XPLANE + (kh * G::PWD + kx * 4 + kw) * 64);
+#pragma unroll
+              for (int os = 0; os < OSW; ++os) acc[t][cs][os] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bfv[os], acc[t][cs][os], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (wave_live) {
+    float* out = a.scratch + (size_t)split * NTAP * a.cin_st * a.cout_st;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+      for (int cs = 0; cs < CSW; ++cs)
+#pragma unroll
+        for (int os = 0; os < OSW; ++os)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = c0 + (wc * CSW + cs) * 16 + kq * 4 + r, o = o0 + (wo * OSW + os) * 16 + m;
+            if (c < a.cin_st && o < a.cout_st) out[((size_t)t * a.cin_st + c) * a.cout_st + o] = acc[t][cs][os][r];
+          }
+  }
+}
+
 struct WgTilePlan { int cfg, c_tile, o_tile, c_tiles, o_tiles, splits, tiles_per_split, total_tiles, tiles_x, tiles_y; };
 
 // cfg 0: 64c x 64o (2x2 waves of 32x32); 1: 64c x 16o (cout-thin); 2: 16c x 64o (cin-thin)
@@ -455,6 +517,24 @@ static void launch_wgrad_tile_t(const WgradTileArgs& a, const WgTilePlan& p, hip
   static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
   if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   hipLaunchKernelGGL(kern, dim3(p.c_tiles * p.o_tiles, p.splits), dim3(TR_THREADS), lds, s, a);
+}
+
+template <int NTAP, int CSW, int OSW, int WC, int WO>
+static void launch_wgrad_tile_f32(const WgradTileArgs& a, const WgTilePlan& p, hipStream_t s) {
+  using G = WgGeomF<NTAP>;
+  const size_t lds = (size_t)CSW * WC * G::XPLANE + (size_t)OSW * WO * G::YPLANE;
+  const dim3 grid(p.c_tiles * p.o_tiles, p.splits);
+  if (a.pre_scale) {
+    auto kern = wgrad_tile_f32_kernel<NTAP, CSW, OSW, WC, WO, true>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(TR_THREADS), lds, s, a);
+  } else {
+    auto kern = wgrad_tile_f32_kernel<NTAP, CSW, OSW, WC, WO, false>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(TR_THREADS), lds, s, a);
+  }
 }
 
 // the pre-activation prologue is a separate instantiation: its 16 extra live registers would push the
@@ -490,23 +570,9 @@ extern "C" int mdie_pack_conv_weight_dev(int dtype, int ksize, int transposed, c
   return MDIE_OK;
 }
 
-static int wgrad_splits(int B, int H, int W, int base_wgs) {
-  const long groups = ((long)B * H * W + 3) / 4;
-  long s = 2048 / (base_wgs > 0 ? base_wgs : 1);      // aim for ~2k workgroups
-  if (s < 1) s = 1;
-  if (s > 256) s = 256;
-  if (s > groups / 16) s = groups / 16 > 0 ? groups / 16 : 1;   // at least 64 pixels per wave-quartet
-  return (int)s;
-}
-
 extern "C" size_t mdie_conv_wgrad_workspace_bytes(int B, int H, int W, int ksize, int cin_stored, int cout_stored) {
   if (B <= 0 || H <= 0 || W <= 0 || cin_stored <= 0 || cout_stored <= 0) return 0;
-  const int nos = cout_stored % 64 == 0 ? 4 : 1;
-  const int base = (cout_stored / (16 * nos)) * cdiv(cin_stored, 64) * ksize * ksize;
-  const size_t slab = (size_t)ksize * ksize * cin_stored * cout_stored * sizeof(float);
-  const size_t f32_need = (size_t)wgrad_splits(B, H, W, base) * slab;
-  const size_t bf16_need = (size_t)wgrad_tile_plan(B, H, W, cin_stored, cout_stored).splits * slab;
-  return f32_need > bf16_need ? f32_need : bf16_need;   // the query is dtype-agnostic
+  return (size_t)wgrad_tile_plan(B, H, W, cin_stored, cout_stored).splits * ksize * ksize * cin_stored * cout_stored * sizeof(float);
 }
 
 extern "C" int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream) {
@@ -517,70 +583,46 @@ extern "C" int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream) {
   MDIE_REQUIRE(d->nseg >= 1 && d->nseg <= MDIE_MAX_SEG, "mdie_conv_wgrad: nseg %d", d->nseg);
   MDIE_REQUIRE(d->dy && d->dw && d->workspace && d->cout > 0 && d->cin > 0, "mdie_conv_wgrad: null/empty");
   MDIE_REQUIRE(d->cout_stored % 16 == 0 && d->cout_stored >= d->cout && d->dy_stride >= d->cout_stored, "mdie_conv_wgrad: cout_stored %d", d->cout_stored);
-  WgradArgs a{};
-  a.B = d->B; a.H = d->H; a.W = d->W; a.ks = d->ksize;
-  a.nseg = d->nseg;
+  MDIE_REQUIRE((d->pre_scale == nullptr) == (d->pre_shift == nullptr), "mdie_conv_wgrad: pre_scale / pre_shift must both be given or both be null");
+  WgradTileArgs t{};
+  t.B = d->B; t.H = d->H; t.W = d->W; t.nseg = d->nseg;
   int c = 0;
   for (int s = 0; s < d->nseg; ++s) {
     MDIE_REQUIRE(d->in[s].ptr && d->in[s].channels > 0 && d->in[s].channels % 16 == 0, "mdie_conv_wgrad: segment %d channels %d", s, d->in[s].channels);
-    a.seg[s].ptr = reinterpret_cast<const char*>(d->in[s].ptr);
-    a.seg[s].ch_begin = c; c += d->in[s].channels; a.seg[s].ch_end = c;
-    a.seg[s].stride = d->in[s].stride;
+    t.seg[s].ptr = reinterpret_cast<const char*>(d->in[s].ptr);
+    t.seg[s].ch_begin = c; c += d->in[s].channels; t.seg[s].ch_end = c;
+    t.seg[s].stride = d->in[s].stride;
   }
-  a.cin_st = c; a.cout_st = d->cout_stored;
   MDIE_REQUIRE(c >= d->cin + (d->split < d->cin ? d->gap : 0), "mdie_conv_wgrad: segments hold %d channels < cin %d + gap", c, d->cin);
-  a.dy = reinterpret_cast<const char*>(d->dy); a.dy_stride = d->dy_stride;
-  a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift;
-  MDIE_REQUIRE((d->pre_scale == nullptr) == (d->pre_shift == nullptr), "mdie_conv_wgrad: pre_scale / pre_shift must both be given or both be null");
   const int taps = d->ksize * d->ksize;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d->dtype == MDIE_BF16) {
-    const WgTilePlan p = wgrad_tile_plan(d->B, d->H, d->W, c, d->cout_stored);
-    const size_t need = (size_t)p.splits * taps * c * d->cout_stored * sizeof(float);
-    if (d->workspace_bytes < need) { set_error("mdie_conv_wgrad: workspace %zu < %zu", d->workspace_bytes, need); return MDIE_ENOSPC; }
-    WgradTileArgs t{};
-    t.B = d->B; t.H = d->H; t.W = d->W; t.nseg = a.nseg;
-    for (int i = 0; i < a.nseg; ++i) t.seg[i] = a.seg[i];
-    t.cin_st = c; t.cout_st = d->cout_stored; t.dy = a.dy; t.dy_stride = a.dy_stride;
-    t.scratch = reinterpret_cast<float*>(d->workspace);
-    t.pre_scale = d->pre_scale; t.pre_shift = d->pre_shift;
-    t.tiles_x = p.tiles_x; t.tiles_y = p.tiles_y; t.total_tiles = p.total_tiles; t.tiles_per_split = p.tiles_per_split; t.o_tiles = p.o_tiles;
-    if (taps == 9) {
-      if (p.cfg == 0) launch_wgrad_tile<9, 2, 2, 2, 2>(t, p, s);
-      else if (p.cfg == 1) launch_wgrad_tile<9, 1, 1, 4, 1>(t, p, s);
-      else launch_wgrad_tile<9, 1, 1, 1, 4>(t, p, s);
-    } else {
-      if (p.cfg == 0) launch_wgrad_tile<1, 2, 2, 2, 2>(t, p, s);
-      else if (p.cfg == 1) launch_wgrad_tile<1, 1, 1, 4, 1>(t, p, s);
-      else launch_wgrad_tile<1, 1, 1, 1, 4>(t, p, s);
-    }
-    MDIE_LAUNCH_CHECK("mdie_conv_wgrad");
-    const size_t total = (size_t)taps * c * d->cout_stored;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(TR_THREADS), 0, s, p.splits, d->ksize, d->transposed, d->cout, d->cin,
-                       d->cout_stored, c, d->split, d->gap, t.scratch, d->dw);
-    MDIE_LAUNCH_CHECK("mdie_conv_wgrad");
-    return MDIE_OK;
-  }
-  const int nos = d->cout_stored % 64 == 0 ? 4 : 1;
-  const int o_tiles = d->cout_stored / (16 * nos), c_tiles = cdiv(c, 64);
-  a.splits = wgrad_splits(d->B, d->H, d->W, o_tiles * c_tiles * taps);
-  const long groups = ((long)d->B * d->H * d->W + 3) / 4;
-  a.groups_per_split = (int)((groups + a.splits - 1) / a.splits);
-  const size_t need = (size_t)a.splits * taps * c * d->cout_stored * sizeof(float);
+  const WgTilePlan p = wgrad_tile_plan(d->B, d->H, d->W, c, d->cout_stored);
+  const size_t need = (size_t)p.splits * taps * c * d->cout_stored * sizeof(float);
   if (d->workspace_bytes < need) { set_error("mdie_conv_wgrad: workspace %zu < %zu", d->workspace_bytes, need); return MDIE_ENOSPC; }
-  a.scratch = reinterpret_cast<float*>(d->workspace);
-  const dim3 grid(o_tiles * c_tiles, taps, a.splits);
-  if (d->dtype == MDIE_F32) {
-    if (nos == 4) hipLaunchKernelGGL((wgrad_kernel<float, 4>), grid, dim3(TR_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<float, 1>), grid, dim3(TR_THREADS), 0, s, a);
-  } else {
-    if (nos == 4) hipLaunchKernelGGL((wgrad_kernel<mdie::bf16, 4>), grid, dim3(TR_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<mdie::bf16, 1>), grid, dim3(TR_THREADS), 0, s, a);
-  }
+  t.cin_st = c; t.cout_st = d->cout_stored;
+  t.dy = reinterpret_cast<const char*>(d->dy); t.dy_stride = d->dy_stride;
+  t.scratch = reinterpret_cast<float*>(d->workspace);
+  t.pre_scale = d->pre_scale; t.pre_shift = d->pre_shift;
+  t.tiles_x = p.tiles_x; t.tiles_y = p.tiles_y; t.total_tiles = p.total_tiles; t.tiles_per_split = p.tiles_per_split; t.o_tiles = p.o_tiles;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define MDIE_WG(LAUNCH)                                                \
+  do {                                                                 \
+    if (taps == 9) {                                                   \
+      if (p.cfg == 0) LAUNCH<9, 2, 2, 2, 2>(t, p, s);                  \
+      else if (p.cfg == 1) LAUNCH<9, 1, 1, 4, 1>(t, p, s);             \
+      else LAUNCH<9, 1, 1, 1, 4>(t, p, s);                             \
+    } else {                                                           \
+      if (p.cfg == 0) LAUNCH<1, 2, 2, 2, 2>(t, p, s);                  \
+      else if (p.cfg == 1) LAUNCH<1, 1, 1, 4, 1>(t, p, s);             \
+      else LAUNCH<1, 1, 1, 1, 4>(t, p, s);                             \
+    }                                                                  \
+  } while (0)
+  if (d->dtype == MDIE_F32) MDIE_WG(launch_wgrad_tile_f32);
+  else MDIE_WG(launch_wgrad_tile);
+#undef MDIE_WG
   MDIE_LAUNCH_CHECK("mdie_conv_wgrad");
   const size_t total = (size_t)taps * c * d->cout_stored;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(TR_THREADS), 0, s, a.splits, d->ksize, d->transposed, d->cout, d->cin, d->cout_stored, c,
-                     d->split, d->gap, a.scratch, d->dw);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(TR_THREADS), 0, s, p.splits, d->ksize, d->transposed, d->cout, d->cin,
+                     d->cout_stored, c, d->split, d->gap, t.scratch, d->dw);
   MDIE_LAUNCH_CHECK("mdie_conv_wgrad");
   return MDIE_OK;
 }
