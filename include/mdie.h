@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 14
+#define MDIE_ABI_VERSION 15
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -87,9 +87,15 @@ typedef struct {
   int out_stride;
   float* out_nchw3;        /* optional: instead of `out`, write output channels 0..2 as fp32 NCHW [B,3,Ho,Wo]
                               (the network's final tensor, models/cdan.py:157); cout must be 16 */
+  float* pool_partial;     /* optional (3x3, cout % 64 == 0, ReLU, no max-pool): additionally emit the channel sums and
+                              maxima of the tensor written, [B][tiles per image][2][cout] with tiles of edge
+                              mdie_conv_tile(B,H,W,cout) in raster order -- the global pools of the CBAM that consumes
+                              it (models/cbam.py:41,44; mdie_cbam_desc.pool_partial) fused into their producer */
 } mdie_conv_desc;
 
 int mdie_conv_fwd(const mdie_conv_desc* d, void* stream);
+/* tile edge (8 or 16) mdie_conv_fwd picks for this shape: pool_partial has ceil(H/t) * ceil(W/t) slabs per image */
+int mdie_conv_tile(int B, int H, int W, int cout);
 
 /* Host-side packing of one convolution weight (fp32, PyTorch layout) into the layout
  * mdie_conv_fwd reads: [cin_chunk][q][tap][cout_pad][16 bytes], where a chunk is 64 bytes of

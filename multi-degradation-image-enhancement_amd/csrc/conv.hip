@@ -58,6 +58,7 @@ struct ConvArgs {
   const float* pre_scale;
   const float* pre_shift;
   const char* weight;
+  float* pool_partial;   // STATS kernels: [B][tiles per image][2][cout] channel sums / maxima of the output
   EpiArgs e;
 };
 
@@ -98,9 +99,10 @@ template <int ACT> __device__ __forceinline__ float act_fn(float v) {
   else return v;
 }
 
-template <typename T, int NCS, int NPS, int TILE, int ACT, bool POOL>
+template <typename T, int NCS, int NPS, int TILE, int ACT, bool POOL, bool STATS = false>
 __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (&esc)[NCS], const float4 (&esh)[NCS],
-                                                f32x4 (&acc)[NCS][NPS], int img, int y0, int x0, int n0, int ps_base, int lq, int lp) {
+                                                f32x4 (&acc)[NCS][NPS], int img, int y0, int x0, int n0, int ps_base, int lq, int lp,
+                                                float (*st_sum)[4] = nullptr, float (*st_max)[4] = nullptr) {
   const int Ho = POOL ? e.H >> 1 : e.H, Wo = POOL ? e.W >> 1 : e.W;
 #pragma unroll
   for (int ps = 0; ps < NPS; ++ps) {
@@ -140,6 +142,15 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
         if (rrow) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] += ld(rrow + cs * 16 + i);
+        }
+        if constexpr (STATS) {   // channel sums / maxima of the STORED values: what a separate pooling pass over `out` would read
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float qv = v[i];
+            if constexpr (sizeof(T) == 2) qv = (float)(bf16)qv;
+            st_sum[cs][i] += qv;
+            st_max[cs][i] = fmaxf(st_max[cs][i], qv);
+          }
         }
         if constexpr (sizeof(T) == 4) {
           *reinterpret_cast<float4*>(orow + cs * 16) = make_float4(v[0], v[1], v[2], v[3]);
@@ -190,7 +201,7 @@ constexpr int conv_min_waves(int BN, int TILE) { return BN == 16 ? 4 : (TILE == 
 // that is not a load, an LDS access or an MFMA is kept off the hot path: 3-D grid instead of index
 // division, incremental patch coordinates, remainder staging iterations under a wave-uniform branch,
 // epilogue constants prefetched at kernel entry.
-template <typename T, int KS, int BN, int TILE>
+template <typename T, int KS, int BN, int TILE, bool STATS = false>
 __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_kernel(const ConvArgs a) {
   using G = ConvGeom<KS, BN, TILE>;
 #ifdef EXP_STAMPS
@@ -407,7 +418,50 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
   if (dbg) { e2.residual = nullptr; e2.res_stride = 0; }
   conv_epilogue<T, NCS, NPS, TILE>(e2, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp);
 #else
-  conv_epilogue<T, NCS, NPS, TILE>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp);
+  if constexpr (!STATS) {
+    conv_epilogue<T, NCS, NPS, TILE>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp);
+  } else {
+    // The tensor this convolution writes feeds a CBAM whose first pass is a global average / max pool over H*W
+    // (models/cbam.py:41,44): emit this tile's per-channel sum and maximum while the values are in registers, one
+    // partial per (image, tile) -- the gate folds the tiles in order (deterministic, independent of the batch).
+    float st_sum[NCS][4], st_max[NCS][4];
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { st_sum[cs][i] = 0.f; st_max[cs][i] = -INFINITY; }
+    conv_epilogue_t<T, NCS, NPS, TILE, MDIE_ACT_RELU, false, true>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp, st_sum, st_max);
+    // over the 16 pixel lanes of a row (same lq = same 4 channels) ...
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) {
+          st_sum[cs][i] += __shfl_xor(st_sum[cs][i], d);
+          st_max[cs][i] = fmaxf(st_max[cs][i], __shfl_xor(st_max[cs][i], d));
+        }
+    // ... then over the 4 waves through LDS (the patch image is dead once every wave is past its last MFMA)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);           // [wave][2][BN]
+    if (lp == 0) {
+#pragma unroll
+      for (int cs = 0; cs < NCS; ++cs)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          red[(wave * 2 + 0) * BN + cs * 16 + lq * 4 + i] = st_sum[cs][i];
+          red[(wave * 2 + 1) * BN + cs * 16 + lq * 4 + i] = st_max[cs][i];
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float ss = 0.f, mm = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < CONV_THREADS / 64; ++w) { ss += red[(w * 2 + 0) * BN + tid]; mm = fmaxf(mm, red[(w * 2 + 1) * BN + tid]); }
+      float* dst = a.pool_partial + ((size_t)img * tpi + trem) * 2 * a.cout + n0 + tid;
+      dst[0] = ss;
+      dst[a.cout] = mm;
+    }
+  }
 #endif
   STAMP(12);
 }
@@ -660,7 +714,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_first_kernel(const FirstArg
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------
-template <typename T, int KS, int BN, int TILE>
+template <typename T, int KS, int BN, int TILE, bool STATS = false>
 static int launch_conv(ConvArgs& a, hipStream_t stream) {
   using G = ConvGeom<KS, BN, TILE>;
   a.tiles_x = cdiv(a.W, TILE); a.tiles_y = cdiv(a.H, TILE);
@@ -672,12 +726,12 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   const dim3 grid(8, a.n_tiles, cdiv(a.tiles_x * a.tiles_y * a.B, 8));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, BN, TILE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, BN, TILE, STATS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, G::BUF_BYTES);
     attr_set = true;
   }
   TimedLaunch tl(KS == 3 ? MDIE_K_CONV3 : MDIE_K_CONV1);
-  hipLaunchKernelGGL((conv_kernel<T, KS, BN, TILE>), grid, dim3(CONV_THREADS), G::BUF_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_kernel<T, KS, BN, TILE, STATS>), grid, dim3(CONV_THREADS), G::BUF_BYTES, stream, a);
   MDIE_LAUNCH_CHECK("mdie_conv_fwd");
   return MDIE_OK;
 }
@@ -690,6 +744,10 @@ static void fill_epi(EpiArgs& e, int H, int W, const float* sc, const float* sh,
   e.out = reinterpret_cast<char*>(out); e.out_stride = out_stride;
   e.nchw3 = nchw3;
 }
+
+}  // namespace mdie
+extern "C" int mdie_conv_tile(int B, int H, int W, int cout);
+namespace mdie {
 
 template <typename T>
 static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
@@ -727,6 +785,10 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   if (d->ksize == 1 && !d->pool && !no_stream && bn == 64 &&
       (size_t)a.nchunk * 4 * bn * 16 + (size_t)2 * a.nchunk * KC * sizeof(float) <= 96 * 1024)
     return launch_conv1x1_stream<T, 4>(a, stream);
+  if (d->pool_partial) {   // 3x3, 64-wide, ReLU, no max-pool: checked by the caller below
+    a.pool_partial = d->pool_partial;
+    return mdie_conv_tile(d->B, d->H, d->W, d->cout) == 8 ? launch_conv<T, 3, 64, 8, true>(a, stream) : launch_conv<T, 3, 64, 16, true>(a, stream);
+  }
   if (d->ksize == 3) {
     if (bn == 64) return small ? launch_conv<T, 3, 64, 8>(a, stream) : launch_conv<T, 3, 64, 16>(a, stream);
     return small ? launch_conv<T, 3, 16, 8>(a, stream) : launch_conv<T, 3, 16, 16>(a, stream);
@@ -872,8 +934,17 @@ extern "C" int mdie_conv_fwd(const mdie_conv_desc* d, void* stream) {
 #ifndef EXP_STAMPS
   MDIE_REQUIRE(!d->residual || (d->res_stride % 4 == 0), "mdie_conv_fwd: res_stride %d", d->res_stride);
 #endif
+  MDIE_REQUIRE(!d->pool_partial || (d->ksize == 3 && d->cout % 64 == 0 && d->act == MDIE_ACT_RELU && !d->pool && !d->out_nchw3),
+               "mdie_conv_fwd: pool_partial needs a 3x3 convolution with cout %% 64 == 0, ReLU and no max-pool");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return d->dtype == MDIE_F32 ? dispatch_conv<float>(d, s) : dispatch_conv<mdie::bf16>(d, s);
+}
+
+extern "C" int mdie_conv_tile(int B, int H, int W, int cout) {
+  // the tile edge mdie_conv_fwd uses for this shape (see dispatch_conv): pool_partial holds one slab per tile
+  const int bn = (cout % 64 == 0) ? 64 : 16;
+  const long wgs16 = (long)mdie::cdiv(H, 16) * mdie::cdiv(W, 16) * B * (cout / bn);
+  return wgs16 < (bn == 16 ? 1024 : 512) ? 8 : 16;
 }
 
 extern "C" int mdie_conv_first_fwd(const mdie_conv_first_desc* d, void* stream) {

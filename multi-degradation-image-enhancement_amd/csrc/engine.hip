@@ -238,7 +238,18 @@ static Plan make_plan(int dtype, int B, int H, int W) {
   const int ch[4] = {512, 256, 128, 64}, chh[4] = {h3, h3, h2, h1}, cww[4] = {w3, w3, w2, w1};
   for (int i = 0; i < 4; ++i) { size_t b = mdie_cbam_workspace_bytes(B, chh[i], cww[i], ch[i]); cb = b > cb ? b : cb; }
   P.cbam_ws = off; P.cbam_ws_bytes = cb; off += align256(cb);
-  P.pool_ws = off; off += align256((size_t)B * 128 * 2 * 128 * sizeof(float));
+  P.pool_ws = off; {
+    // pooling partials written by the producer of a CBAM input: upsample+skip (<= 128 slabs x 128 channels) or the
+    // 512- / 256-channel convolutions in front of the bottleneck CBAM and cbam1 (one slab per conv tile, <= 256)
+    size_t floats = (size_t)128 * 2 * 128;
+    const int widths[2] = {512, 256};
+    for (int i = 0; i < 2; ++i) {
+      const int t = mdie_conv_tile(B, h3, w3, widths[i]);
+      const size_t slabs = (size_t)cdiv(h3, t) * cdiv(w3, t);
+      if (slabs <= MDIE_POOL_SLABS_MAX && slabs * 2 * widths[i] > floats) floats = slabs * 2 * widths[i];   // (more tiles: that CBAM pools on its own)
+    }
+    off += align256((size_t)B * floats * sizeof(float));
+  }
   P.total = off;
   return P;
 }
@@ -399,7 +410,7 @@ struct Ctx {
 static mdie_seg seg(const Ctx& c, const Buf& b) { return mdie_seg{c.ws + b.off, b.C, b.C}; }
 
 static int run_conv(const Ctx& c, int id, int H, int W, std::initializer_list<Buf> in, const Buf& out, int act, int pool,
-                    const Buf* residual, float* out_nchw3 = nullptr) {
+                    const Buf* residual, float* out_nchw3 = nullptr, float* pool_partial = nullptr) {
   const ConvSpec& s = arch(c.dtype).conv[id];
   mdie_conv_desc d{};
   d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.ksize = s.ks;
@@ -418,6 +429,7 @@ static int run_conv(const Ctx& c, int id, int H, int W, std::initializer_list<Bu
   if (residual) { d.residual = c.ws + residual->off; d.res_stride = residual->C; }
   d.out = c.ws + out.off; d.out_stride = out.C;
   d.out_nchw3 = out_nchw3;
+  d.pool_partial = pool_partial;
   return mdie_conv_fwd(&d, c.stream);
 }
 
@@ -432,8 +444,9 @@ static int run_dense(const Ctx& c, int block, int H, int W, const Buf& base, con
   return run_conv(c, id0 + 4, H, W, {base, g[0], g[1], g[2], g[3]}, out, act, 0, nullptr, out_nchw3);
 }
 
+// pooled_slabs > 0: the producer of x already wrote that many pooling partials per image into the plan's pool buffer
 static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, const Buf& x, const Buf* mul, const Buf& out,
-                          bool pooled = false) {
+                          int pooled_slabs = 0) {
   const CbamBlob& o = c.L.cbam[id];
   mdie_cbam_desc d{};
   d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.C = arch(c.dtype).cbam[id].C;
@@ -445,7 +458,7 @@ static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, con
   if (mul) { d.mul = c.ws + mul->off; d.mul_stride = mul->C; }
   d.out = c.ws + out.off; d.out_stride = out.C;
   d.workspace = c.ws + P.cbam_ws; d.workspace_bytes = P.cbam_ws_bytes;
-  if (pooled) { d.pool_partial = reinterpret_cast<const float*>(c.ws + P.pool_ws); d.pool_slabs = mdie_pool_slabs(H, W); }
+  if (pooled_slabs > 0) { d.pool_partial = reinterpret_cast<const float*>(c.ws + P.pool_ws); d.pool_slabs = pooled_slabs; }
   return mdie_cbam_fwd(&d, c.stream);
 }
 
@@ -500,21 +513,28 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   RUN(side_dense(1, h2, w2));
   RUN(run_conv(c, CV_E3, h2, w2, {P.o[1]}, P.o[2], MDIE_ACT_RELU, 1, nullptr));
   RUN(side_dense(2, h3, w3));
-  RUN(run_conv(c, CV_E4, h3, w3, {P.o[2]}, P.e, MDIE_ACT_RELU, 0, nullptr));
+  // the two CBAMs at the deep end pool tensors a 64-wide convolution has just written: that convolution emits the
+  // per-tile channel sums / maxima itself (one slab per tile), unless the picture is so large that a gate would
+  // have to fold more than MDIE_POOL_SLABS_MAX of them
+  float* pool_buf = reinterpret_cast<float*>(c.ws + P.pool_ws);
+  const int te = mdie_conv_tile(B, h3, w3, 512), td = mdie_conv_tile(B, h3, w3, 256);
+  const int slabs_e = cdiv(h3, te) * cdiv(w3, te), slabs_d = cdiv(h3, td) * cdiv(w3, td);
+  const bool fuse_e = slabs_e <= MDIE_POOL_SLABS_MAX, fuse_d = slabs_d <= MDIE_POOL_SLABS_MAX;
+  RUN(run_conv(c, CV_E4, h3, w3, {P.o[2]}, P.e, MDIE_ACT_RELU, 0, nullptr, nullptr, fuse_e ? pool_buf : nullptr));
   // bottleneck, models/cdan.py:173
-  RUN(run_cbam_stage(c, P, CB_BOTT, h3, w3, P.e, nullptr, P.bott));
+  RUN(run_cbam_stage(c, P, CB_BOTT, h3, w3, P.e, nullptr, P.bott, fuse_e ? slabs_e : 0));
   // Decoder.forward, models/cdan.py:126-159
-  RUN(run_conv(c, CV_D1, h3, w3, {P.bott}, P.t1, MDIE_ACT_RELU, 0, &P.o[2]));      // convT+BN+ReLU, + skip2
+  RUN(run_conv(c, CV_D1, h3, w3, {P.bott}, P.t1, MDIE_ACT_RELU, 0, &P.o[2], nullptr, fuse_d ? pool_buf : nullptr));   // convT+BN+ReLU, + skip2
   RUN(join_dense(2));
-  RUN(run_cbam_stage(c, P, CB_1, h3, w3, P.t1, &P.d[2], P.u1));                     // cbam1, *= dense3
+  RUN(run_cbam_stage(c, P, CB_1, h3, w3, P.t1, &P.d[2], P.u1, fuse_d ? slabs_d : 0));  // cbam1, *= dense3
   RUN(run_conv(c, CV_D2, h3, w3, {P.u1}, P.t2lo, MDIE_ACT_RELU, 0, nullptr));
   RUN(run_up(c, P, h3, w3, P.t2lo, P.o[1], P.t2));                                     // bilinear x2 + skip1
   RUN(join_dense(1));
-  RUN(run_cbam_stage(c, P, CB_2, h2, w2, P.t2, &P.d[1], P.u2, true));
+  RUN(run_cbam_stage(c, P, CB_2, h2, w2, P.t2, &P.d[1], P.u2, mdie_pool_slabs(h2, w2)));
   RUN(run_conv(c, CV_D3, h2, w2, {P.u2}, P.t3lo, MDIE_ACT_RELU, 0, nullptr));
   RUN(run_up(c, P, h2, w2, P.t3lo, P.o[0], P.t3));
   RUN(join_dense(0));
-  RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3, true));
+  RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3, mdie_pool_slabs(h1, w1)));
   RUN(run_conv(c, CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
   if (!(d->flags & MDIE_FWD_FUSED_TAIL)) {
     // bilinear x2 + x (x read from its fp32 NCHW planes), final_dense, sigmoid written straight to NCHW

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 14
+ABI_VERSION = 15
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 LOSS_KINDS = {"mse": 0, "l1": 1, "charbonnier": 2, "ssim": 3, "gradient_l1": 4}
@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
                 ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("weight", C.c_void_p),
                 ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int), ("pool", C.c_int),
                 ("residual", C.c_void_p), ("res_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int),
-                ("out_nchw3", C.c_void_p)]
+                ("out_nchw3", C.c_void_p), ("pool_partial", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -137,6 +137,7 @@ class CdanFwdDesc(C.Structure):
 # name -> (restype, argtypes); must list every function include/mdie.h declares
 SIGNATURES = {
     "mdie_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "mdie_conv_tile": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mdie_conv_weight_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mdie_pack_conv_weight": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p]),
