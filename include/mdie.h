@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 16
+#define MDIE_ABI_VERSION 15
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
@@ -87,12 +87,10 @@ typedef struct {
   int out_stride;
   float* out_nchw3;        /* optional: instead of `out`, write output channels 0..2 as fp32 NCHW [B,3,Ho,Wo]
                               (the network's final tensor, models/cdan.py:157); cout must be 16 */
-  float* pool_partial;     /* optional (3x3, no max-pool): additionally emit per-channel statistics of the tensor written,
-                              [B][tiles per image][2][cout] with tiles of edge mdie_conv_tile(B,H,W,cout) in raster order:
-                              act = RELU (cout % 64 == 0): (sum, max) -- the global pools of the CBAM that consumes it
-                              (models/cbam.py:41,44; mdie_cbam_desc.pool_partial) fused into their producer;
-                              act = NONE, no residual: (sum, sum of squares) -- the batch statistics of the BatchNorm that
-                              follows in training mode (mdie_bn_stats_from_partials) */
+  float* pool_partial;     /* optional (3x3, cout % 64 == 0, ReLU, no max-pool): additionally emit the channel sums and
+                              maxima of the tensor written, [B][tiles per image][2][cout] with tiles of edge
+                              mdie_conv_tile(B,H,W,cout) in raster order -- the global pools of the CBAM that consumes
+                              it (models/cbam.py:41,44; mdie_cbam_desc.pool_partial) fused into their producer */
 } mdie_conv_desc;
 
 int mdie_conv_fwd(const mdie_conv_desc* d, void* stream);
@@ -361,9 +359,6 @@ size_t mdie_bn_workspace_bytes(int C);
 /* mean[C], var[C] (biased) over N pixels */
 int mdie_bn_stats(int dtype, long N, const void* x, int C, int stride, float* mean, float* var, void* workspace,
                   size_t workspace_bytes, void* stream);
-/* the same from nparts partial blocks [nparts][2][C] = (sum, sum of squares) written by a producer (mdie_conv_fwd
- * pool_partial with act = NONE): mean[C], var[C] over N pixels */
-int mdie_bn_stats_from_partials(int nparts, int C, long N, const float* partial, float* mean, float* var, void* stream);
 /* scale = gamma / sqrt(var + eps), shift = beta - mean * scale, invstd, per STORED channel (mean / var / outputs are
  * indexed by stored channel; gamma / beta / running_* by real channel: real c >= split is stored at c + gap; padding
  * gets scale = shift = 0).  running_* (nullable) are updated with `momentum` and the unbiased variance. */

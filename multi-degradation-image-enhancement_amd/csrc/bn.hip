@@ -584,13 +584,6 @@ extern "C" int mdie_bn_stats(int dtype, long N, const void* x, int C, int stride
   return MDIE_OK;
 }
 
-extern "C" int mdie_bn_stats_from_partials(int nparts, int C, long N, const float* partial, float* mean, float* var, void* stream) {
-  MDIE_REQUIRE(nparts > 0 && C > 0 && N > 0 && partial && mean && var, "mdie_bn_stats_from_partials: bad argument");
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), nparts, C, (double)N, partial, mean, var);
-  MDIE_LAUNCH_CHECK("mdie_bn_stats_from_partials");
-  return MDIE_OK;
-}
-
 extern "C" int mdie_bn_fold(int C_stored, int C_real, int split, int gap, const float* mean, const float* var, const float* gamma, const float* beta,
                             float eps, float momentum, long count, float* running_mean, float* running_var, float* scale, float* shift, float* invstd,
                             void* stream) {

@@ -99,7 +99,7 @@ template <int ACT> __device__ __forceinline__ float act_fn(float v) {
   else return v;
 }
 
-template <typename T, int NCS, int NPS, int TILE, int ACT, bool POOL, int STATS = 0>
+template <typename T, int NCS, int NPS, int TILE, int ACT, bool POOL, bool STATS = false>
 __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (&esc)[NCS], const float4 (&esh)[NCS],
                                                 f32x4 (&acc)[NCS][NPS], int img, int y0, int x0, int n0, int ps_base, int lq, int lp,
                                                 float (*st_sum)[4] = nullptr, float (*st_max)[4] = nullptr) {
@@ -143,14 +143,13 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] += ld(rrow + cs * 16 + i);
         }
-        if constexpr (STATS != 0) {   // statistics of the STORED values: what a separate pass over `out` would read
+        if constexpr (STATS) {   // channel sums / maxima of the STORED values: what a separate pooling pass over `out` would read
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float qv = v[i];
             if constexpr (sizeof(T) == 2) qv = (float)(bf16)qv;
             st_sum[cs][i] += qv;
-            if constexpr (STATS == 1) st_max[cs][i] = fmaxf(st_max[cs][i], qv);   // (sum, max): global pools of a CBAM
-            else st_max[cs][i] = fmaf(qv, qv, st_max[cs][i]);                       // (sum, sum of squares): batch-stat BatchNorm
+            st_max[cs][i] = fmaxf(st_max[cs][i], qv);
           }
         }
         if constexpr (sizeof(T) == 4) {
@@ -202,7 +201,7 @@ constexpr int conv_min_waves(int BN, int TILE) { return BN == 16 ? 4 : (TILE == 
 // that is not a load, an LDS access or an MFMA is kept off the hot path: 3-D grid instead of index
 // division, incremental patch coordinates, remainder staging iterations under a wave-uniform branch,
 // epilogue constants prefetched at kernel entry.
-template <typename T, int KS, int BN, int TILE, int STATS = 0>
+template <typename T, int KS, int BN, int TILE, bool STATS = false>
 __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_kernel(const ConvArgs a) {
   using G = ConvGeom<KS, BN, TILE>;
 #ifdef EXP_STAMPS
@@ -419,7 +418,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
   if (dbg) { e2.residual = nullptr; e2.res_stride = 0; }
   conv_epilogue<T, NCS, NPS, TILE>(e2, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp);
 #else
-  if constexpr (STATS == 0) {
+  if constexpr (!STATS) {
     conv_epilogue<T, NCS, NPS, TILE>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp);
   } else {
     // The tensor this convolution writes feeds a CBAM whose first pass is a global average / max pool over H*W
@@ -429,9 +428,8 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { st_sum[cs][i] = 0.f; st_max[cs][i] = STATS == 1 ? -INFINITY : 0.f; }
-    conv_epilogue_t<T, NCS, NPS, TILE, (STATS == 1 ? MDIE_ACT_RELU : MDIE_ACT_NONE), false, STATS>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp,
-                                                                                                   st_sum, st_max);
+      for (int i = 0; i < 4; ++i) { st_sum[cs][i] = 0.f; st_max[cs][i] = -INFINITY; }
+    conv_epilogue_t<T, NCS, NPS, TILE, MDIE_ACT_RELU, false, true>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp, st_sum, st_max);
     // over the 16 pixel lanes of a row (same lq = same 4 channels) ...
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs)
@@ -440,8 +438,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
 #pragma unroll
         for (int d = 8; d > 0; d >>= 1) {
           st_sum[cs][i] += __shfl_xor(st_sum[cs][i], d);
-          if constexpr (STATS == 1) st_max[cs][i] = fmaxf(st_max[cs][i], __shfl_xor(st_max[cs][i], d));
-          else st_max[cs][i] += __shfl_xor(st_max[cs][i], d);
+          st_max[cs][i] = fmaxf(st_max[cs][i], __shfl_xor(st_max[cs][i], d));
         }
     // ... then over the 4 waves through LDS (the patch image is dead once every wave is past its last MFMA)
     __syncthreads();
@@ -457,12 +454,9 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
     }
     __syncthreads();
     if (tid < BN) {
-      float ss = 0.f, mm = STATS == 1 ? -INFINITY : 0.f;
+      float ss = 0.f, mm = -INFINITY;
 #pragma unroll
-      for (int w = 0; w < CONV_THREADS / 64; ++w) {
-        ss += red[(w * 2 + 0) * BN + tid];
-        mm = STATS == 1 ? fmaxf(mm, red[(w * 2 + 1) * BN + tid]) : mm + red[(w * 2 + 1) * BN + tid];
-      }
+      for (int w = 0; w < CONV_THREADS / 64; ++w) { ss += red[(w * 2 + 0) * BN + tid]; mm = fmaxf(mm, red[(w * 2 + 1) * BN + tid]); }
       float* dst = a.pool_partial + ((size_t)img * tpi + trem) * 2 * a.cout + n0 + tid;
       dst[0] = ss;
       dst[a.cout] = mm;
@@ -720,7 +714,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_first_kernel(const FirstArg
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------
-template <typename T, int KS, int BN, int TILE, int STATS = 0>
+template <typename T, int KS, int BN, int TILE, bool STATS = false>
 static int launch_conv(ConvArgs& a, hipStream_t stream) {
   using G = ConvGeom<KS, BN, TILE>;
   a.tiles_x = cdiv(a.W, TILE); a.tiles_y = cdiv(a.H, TILE);
@@ -791,12 +785,9 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   if (d->ksize == 1 && !d->pool && !no_stream && bn == 64 &&
       (size_t)a.nchunk * 4 * bn * 16 + (size_t)2 * a.nchunk * KC * sizeof(float) <= 96 * 1024)
     return launch_conv1x1_stream<T, 4>(a, stream);
-  if (d->pool_partial) {   // shapes checked by the caller below
+  if (d->pool_partial) {   // 3x3, 64-wide, ReLU, no max-pool: checked by the caller below
     a.pool_partial = d->pool_partial;
-    const bool t8 = mdie_conv_tile(d->B, d->H, d->W, d->cout) == 8;
-    if (d->act == MDIE_ACT_RELU) return t8 ? launch_conv<T, 3, 64, 8, 1>(a, stream) : launch_conv<T, 3, 64, 16, 1>(a, stream);
-    if (bn == 64) return t8 ? launch_conv<T, 3, 64, 8, 2>(a, stream) : launch_conv<T, 3, 64, 16, 2>(a, stream);
-    return t8 ? launch_conv<T, 3, 16, 8, 2>(a, stream) : launch_conv<T, 3, 16, 16, 2>(a, stream);
+    return mdie_conv_tile(d->B, d->H, d->W, d->cout) == 8 ? launch_conv<T, 3, 64, 8, true>(a, stream) : launch_conv<T, 3, 64, 16, true>(a, stream);
   }
   if (d->ksize == 3) {
     if (bn == 64) return small ? launch_conv<T, 3, 64, 8>(a, stream) : launch_conv<T, 3, 64, 16>(a, stream);
@@ -943,10 +934,8 @@ extern "C" int mdie_conv_fwd(const mdie_conv_desc* d, void* stream) {
 #ifndef EXP_STAMPS
   MDIE_REQUIRE(!d->residual || (d->res_stride % 4 == 0), "mdie_conv_fwd: res_stride %d", d->res_stride);
 #endif
-  MDIE_REQUIRE(!d->pool_partial || (d->ksize == 3 && !d->pool && !d->out_nchw3 &&
-                                    ((d->act == MDIE_ACT_RELU && d->cout % 64 == 0) || (d->act == MDIE_ACT_NONE && !d->residual))),
-               "mdie_conv_fwd: pool_partial needs a 3x3 convolution without max-pool: ReLU with cout %% 64 == 0 -> (sum, max), "
-               "or no activation and no residual -> (sum, sum of squares)");
+  MDIE_REQUIRE(!d->pool_partial || (d->ksize == 3 && d->cout % 64 == 0 && d->act == MDIE_ACT_RELU && !d->pool && !d->out_nchw3),
+               "mdie_conv_fwd: pool_partial needs a 3x3 convolution with cout %% 64 == 0, ReLU and no max-pool");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return d->dtype == MDIE_F32 ? dispatch_conv<float>(d, s) : dispatch_conv<mdie::bf16>(d, s);
 }

@@ -88,10 +88,8 @@ def _zeros(n, dev):
     return _ZEROS[key]
 
 
-def _conv_raw(dt, segs, packed, bias_st, ks, cout_st, out, pre=None, act=L.ACT_NONE, out_nchw3=None, stats=None):
-    """out = act(conv_k(relu(cat(segs) * pre_scale + pre_shift)?) + bias); out: NHWC view with >= cout_st channels.
-    stats = (mean, var): also the batch statistics of `out` (3x3, no activation), from partial sums the convolution
-    emits per tile -- the BatchNorm that follows never reads `out` just to count it."""
+def _conv_raw(dt, segs, packed, bias_st, ks, cout_st, out, pre=None, act=L.ACT_NONE, out_nchw3=None):
+    """out = act(conv_k(relu(cat(segs) * pre_scale + pre_shift)?) + bias); out: NHWC view with >= cout_st channels."""
     B, _, H, W = segs[0].shape
     d = L.ConvDesc()
     d.dtype, d.B, d.H, d.W, d.ksize = dt, B, H, W, ks
@@ -108,16 +106,7 @@ def _conv_raw(dt, segs, packed, bias_st, ks, cout_st, out, pre=None, act=L.ACT_N
     d.residual, d.res_stride = None, 0
     d.out, d.out_stride = out.data_ptr(), out.stride(3)
     d.out_nchw3 = out_nchw3.data_ptr() if out_nchw3 is not None else None
-    partial = None
-    if stats is not None:
-        t = L.lib.mdie_conv_tile(B, H, W, cout_st)
-        nparts = B * ((H + t - 1) // t) * ((W + t - 1) // t)
-        partial = torch.empty(nparts, 2, cout_st, dtype=torch.float32, device=out.device)
-        d.pool_partial = partial.data_ptr()
     L.check(L.lib.mdie_conv_fwd(C.byref(d), _sp(out.device)), "mdie_conv_fwd")
-    if stats is not None:
-        L.check(L.lib.mdie_bn_stats_from_partials(partial.shape[0], cout_st, B * H * W, partial.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
-                                                  _sp(out.device)), "mdie_bn_stats_from_partials")
 
 
 def _pad_vec(v, n):
@@ -195,8 +184,9 @@ class _ConvBnFn(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         w32 = _f32(weight)
         y = _empty(dt, B, cout, H, W, dev)
+        _conv_raw(dt, [x], _pack(dt, w32, 3, False, cout, cin, cout, cin_st), _f32(bias), 3, cout, y)
         mv = torch.empty(2, cout, dtype=torch.float32, device=dev)
-        _conv_raw(dt, [x], _pack(dt, w32, 3, False, cout, cin, cout, cin_st), _f32(bias), 3, cout, y, stats=(mv[0], mv[1]))
+        _Bn.stats(dt, y, mv[0], mv[1])
         k = _Bn.fold(cout, cout, cout, 0, mv[0], mv[1], bn, 0.1, B * H * W, dev)
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         o = _empty(dt, B, cout, Ho, Wo, dev) if need_o else None
@@ -271,8 +261,8 @@ class _DenseFn(torch.autograd.Function):
             segs = [x] + ([grow[:, :16 * l]] if l else [])
             if l < 4:
                 out = grow[:, 16 * l:16 * l + 16]
-                _conv_raw(dt, segs, _pack(dt, w, 3, False, 16, cin_st), _f32(params[4 * l + 3]), 3, 16, out, pre=(k[0], k[1]),
-                          stats=(mv[0, cin_st:cin_st + 16], mv[1, cin_st:cin_st + 16]))
+                _conv_raw(dt, segs, _pack(dt, w, 3, False, 16, cin_st), _f32(params[4 * l + 3]), 3, 16, out, pre=(k[0], k[1]))
+                _Bn.stats(dt, out, mv[0, cin_st:cin_st + 16], mv[1, cin_st:cin_st + 16])
             else:
                 cout = w.shape[0]
                 cout_st = (cout + 15) // 16 * 16
@@ -358,8 +348,9 @@ class _DeconvFn(torch.autograd.Function):
         cout_st = (cout + 15) // 16 * 16
         w32 = _f32(weight)
         y = _empty(dt, B, cout_st, H, W, dev)
+        _conv_raw(dt, [x], _pack(dt, w32, 3, True, cout, cin, cout_st, cin), _pad_vec(bias, cout_st), 3, cout_st, y)
         mv = torch.empty(2, cout_st, dtype=torch.float32, device=dev)
-        _conv_raw(dt, [x], _pack(dt, w32, 3, True, cout, cin, cout_st, cin), _pad_vec(bias, cout_st), 3, cout_st, y, stats=(mv[0], mv[1]))
+        _Bn.stats(dt, y, mv[0], mv[1])
         k = _Bn.fold(cout_st, cout, cout_st, 0, mv[0], mv[1], bn, 0.1, B * H * W, dev)
         Ho, Wo = (2 * H, 2 * W) if up else (H, W)
         out = _empty(dt, B, cout_st, Ho, Wo, dev)
