@@ -29,6 +29,7 @@
 namespace mdie {
 
 constexpr int CONV_THREADS = 256;
+constexpr int SMALL_GRID_WGS = 512;   // fewer 16x16-tile workgroups than this -> 8x8 tiles
 constexpr int PWP = 24;  // LDS patch row pitch in pixels: >= TILE+2 and == 8 (mod 16)
 
 struct SegDev {
@@ -774,11 +775,12 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   fill_epi(a.e, d->H, d->W, d->post_scale, d->post_shift, d->act, d->pool, d->residual, d->res_stride, d->out, d->out_stride, d->out_nchw3);
   const int bn = (d->cout % 64 == 0) ? 64 : 16;
   a.n_tiles = d->cout / bn;
-  // Small feature maps (32x32, 64x64 at the network's deep end) do not fill 256 CUs with 16x16 tiles:
-  // switch to 8x8 tiles (4x the workgroups) when the 16x16 grid would leave CUs idle.
+  // Small feature maps (32x32 at the network's deep end) do not fill 256 CUs with 16x16 tiles: switch to 8x8 tiles
+  // (4x the workgroups) when the 16x16 grid would have fewer than 2 workgroups per CU.  (Measured, B=32 256x256: a
+  // threshold of 1024 for the 16-output layers put the 64x64 dense2 layers on 8x8 tiles and cost 1.5 % of the step.)
   const long wgs16 = (long)cdiv(d->H, 16) * cdiv(d->W, 16) * d->B * a.n_tiles;
   static const int force8 = getenv("MDIE_CONV_TILE8") ? atoi(getenv("MDIE_CONV_TILE8")) : 0;  // experiments: 1 = thin, 2 = all
-  const bool small = wgs16 < (bn == 16 ? 1024 : 512) || (force8 == 1 && bn == 16) || force8 == 2;
+  const bool small = wgs16 < SMALL_GRID_WGS || (force8 == 1 && bn == 16) || force8 == 2;
   static const int no_stream = getenv("MDIE_CONV1_STREAM") ? !atoi(getenv("MDIE_CONV1_STREAM")) : 0;   // experiments: 0 = staged kernel
   // (64-wide output tiles only: with 16 outputs there are 4 MFMAs per 4 loads and the staged kernel is faster -- measured
   //  final.tr 85 us staged vs 92 us streaming, dense1.tr 58 us staged vs 47 us streaming, B=32 256x256 bf16)
@@ -944,7 +946,7 @@ extern "C" int mdie_conv_tile(int B, int H, int W, int cout) {
   // the tile edge mdie_conv_fwd uses for this shape (see dispatch_conv): pool_partial holds one slab per tile
   const int bn = (cout % 64 == 0) ? 64 : 16;
   const long wgs16 = (long)mdie::cdiv(H, 16) * mdie::cdiv(W, 16) * B * (cout / bn);
-  return wgs16 < (bn == 16 ? 1024 : 512) ? 8 : 16;
+  return wgs16 < mdie::SMALL_GRID_WGS ? 8 : 16;
 }
 
 extern "C" int mdie_conv_first_fwd(const mdie_conv_first_desc* d, void* stream) {
