@@ -271,13 +271,10 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
       if (px >= PW) { px -= PW; py += 1; }
     }
   }
-  int wsrc_off[W_IT];   // byte offset of this thread's weight unit inside one chunk
-#pragma unroll
-  for (int it = 0; it < W_IT; ++it) {
-    const int u = tid + it * CONV_THREADS;
-    const int qt = u / BN, n = u - qt * BN;  // qt = q * NTAP + tap (BN is a power of two)
-    wsrc_off[it] = (qt * a.cout + n0 + n) * 16;
-  }
+  // byte offset of this thread's weight unit inside one chunk: unit u = tid + it*256 -> (qt, n) = (u / BN, u % BN), so the
+  // offsets of successive iterations differ by a wave-uniform constant (256 / BN rows of cout units): one register, not W_IT
+  const int wsrc_off0 = ((tid / BN) * a.cout + n0 + (tid % BN)) * 16;
+  const int wsrc_step = (CONV_THREADS / BN) * a.cout * 16;
   const size_t wchunk_bytes = (size_t)4 * NTAP * a.cout * 16;
 
   // staging registers (chunk in flight)
@@ -313,7 +310,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
       wv[it] = make_uint4(0, 0, 0, 0);
 #ifndef EXP_NO_WLOAD
       if (it < W_IT - 1 || wave < W_LAST_WAVES)
-        if (tid + it * CONV_THREADS < W_UNITS) wv[it] = *reinterpret_cast<const uint4*>(wsrc + wsrc_off[it]);
+        if (tid + it * CONV_THREADS < W_UNITS) wv[it] = *reinterpret_cast<const uint4*>(wsrc + wsrc_off0 + it * wsrc_step);
 #endif
     }
     if (has_pre && chunk_live) {
