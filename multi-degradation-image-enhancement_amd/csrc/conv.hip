@@ -255,20 +255,24 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
 
   // ---- staging geometry: unit u = tid + it*256 -> patch pixel u>>2 (advances 64 pixels per iteration) ----
   int gpix[PATCH_IT];   // (img*H + gy)*W + gx, or -1 outside the picture / past the patch
-  int pdst[PATCH_IT];   // LDS byte offset of the unit
+  // LDS byte offset of the unit: first one + a running sum of two possible strides (64 pixels further = 64/PW rows and 64%PW
+  // columns, one more row when the column wraps) -- a start offset and a wrap bit mask instead of PATCH_IT registers
+  constexpr int PD_STEP = ((64 / PW) * PWP + 64 % PW) * 16, PD_WRAP = (PWP - PW) * 16;
+  constexpr int LAST_UNITS = PATCH_UNITS - (PATCH_IT - 1) * CONV_THREADS;   // units of the (partial) last iteration
+  int pdst0, pwrap = 0;
   {
     int pix = tid >> 2;
     int py = pix / PW, px = pix - py * PW;
     const int base = img * a.H * a.W;
+    pdst0 = q * G::PLANE + (py * PWP + px) * 16;
 #pragma unroll
     for (int it = 0; it < PATCH_IT; ++it) {
       const int gy = y0 + py - PAD, gx = x0 + px - PAD;
-      const bool in_patch = (it < PATCH_IT - 1) || (tid + it * CONV_THREADS < PATCH_UNITS);
+      const bool in_patch = (it < PATCH_IT - 1) || (tid < LAST_UNITS);
       const bool ok = in_patch && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       gpix[it] = ok ? base + gy * a.W + gx : -1;
-      pdst[it] = in_patch ? q * G::PLANE + (py * PWP + px) * 16 : -1;
       px += 64 % PW; py += 64 / PW;
-      if (px >= PW) { px -= PW; py += 1; }
+      if (px >= PW) { px -= PW; py += 1; pwrap |= 1 << it; }
     }
   }
   // byte offset of this thread's weight unit inside one chunk: unit u = tid + it*256 -> (qt, n) = (u / BN, u % BN), so the
@@ -329,10 +333,11 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
   };
 
   auto store_chunk = [&]() {
+    int pd = pdst0;
 #pragma unroll
     for (int it = 0; it < PATCH_IT; ++it) {
       if (it < PATCH_IT - 1 || wave < PATCH_LAST_WAVES) {
-        if (pdst[it] >= 0) {
+        if (it < PATCH_IT - 1 || tid < LAST_UNITS) {
           uint4 v = pv[it];
           if (has_pre && chunk_live && gpix[it] >= 0) {
             float f[VEC];
@@ -341,9 +346,10 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
             for (int i = 0; i < VEC; ++i) f[i] = fmaxf(fmaf(f[i], ps_[i], pb_[i]), 0.0f);
             v = Vec16<T>::pack(f);
           }
-          *reinterpret_cast<uint4*>(lds_patch + pdst[it]) = v;
+          *reinterpret_cast<uint4*>(lds_patch + pd) = v;
         }
       }
+      pd += PD_STEP + (((pwrap >> it) & 1) ? PD_WRAP : 0);
     }
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
