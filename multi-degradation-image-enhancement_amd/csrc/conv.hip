@@ -254,7 +254,9 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
   const bool has_pre = a.pre_scale != nullptr;
 
   // ---- staging geometry: unit u = tid + it*256 -> patch pixel u>>2 (advances 64 pixels per iteration) ----
-  int gpix[PATCH_IT];   // (img*H + gy)*W + gx, or -1 outside the picture / past the patch
+  // global pixel index (img*H + gy)*W + gx of the units: like the LDS offsets a start value and a running sum, plus a bit
+  // mask of the iterations whose pixel lies inside the picture (and inside the patch)
+  int gpix0, ginside = 0;
   // LDS byte offset of the unit: first one + a running sum of two possible strides (64 pixels further = 64/PW rows and 64%PW
   // columns, one more row when the column wraps) -- a start offset and a wrap bit mask instead of PATCH_IT registers
   constexpr int PD_STEP = ((64 / PW) * PWP + 64 % PW) * 16, PD_WRAP = (PWP - PW) * 16;
@@ -265,12 +267,13 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
     int py = pix / PW, px = pix - py * PW;
     const int base = img * a.H * a.W;
     pdst0 = q * G::PLANE + (py * PWP + px) * 16;
+    gpix0 = base + (y0 + py - PAD) * a.W + (x0 + px - PAD);
 #pragma unroll
     for (int it = 0; it < PATCH_IT; ++it) {
       const int gy = y0 + py - PAD, gx = x0 + px - PAD;
       const bool in_patch = (it < PATCH_IT - 1) || (tid < LAST_UNITS);
       const bool ok = in_patch && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      gpix[it] = ok ? base + gy * a.W + gx : -1;
+      ginside |= (ok ? 1 : 0) << it;
       px += 64 % PW; py += 64 / PW;
       if (px >= PW) { px -= PW; py += 1; pwrap |= 1 << it; }
     }
@@ -299,13 +302,16 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
       }
     }
     chunk_live = sbase != nullptr;
+    int gp = gpix0;
+    const int g_step = (64 / PW) * a.W + 64 % PW, g_wrap = a.W - PW;
 #pragma unroll
     for (int it = 0; it < PATCH_IT; ++it) {
       pv[it] = make_uint4(0, 0, 0, 0);
 #ifndef EXP_NO_GLOAD
       if (it < PATCH_IT - 1 || wave < PATCH_LAST_WAVES)
-        if (chunk_live && gpix[it] >= 0) pv[it] = *reinterpret_cast<const uint4*>(sbase + (size_t)gpix[it] * sstride);
+        if (chunk_live && ((ginside >> it) & 1)) pv[it] = *reinterpret_cast<const uint4*>(sbase + (size_t)gp * sstride);
 #endif
+      gp += g_step + (((pwrap >> it) & 1) ? g_wrap : 0);
     }
     // weights of this chunk: global [chunk][q][tap][cout] x 16 B  ->  LDS [q][tap][BN] x 16 B (linear copy per (q, tap))
     const char* wsrc = a.weight + chunk * wchunk_bytes;
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
       if (it < PATCH_IT - 1 || wave < PATCH_LAST_WAVES) {
         if (it < PATCH_IT - 1 || tid < LAST_UNITS) {
           uint4 v = pv[it];
-          if (has_pre && chunk_live && gpix[it] >= 0) {
+          if (has_pre && chunk_live && ((ginside >> it) & 1)) {
             float f[VEC];
             Vec16<T>::unpack(v, f);
 #pragma unroll
