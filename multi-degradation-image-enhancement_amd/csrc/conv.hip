@@ -225,6 +225,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_patch = smem;
   char* lds_w = smem + 4 * G::PLANE;
+  float* lds_pre = reinterpret_cast<float*>(smem + G::BUF_BYTES);   // [2][nchunk * KC] pre_scale, pre_shift (when present)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
 
   const int q = tid & 3;  // this thread's 16-byte column while staging the patch (CONV_THREADS % 4 == 0)
   const bool has_pre = a.pre_scale != nullptr;
+  const int kpad = a.nchunk * KC;
 
   // ---- staging geometry: unit u = tid + it*256 -> patch pixel u>>2 (advances 64 pixels per iteration) ----
   // global pixel index (img*H + gy)*W + gx of the units: like the LDS offsets a start value and a running sum, plus a bit
@@ -287,8 +289,8 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
   // staging registers (chunk in flight)
   uint4 pv[PATCH_IT];
   uint4 wv[W_IT];
-  float ps_[VEC], pb_[VEC];
   bool chunk_live = false;  // this thread's channel column exists in the chunk
+  int chunk_c0 = 0;         // first stored channel of this thread's column in the chunk in flight
 
   auto load_chunk = [&](int chunk) {
     const int c0 = chunk * KC + q * VEC;  // first stored channel of this thread's column
@@ -323,23 +325,22 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
         if (tid + it * CONV_THREADS < W_UNITS) wv[it] = *reinterpret_cast<const uint4*>(wsrc + wsrc_off0 + it * wsrc_step);
 #endif
     }
-    if (has_pre && chunk_live) {
-      if constexpr (VEC == 8) {
-        const float4 s0 = *reinterpret_cast<const float4*>(a.pre_scale + c0), s1 = *reinterpret_cast<const float4*>(a.pre_scale + c0 + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(a.pre_shift + c0), b1 = *reinterpret_cast<const float4*>(a.pre_shift + c0 + 4);
-        ps_[0] = s0.x; ps_[1] = s0.y; ps_[2] = s0.z; ps_[3] = s0.w; ps_[4] = s1.x; ps_[5] = s1.y; ps_[6] = s1.z; ps_[7] = s1.w;
-        pb_[0] = b0.x; pb_[1] = b0.y; pb_[2] = b0.z; pb_[3] = b0.w; pb_[4] = b1.x; pb_[5] = b1.y; pb_[6] = b1.z; pb_[7] = b1.w;
-      } else {
-        const float4 s0 = *reinterpret_cast<const float4*>(a.pre_scale + c0);
-        const float4 b0 = *reinterpret_cast<const float4*>(a.pre_shift + c0);
-        ps_[0] = s0.x; ps_[1] = s0.y; ps_[2] = s0.z; ps_[3] = s0.w;
-        pb_[0] = b0.x; pb_[1] = b0.y; pb_[2] = b0.z; pb_[3] = b0.w;
-      }
-    }
+    chunk_c0 = c0;
   };
 
   auto store_chunk = [&]() {
     int pd = pdst0;
+    // pre-activation constants of this thread's channels: read from their LDS copy here, not loaded with the chunk
+    // (where 16 registers would stay live across the whole MFMA phase)
+    float ps_[VEC], pb_[VEC];
+    if (has_pre && chunk_live) {
+#pragma unroll
+      for (int i = 0; i < VEC; i += 4) {
+        const float4 s4 = *reinterpret_cast<const float4*>(lds_pre + chunk_c0 + i), b4 = *reinterpret_cast<const float4*>(lds_pre + kpad + chunk_c0 + i);
+        ps_[i] = s4.x; ps_[i + 1] = s4.y; ps_[i + 2] = s4.z; ps_[i + 3] = s4.w;
+        pb_[i] = b4.x; pb_[i + 1] = b4.y; pb_[i + 2] = b4.z; pb_[i + 3] = b4.w;
+      }
+    }
 #pragma unroll
     for (int it = 0; it < PATCH_IT; ++it) {
       if (it < PATCH_IT - 1 || wave < PATCH_LAST_WAVES) {
@@ -368,6 +369,13 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
 
   STAMP(1);
   load_chunk(0);   // first memory requests leave before the rest of the bookkeeping
+  if (has_pre) {   // launch-uniform
+    for (int c = tid; c < kpad; c += CONV_THREADS) {
+      lds_pre[c] = c < a.cin ? a.pre_scale[c] : 0.f;
+      lds_pre[kpad + c] = c < a.cin ? a.pre_shift[c] : 0.f;
+    }
+    __syncthreads();
+  }
   STAMP(2);
 
   // epilogue constants: fetched now, consumed after the last MFMA (no exposed latency at the tail)
@@ -737,11 +745,12 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, BN, TILE, STATS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G::BUF_BYTES);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G::BUF_BYTES + 8 * 1024);
     attr_set = true;
   }
   TimedLaunch tl(KS == 3 ? MDIE_K_CONV3 : MDIE_K_CONV1);
-  hipLaunchKernelGGL((conv_kernel<T, KS, BN, TILE, STATS>), grid, dim3(CONV_THREADS), G::BUF_BYTES, stream, a);
+  const size_t lds = G::BUF_BYTES + (a.pre_scale ? (size_t)2 * a.nchunk * Traits<T>::KC * sizeof(float) : 0);
+  hipLaunchKernelGGL((conv_kernel<T, KS, BN, TILE, STATS>), grid, dim3(CONV_THREADS), lds, stream, a);
   MDIE_LAUNCH_CHECK("mdie_conv_fwd");
   return MDIE_OK;
 }
