@@ -633,7 +633,7 @@ struct FirstArgs {
 };
 
 template <typename T, int BN>
-__global__ __launch_bounds__(CONV_THREADS) void conv_first_kernel(const FirstArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_kernel(const FirstArgs a) {
   constexpr int TILE = 16, PW = TILE + 2;
   constexpr int E = sizeof(T);
   constexpr int NCS = BN / 16, NPS = 4;
