@@ -29,6 +29,8 @@ void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
 
 typedef __bf16 bf16;
 
@@ -74,6 +76,36 @@ template <> struct Vec16<bf16> {
   }
   __device__ __forceinline__ static uint4 pack(const float* f) {
     return make_uint4(bf_pack(f[0], f[1]), bf_pack(f[2], f[3]), bf_pack(f[4], f[5]), bf_pack(f[6], f[7]));
+  }
+};
+
+// relu(x * s + b) on the VEC channels of a 16-byte unit (the DenseLayer pre-activation, models/cdan.py:35-36, folded BatchNorm).
+// Issue-bound kernels stage every input unit through this, so it is written for instruction count: packed fp32 FMAs
+// (v_pk_fma_f32), one v_cvt_pk_bf16_f32 per pair, and the ReLU AFTER rounding as a packed int16 max (rounding keeps the
+// sign, so max(bits, 0) on the bf16 halves equals rounding relu(x)): 20 VALU instructions per unit instead of 28.
+template <typename T> struct PreAct;
+template <> struct PreAct<bf16> {
+  static constexpr int NP = 4;
+  __device__ __forceinline__ static uint4 apply(const uint4& v, const f32x2 (&s)[4], const f32x2 (&b)[4]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 x = {bf_lo(w[i]), bf_hi(w[i])};
+      const f32x2 r = __builtin_elementwise_fma(x, s[i], b[i]);
+      const i16x2 m = __builtin_elementwise_max(__builtin_bit_cast(i16x2, __builtin_convertvector(r, bf16x2)), i16x2{0, 0});
+      o[i] = __builtin_bit_cast(uint32_t, m);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+  }
+};
+template <> struct PreAct<float> {
+  static constexpr int NP = 2;
+  __device__ __forceinline__ static uint4 apply(const uint4& v, const f32x2 (&s)[2], const f32x2 (&b)[2]) {
+    const f32x2 r0 = __builtin_elementwise_fma(f32x2{__uint_as_float(v.x), __uint_as_float(v.y)}, s[0], b[0]);
+    const f32x2 r1 = __builtin_elementwise_fma(f32x2{__uint_as_float(v.z), __uint_as_float(v.w)}, s[1], b[1]);
+    return make_uint4(__float_as_uint(fmaxf(r0.x, 0.f)), __float_as_uint(fmaxf(r0.y, 0.f)),
+                      __float_as_uint(fmaxf(r1.x, 0.f)), __float_as_uint(fmaxf(r1.y, 0.f)));
   }
 };
 

@@ -84,6 +84,14 @@ __device__ __forceinline__ void tile_pixel(int ps, int p, int& y, int& x) {
   y = 2 * (blk / BPR) + ((p >> 1) & 1);
   x = 2 * (blk % BPR) + (p & 1);
 }
+// A wave's NPS subtiles start on a multiple of NPS, so subtile ps of the wave sits at a compile-time offset from
+// subtile 0 (TILE = 16: 4 subtiles = a 4x16 strip of rows, dy = 2*(ps/2), dx = 8*(ps%2)): every per-subtile address
+// is one lane-dependent base plus a wave-uniform constant, instead of a fresh index computation per subtile.
+template <int TILE, int NPS> struct TileStep {
+  static_assert(NPS == 1 || (TILE == 16 && NPS == 4), "subtile offsets are derived for 8x8 (1 subtile) and 16x16 (4 subtiles) tiles");
+  __device__ __forceinline__ static constexpr int dy(int ps) { return 2 * (ps >> 1); }
+  __device__ __forceinline__ static constexpr int dx(int ps) { return 8 * (ps & 1); }
+};
 
 // ---- epilogue: affine, activation, residual, 2x2 max-pool, NHWC store -----------------------------------------
 // max over the 4 lanes of a quad (the 2x2 pooling window) with DPP quad_perm swaps: no LDS traffic
@@ -104,18 +112,25 @@ template <typename T, int NCS, int NPS, int TILE, int ACT, bool POOL, bool STATS
 __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (&esc)[NCS], const float4 (&esh)[NCS],
                                                 f32x4 (&acc)[NCS][NPS], int img, int y0, int x0, int n0, int ps_base, int lq, int lp,
                                                 float (*st_sum)[4] = nullptr, float (*st_max)[4] = nullptr) {
-  const int Ho = POOL ? e.H >> 1 : e.H, Wo = POOL ? e.W >> 1 : e.W;
+  using TS = TileStep<TILE, NPS>;
+  constexpr int SH = POOL ? 1 : 0;
+  const int Ho = e.H >> SH, Wo = e.W >> SH;
+  int ty0, tx0;
+  tile_pixel<TILE>(ps_base, lp, ty0, tx0);
+  const int gy0 = y0 + ty0, gx0 = x0 + tx0;
+  const int oy0 = gy0 >> SH, ox0 = gx0 >> SH;
+  const size_t opix0 = ((size_t)img * Ho + oy0) * Wo + ox0;
+  T* const orow0 = reinterpret_cast<T*>(e.out) + opix0 * e.out_stride + n0 + lq * 4;
+  const T* const rrow0 = e.residual ? reinterpret_cast<const T*>(e.residual) + opix0 * e.res_stride + n0 + lq * 4 : nullptr;
 #pragma unroll
   for (int ps = 0; ps < NPS; ++ps) {
-    int y, x;
-    tile_pixel<TILE>(ps_base + ps, lp, y, x);
-    const int gy = y0 + y, gx = x0 + x;
+    const int gy = gy0 + TS::dy(ps), gx = gx0 + TS::dx(ps);
     const bool inside = gy < e.H && gx < e.W;
     const bool writer = POOL ? (inside && (lp & 3) == 0) : inside;
-    const int oy = POOL ? gy >> 1 : gy, ox = POOL ? gx >> 1 : gx;
-    const size_t opix = ((size_t)img * Ho + oy) * Wo + ox;
-    T* orow = reinterpret_cast<T*>(e.out) + opix * e.out_stride + n0 + lq * 4;
-    const T* rrow = e.residual ? reinterpret_cast<const T*>(e.residual) + opix * e.res_stride + n0 + lq * 4 : nullptr;
+    const int oy = oy0 + (TS::dy(ps) >> SH), ox = ox0 + (TS::dx(ps) >> SH);
+    const int dpix = (TS::dy(ps) >> SH) * Wo + (TS::dx(ps) >> SH);   // wave-uniform
+    T* orow = orow0 + (ptrdiff_t)dpix * e.out_stride;
+    const T* rrow = rrow0 ? rrow0 + (ptrdiff_t)dpix * e.res_stride : nullptr;
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs) {
       const float4 sc = esc[cs], sh = esh[cs];
@@ -332,13 +347,13 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
     int pd = pdst0;
     // pre-activation constants of this thread's channels: read from their LDS copy here, not loaded with the chunk
     // (where 16 registers would stay live across the whole MFMA phase)
-    float ps_[VEC], pb_[VEC];
+    f32x2 ps_[VEC / 2], pb_[VEC / 2];
     if (has_pre && chunk_live) {
 #pragma unroll
       for (int i = 0; i < VEC; i += 4) {
         const float4 s4 = *reinterpret_cast<const float4*>(lds_pre + chunk_c0 + i), b4 = *reinterpret_cast<const float4*>(lds_pre + kpad + chunk_c0 + i);
-        ps_[i] = s4.x; ps_[i + 1] = s4.y; ps_[i + 2] = s4.z; ps_[i + 3] = s4.w;
-        pb_[i] = b4.x; pb_[i + 1] = b4.y; pb_[i + 2] = b4.z; pb_[i + 3] = b4.w;
+        ps_[i / 2] = f32x2{s4.x, s4.y}; ps_[i / 2 + 1] = f32x2{s4.z, s4.w};
+        pb_[i / 2] = f32x2{b4.x, b4.y}; pb_[i / 2 + 1] = f32x2{b4.z, b4.w};
       }
     }
 #pragma unroll
@@ -346,13 +361,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
       if (it < PATCH_IT - 1 || wave < PATCH_LAST_WAVES) {
         if (it < PATCH_IT - 1 || tid < LAST_UNITS) {
           uint4 v = pv[it];
-          if (has_pre && chunk_live && ((ginside >> it) & 1)) {
-            float f[VEC];
-            Vec16<T>::unpack(v, f);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) f[i] = fmaxf(fmaf(f[i], ps_[i], pb_[i]), 0.0f);
-            v = Vec16<T>::pack(f);
-          }
+          if (has_pre && chunk_live && ((ginside >> it) & 1)) v = PreAct<T>::apply(v, ps_, pb_);
           *reinterpret_cast<uint4*>(lds_patch + pd) = v;
         }
       }
@@ -392,14 +401,14 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
 #pragma unroll
     for (int j = 0; j < NPS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // per-lane LDS read offsets
-  int xoff[NPS];
-#pragma unroll
-  for (int ps = 0; ps < NPS; ++ps) {
+  // per-lane LDS read offset of pixel subtile 0; the other subtiles are compile-time offsets from it (TileStep)
+  int xoff0;
+  {
     int y, x;
-    tile_pixel<TILE>(wave * NPS + ps, lp, y, x);
-    xoff[ps] = lq * G::PLANE + (y * PWP + x) * 16;
+    tile_pixel<TILE>(wave * NPS, lp, y, x);
+    xoff0 = lq * G::PLANE + (y * PWP + x) * 16;
   }
+  using TS = TileStep<TILE, NPS>;
   const int woff = lq * G::WPLANE + lp * 16;
 
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
         wf[cs] = *reinterpret_cast<const uint4*>(lds_w + (tap * BN + cs * 16) * 16 + woff);
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps)
-        xf[ps] = *reinterpret_cast<const uint4*>(lds_patch + (kh * PWP + kw) * 16 + xoff[ps]);
+        xf[ps] = *reinterpret_cast<const uint4*>(lds_patch + ((kh + TS::dy(ps)) * PWP + kw + TS::dx(ps)) * 16 + xoff0);
 #pragma unroll
       for (int cs = 0; cs < NCS; ++cs)
 #pragma unroll
@@ -562,21 +571,15 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv1x1_stream_kernel(const C
       if (chunk + 1 < a.nchunk) load_chunk(chunk + 1, xn);      // in flight during this chunk's MFMAs
       if (PRE) {
         const int c0 = chunk * KC + lq * VEC;
-        float psc[VEC], psh[VEC];
+        f32x2 psc[VEC / 2], psh[VEC / 2];
 #pragma unroll
         for (int i = 0; i < VEC; i += 4) {
           const float4 s4 = *reinterpret_cast<const float4*>(lds_pre + c0 + i), b4 = *reinterpret_cast<const float4*>(lds_pre + kpad + c0 + i);
-          psc[i] = s4.x; psc[i + 1] = s4.y; psc[i + 2] = s4.z; psc[i + 3] = s4.w;
-          psh[i] = b4.x; psh[i + 1] = b4.y; psh[i + 2] = b4.z; psh[i + 3] = b4.w;
+          psc[i / 2] = f32x2{s4.x, s4.y}; psc[i / 2 + 1] = f32x2{s4.z, s4.w};
+          psh[i / 2] = f32x2{b4.x, b4.y}; psh[i / 2 + 1] = f32x2{b4.z, b4.w};
         }
 #pragma unroll
-        for (int ps = 0; ps < NPS; ++ps) {
-          float f[VEC];
-          Vec16<T>::unpack(xf[ps], f);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) f[i] = fmaxf(fmaf(f[i], psc[i], psh[i]), 0.0f);
-          xf[ps] = Vec16<T>::pack(f);   // (channels beyond cin have scale = shift = 0 and zero weights)
-        }
+        for (int ps = 0; ps < NPS; ++ps) xf[ps] = PreAct<T>::apply(xf[ps], psc, psh);   // (channels beyond cin have scale = shift = 0 and zero weights)
       }
       uint4 wf[NCS];
 #pragma unroll

@@ -11,6 +11,7 @@ SHAPES = {
     "conv2": ([64], 128, 128, 3, True, False), "conv4": ([256], 512, 32, 3, False, False),
     "d1l3": ([64, 16, 16, 16], 16, 128, 3, False, True), "fl3": ([16, 16, 16, 16], 16, 256, 3, False, True),
     "ftr": ([16, 16, 16, 16, 16], 16, 256, 1, False, True),
+    "fl0": ([8], 16, 256, 3, False, True), "fl1": ([8, 16], 16, 256, 3, False, True),
 }
 dt = L.BF16
 td = torch.bfloat16
