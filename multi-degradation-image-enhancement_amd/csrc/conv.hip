@@ -52,7 +52,7 @@ struct EpiArgs {
 
 struct ConvArgs {
   int B, H, W;
-  int tiles_x, tiles_y, n_tiles, n_tiles_log2;
+  int tiles_x, tiles_y, n_tiles;
   int cin, nchunk, cout;
   int nseg;
   SegDev seg[MDIE_MAX_SEG];
@@ -742,8 +742,11 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   // One tile per workgroup.  (Measured on MI355X: persistent workgroups walking the flattened
   // (tile, chunk) stages with two LDS stage buffers were 5-25 % SLOWER on every layer shape --
   // the doubled LDS/VGPR footprint halves the resident workgroups, and resident workgroups are what
-  // hides the staging latency here.)
-  a.n_tiles_log2 = 0;
+  // hides the staging latency here.  A persistent variant WITHOUT the second stage -- single-chunk 16-output layers,
+  // weights and constants in LDS once per workgroup, next tile's patch prefetched into registers across the MFMA phase
+  // and the epilogue, same 4 workgroups per CU -- measured exactly the time of this kernel (final.l0/l1 47.7/48.4 us
+  // vs 48.2/50.8 us), as did the same launch with its stores compiled out (43/52 us): per tile these layers cost
+  // ~13 k cycles of a CU slot whether or not setup, weight staging, load latency or stores are on the path.)
   const dim3 grid(8, a.n_tiles, cdiv(a.tiles_x * a.tiles_y * a.B, 8));
   static bool attr_set = false;
   if (!attr_set) {

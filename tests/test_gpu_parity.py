@@ -456,6 +456,49 @@ def test_run_py_test_phase_end_to_end(E, tmp_path):
     assert len(run_dirs) == 1 and os.path.exists(os.path.join(root, "runs", "noise_example", run_dirs[0], "summary.json"))
 
 
+@pytest.mark.parametrize("prec,cin_segs", [("bf16", [8]), ("bf16", [8, 16]), ("bf16", [16, 8, 8]), ("fp32", [8]), ("fp32", [4, 8, 4])])
+@pytest.mark.parametrize("shape,pre", [((4, 200, 216), True), ((5, 176, 160), False)])
+def test_thin_single_chunk_conv(E, L, prec, cin_segs, shape, pre):
+    """3x3 convolution with 16 outputs whose input fits one K chunk (the first DenseLayers of final_dense, models/cdan.py:150)
+    on a grid large enough for 16x16 tiles (>= 512 workgroups).  Ragged tile edges, several input segments with
+    their own strides, pre-activation BN+ReLU, output written into a slice of a wider buffer; checked against torch's CPU
+    convolution on the same (bf16-rounded where stored as bf16) operands."""
+    import ctypes as C
+    import torch.nn.functional as F
+    bf = prec == "bf16"
+    dt, td = (L.BF16, torch.bfloat16) if bf else (L.F32, torch.float32)
+    rnd = (lambda t: t.bfloat16().float()) if bf else (lambda t: t)
+    B, H, W = shape
+    cin, cout = sum(cin_segs), 16
+    g = torch.Generator().manual_seed(cin * 7 + H)
+    strides = [c + (8 if i % 2 else 0) for i, c in enumerate(cin_segs)]
+    bufs = [rnd(torch.randn(B, H, W, st, generator=g)) for st in strides]
+    w = rnd(torch.randn(cout, cin, 3, 3, generator=g) * 0.2)
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ps, pt = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    x = torch.cat([b[..., :c] for b, c in zip(bufs, cin_segs)], 3)
+    xa = rnd(torch.relu(x * ps + pt)) if pre else x
+    ref = torch.relu(F.conv2d(xa.permute(0, 3, 1, 2), w, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+
+    dbufs = [b.cuda().to(td) for b in bufs]
+    wp = E.pack_conv_weight(w, dt, cin_stored=cin).cuda()
+    dsc, dsh, dps, dpt = sc.cuda(), sh.cuda(), ps.cuda(), pt.cuda()
+    out = torch.full((B, H, W, 40), -7.0, device="cuda", dtype=td)
+    d = L.ConvDesc()
+    d.dtype, d.B, d.H, d.W, d.ksize, d.nseg = dt, B, H, W, 3, len(dbufs)
+    for i, (b, c) in enumerate(zip(dbufs, cin_segs)):
+        d.inp[i] = L.Seg(b.data_ptr(), c, b.shape[3])
+    d.cin, d.cout = cin, cout
+    d.pre_scale, d.pre_shift = (dps.data_ptr(), dpt.data_ptr()) if pre else (None, None)
+    d.weight, d.post_scale, d.post_shift = wp.data_ptr(), dsc.data_ptr(), dsh.data_ptr()
+    d.act, d.pool = L.ACT_RELU, 0
+    d.out, d.out_stride = out[..., 16:].data_ptr(), 40
+    L.check(L.lib.mdie_conv_fwd(C.byref(d), None), "mdie_conv_fwd")
+    torch.cuda.synchronize()
+    assert rel_to_max(out[..., 16:32], ref) <= (8e-3 if bf else 2e-5)
+    assert (out[..., :16] == -7.0).all() and (out[..., 32:] == -7.0).all()     # nothing written outside the slice
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # training mode (SURVEY.md 8a rows a5, a13, a14): HIP convolutions (forward / dgrad / wgrad) under autograd
 # ---------------------------------------------------------------------------------------------------------------------
