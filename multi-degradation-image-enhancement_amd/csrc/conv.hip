@@ -240,7 +240,8 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_patch = smem;
   char* lds_w = smem + 4 * G::PLANE;
-  float* lds_pre = reinterpret_cast<float*>(smem + G::BUF_BYTES);   // [2][nchunk * KC] pre_scale, pre_shift (when present)
+  float* lds_epi = reinterpret_cast<float*>(smem + G::BUF_BYTES);   // [2][BN] post_scale, post_shift of this workgroup's output channels
+  float* lds_pre = lds_epi + 2 * BN;                                // [2][nchunk * KC] pre_scale, pre_shift (when present)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -377,23 +378,35 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
   };
 
   STAMP(1);
-  load_chunk(0);   // first memory requests leave before the rest of the bookkeeping
+  // Launch constants (pre-activation scale/shift of the input channels, post scale/shift of this workgroup's output
+  // channels) go to LDS.  Their loads are issued BEFORE the first chunk's and their LDS writes come AFTER it is issued:
+  // vector loads return in order, so the writes wait for these few dwords only (a counted vmcnt), not for the patch.
+  constexpr int PRE_IT = 2;   // covers 512 input channels; more take the loop below
+  float cpre[2][PRE_IT], cepi[2];
+  if (has_pre) {
+#pragma unroll
+    for (int i = 0; i < PRE_IT; ++i) {
+      const int c = tid + i * CONV_THREADS;
+      cpre[0][i] = c < a.cin ? a.pre_scale[c] : 0.f;
+      cpre[1][i] = c < a.cin ? a.pre_shift[c] : 0.f;
+    }
+  }
+  if (tid < BN) { cepi[0] = a.e.post_scale[n0 + tid]; cepi[1] = a.e.post_shift[n0 + tid]; }
+  load_chunk(0);
   if (has_pre) {   // launch-uniform
-    for (int c = tid; c < kpad; c += CONV_THREADS) {
+#pragma unroll
+    for (int i = 0; i < PRE_IT; ++i) {
+      const int c = tid + i * CONV_THREADS;
+      if (c < kpad) { lds_pre[c] = cpre[0][i]; lds_pre[kpad + c] = cpre[1][i]; }
+    }
+    for (int c = tid + PRE_IT * CONV_THREADS; c < kpad; c += CONV_THREADS) {
       lds_pre[c] = c < a.cin ? a.pre_scale[c] : 0.f;
       lds_pre[kpad + c] = c < a.cin ? a.pre_shift[c] : 0.f;
     }
-    __syncthreads();
   }
+  if (tid < BN) { lds_epi[tid] = cepi[0]; lds_epi[BN + tid] = cepi[1]; }   // read back after the last MFMA: visible after any barrier below
+  if (has_pre) __syncthreads();
   STAMP(2);
-
-  // epilogue constants: fetched now, consumed after the last MFMA (no exposed latency at the tail)
-  float4 esc[NCS], esh[NCS];
-#pragma unroll
-  for (int cs = 0; cs < NCS; ++cs) {
-    esc[cs] = *reinterpret_cast<const float4*>(a.e.post_scale + n0 + cs * 16 + lq * 4);
-    esh[cs] = *reinterpret_cast<const float4*>(a.e.post_shift + n0 + cs * 16 + lq * 4);
-  }
 
   f32x4 acc[NCS][NPS];
 #pragma unroll
@@ -421,25 +434,40 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
     if (chunk < 2) STAMP(5 + 4 * chunk);
 
 #ifndef EXP_NO_MFMA
-#pragma unroll
-    for (int tap = 0; tap < NTAP; ++tap) {
+    // Operand fragments are double-buffered by hand: the reads of tap t+1 are issued before the MFMAs of tap t and pinned
+    // there (sched_barrier).  Left to itself the scheduler, at the register cap, emits ds_read -> s_waitcnt lgkmcnt(0) ->
+    // MFMA chains that expose an LDS round trip per MFMA (the MFMA phase of a 16-output tile took 2.9 k cycles for 36 MFMAs).
+    uint4 wf[2][NCS], xf[2][NPS];
+    auto read_tap = [&](int tap, int b) {
       const int kh = tap / KS, kw = tap - kh * KS;
-      uint4 wf[NCS], xf[NPS];
 #pragma unroll
       for (int cs = 0; cs < NCS; ++cs)
-        wf[cs] = *reinterpret_cast<const uint4*>(lds_w + (tap * BN + cs * 16) * 16 + woff);
+        wf[b][cs] = *reinterpret_cast<const uint4*>(lds_w + (tap * BN + cs * 16) * 16 + woff);
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps)
-        xf[ps] = *reinterpret_cast<const uint4*>(lds_patch + ((kh + TS::dy(ps)) * PWP + kw + TS::dx(ps)) * 16 + xoff0);
+        xf[b][ps] = *reinterpret_cast<const uint4*>(lds_patch + ((kh + TS::dy(ps)) * PWP + kw + TS::dx(ps)) * 16 + xoff0);
+    };
+    read_tap(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+      if (tap + 1 < NTAP) read_tap(tap + 1, (tap + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int cs = 0; cs < NCS; ++cs)
 #pragma unroll
-        for (int ps = 0; ps < NPS; ++ps) acc[cs][ps] = mma16<T>(wf[cs], xf[ps], acc[cs][ps]);
+        for (int ps = 0; ps < NPS; ++ps) acc[cs][ps] = mma16<T>(wf[tap & 1][cs], xf[tap & 1][ps], acc[cs][ps]);
+      __builtin_amdgcn_sched_barrier(0);
     }
 #endif
     if (chunk < 2) STAMP(6 + 4 * chunk);
   }
   STAMP(11);
+  float4 esc[NCS], esh[NCS];
+#pragma unroll
+  for (int cs = 0; cs < NCS; ++cs) {
+    esc[cs] = *reinterpret_cast<const float4*>(lds_epi + cs * 16 + lq * 4);
+    esh[cs] = *reinterpret_cast<const float4*>(lds_epi + BN + cs * 16 + lq * 4);
+  }
 #ifdef EXP_STAMPS
   EpiArgs e2 = a.e;
   if (dbg) { e2.residual = nullptr; e2.res_stride = 0; }
@@ -659,12 +687,10 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_kernel(const First
     for (int cs = 0; cs < NCS; ++cs)
       wf[s][cs] = *reinterpret_cast<const uint4*>(a.weight + ((size_t)s * a.cout + n0 + cs * 16 + lp) * 64 + lq * 16);
 
-  float4 esc[NCS], esh[NCS];
-#pragma unroll
-  for (int cs = 0; cs < NCS; ++cs) {
-    esc[cs] = *reinterpret_cast<const float4*>(a.e.post_scale + n0 + cs * 16 + lq * 4);
-    esh[cs] = *reinterpret_cast<const float4*>(a.e.post_shift + n0 + cs * 16 + lq * 4);
-  }
+  // epilogue constants -> LDS (written with the patch, read back per pixel subtile: 8*NCS registers less across the loop)
+  __shared__ __attribute__((aligned(16))) float lds_epi[2 * BN];
+  float cepi[2] = {0.f, 0.f};
+  if (tid < BN) { cepi[0] = a.e.post_scale[n0 + tid]; cepi[1] = a.e.post_shift[n0 + tid]; }
   // input patch: issue every global load before the first wait
   const size_t plane = (size_t)a.H * a.W;
   constexpr int PIT = (PW * PW + CONV_THREADS - 1) / CONV_THREADS;
@@ -691,6 +717,7 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_kernel(const First
       else *reinterpret_cast<float4*>(d) = make_float4(xin[it][0], xin[it][1], xin[it][2], 0.f);
     }
   }
+  if (tid < BN) { lds_epi[tid] = cepi[0]; lds_epi[BN + tid] = cepi[1]; }
   __syncthreads();
 
   // this lane's im2col columns k = tap*3 + c -> element offsets in the [pixel][4] patch (lane-constant)
@@ -705,32 +732,50 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_kernel(const First
       goff[s][i] = tap < 9 ? ((tap / 3) * PW + (tap % 3)) * 4 + c : 0;
     }
 
-#pragma unroll
-  for (int ps = 0; ps < NPS; ++ps) {
+  // gather of one pixel subtile's im2col operands; the next subtile's gather is issued before this one's MFMAs and
+  // epilogue (pinned by sched_barrier), so its LDS round trips ride under them
+  auto gather = [&](int ps, uint4 (&xf)[STEPS]) {
     int y, x;
     tile_pixel<TILE>(wave * NPS + ps, lp, y, x);
     const T* base = patch + (y * PW + x) * 4;
-    f32x4 acc[NCS][1];
-#pragma unroll
-    for (int i = 0; i < NCS; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      uint4 xf;
       if constexpr (E == 2) {
         uint32_t h[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) h[i] = *reinterpret_cast<const unsigned short*>(base + goff[s][i]);
-        xf = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        xf[s] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
       } else {
         uint32_t h[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) h[i] = *reinterpret_cast<const uint32_t*>(base + goff[s][i]);
-        xf = make_uint4(h[0], h[1], h[2], h[3]);
+        xf[s] = make_uint4(h[0], h[1], h[2], h[3]);
       }
+    }
+  };
+  constexpr bool AHEAD = E == 2;   // (the f32 variant has no registers left for a second operand buffer at 4 waves/SIMD)
+  uint4 xf[2][STEPS];
+  if constexpr (AHEAD) gather(0, xf[0]);
 #pragma unroll
-      for (int cs = 0; cs < NCS; ++cs) acc[cs][0] = mma16<T>(wf[s][cs], xf, acc[cs][0]);
+  for (int ps = 0; ps < NPS; ++ps) {
+    if constexpr (AHEAD) { if (ps + 1 < NPS) gather(ps + 1, xf[(ps + 1) & 1]); }
+    else gather(ps, xf[ps & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[NCS][1];
+#pragma unroll
+    for (int i = 0; i < NCS; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+      for (int cs = 0; cs < NCS; ++cs) acc[cs][0] = mma16<T>(wf[s][cs], xf[ps & 1][s], acc[cs][0]);
+    float4 esc[NCS], esh[NCS];
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs) {
+      esc[cs] = *reinterpret_cast<const float4*>(lds_epi + cs * 16 + lq * 4);
+      esh[cs] = *reinterpret_cast<const float4*>(lds_epi + BN + cs * 16 + lq * 4);
     }
     conv_epilogue<T, NCS, 1, TILE>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS + ps, lq, lp);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -755,7 +800,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     attr_set = true;
   }
   TimedLaunch tl(KS == 3 ? MDIE_K_CONV3 : MDIE_K_CONV1);
-  const size_t lds = G::BUF_BYTES + (a.pre_scale ? (size_t)2 * a.nchunk * Traits<T>::KC * sizeof(float) : 0);
+  const size_t lds = G::BUF_BYTES + 2 * BN * sizeof(float) + (a.pre_scale ? (size_t)2 * a.nchunk * Traits<T>::KC * sizeof(float) : 0);
   hipLaunchKernelGGL((conv_kernel<T, KS, BN, TILE, STATS>), grid, dim3(CONV_THREADS), lds, stream, a);
   MDIE_LAUNCH_CHECK("mdie_conv_fwd");
   return MDIE_OK;
