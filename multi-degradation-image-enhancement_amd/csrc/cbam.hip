@@ -8,6 +8,11 @@
 // finish), and the global pools are deterministic two-level reductions (no float atomics).
 #include "common.hpp"
 
+// No implicit FMA contraction in this file: its loops are unrolled, and the unrolled body and the remainder loop must
+// round identically -- which copy handles a pixel depends on the grid, i.e. on the batch size, and an image's result
+// must not (tests/test_gpu_parity.py::test_full_batch_properties).  Fused multiply-adds are written as fmaf() where wanted.
+#pragma clang fp contract(off)
+
 namespace mdie {
 
 constexpr int CB_THREADS = 256;
@@ -48,7 +53,8 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_pool_kernel(const CbamArgs a)
   float s[VEC], m[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { s[i] = 0.f; m[i] = -INFINITY; }
-  for (int p = p_begin + r; p < p_end; p += rows) {
+#pragma unroll 4
+  for (int p = p_begin + r; p < p_end; p += rows) {   // (unrolled: 4 independent 16-byte loads in flight per thread)
     const uint4 u = *reinterpret_cast<const uint4*>(a.x + ((size_t)img * npix + p) * a.x_stride * sizeof(T) + (size_t)v * 16);
     float f[VEC];
     Vec16<T>::unpack(u, f);
@@ -76,19 +82,40 @@ __device__ __forceinline__ void cbam_gate_block(const CbamArgs& a, int img, floa
   const int Hd = a.C / 16;
   const int tid = threadIdx.x;
   const float inv = 1.0f / (float)(a.H * a.W);
-  for (int c = tid; c < a.C; c += CB_THREADS) {
-    float s = 0.f, m = -INFINITY;
-    for (int k = 0; k < a.nslab; ++k) {
-      const float* p = a.partial + ((size_t)img * a.nslab + k) * 2 * a.C;
-      s += p[c];
-      m = fmaxf(m, p[a.C + c]);
+  // Every phase of this block is a chain of dependent L2 round trips unless its loads are issued together (the block ran
+  // 15-30 us of a 25-35 us launch that way), so each phase spreads its loads over all 256 threads and unrolls them.
+  // Phase 1: fold the pooled partials of the image's slabs.  Thread = (channel c, slab class q): class q sums slabs
+  // q, q+P, q+2P, ... in order, then the classes are combined in order -- fixed by (C, nslab) alone, i.e. by the resolution.
+  {
+    const int cg = a.C < CB_THREADS ? a.C : CB_THREADS;   // threads along the channels
+    const int P = CB_THREADS / cg;                        // slab classes (1 when C >= 256)
+    const int q = tid / cg;
+    for (int c = tid - q * cg; c < a.C; c += cg) {
+      float s = 0.f, m = -INFINITY;
+      const float* p = a.partial + (size_t)img * a.nslab * 2 * a.C + c;
+#pragma unroll 8
+      for (int k = q; k < a.nslab; k += P) {
+        s += p[(size_t)k * 2 * a.C];
+        m = fmaxf(m, p[(size_t)k * 2 * a.C + a.C]);
+      }
+      if (P == 1) { avg[c] = s * inv; mx[c] = m; }
+      else { part[q * cg + c] = s; part[CB_THREADS + q * cg + c] = m; }
     }
-    avg[c] = s * inv;
-    mx[c] = m;
+    if (P > 1) {
+      __syncthreads();
+      if (tid < a.C) {
+        float s = 0.f, m = -INFINITY;
+        for (int k = 0; k < P; ++k) { s += part[k * cg + tid]; m = fmaxf(m, part[CB_THREADS + k * cg + tid]); }
+        avg[tid] = s * inv;
+        mx[tid] = m;
+      }
+    }
   }
   __syncthreads();
+  // Phase 2: hidden layer, split over (unit j, part q): 256/Hd parts per unit, each a contiguous run of C/parts channels for
+  // BOTH pooled vectors (a per-output loop serialises 2*Hd cold-miss round trips: 42 us at C=512)
   const int parts = CB_THREADS / Hd;           // 8 (C=512) .. 256 (C=16)
-  const int run = a.C / parts > 0 ? a.C / parts : 1;  // channels per part
+  const int run = a.C / parts > 0 ? a.C / parts : 1;  // channels per part: 1 (C<=64), 4, 16, 64
   {
     const int j = tid / parts, q = tid - j * parts;
     float sa = 0.f, sm = 0.f;
@@ -96,7 +123,18 @@ __device__ __forceinline__ void cbam_gate_block(const CbamArgs& a, int img, floa
       const int c0 = q * run;
       if (c0 < a.C) {
         const float* w = a.w1 + (size_t)j * a.C + c0;
-        for (int i = 0; i < run; ++i) { const float wv = w[i]; sa = fmaf(wv, avg[c0 + i], sa); sm = fmaf(wv, mx[c0 + i], sm); }
+        if (run >= 4 && ((uintptr_t)w & 15) == 0) {   // 16-byte aligned runs: all their loads in flight at once
+#pragma unroll 4
+          for (int i = 0; i < run; i += 4) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + i);
+            sa = fmaf(wv.x, avg[c0 + i], sa); sm = fmaf(wv.x, mx[c0 + i], sm);
+            sa = fmaf(wv.y, avg[c0 + i + 1], sa); sm = fmaf(wv.y, mx[c0 + i + 1], sm);
+            sa = fmaf(wv.z, avg[c0 + i + 2], sa); sm = fmaf(wv.z, mx[c0 + i + 2], sm);
+            sa = fmaf(wv.w, avg[c0 + i + 3], sa); sm = fmaf(wv.w, mx[c0 + i + 3], sm);
+          }
+        } else {
+          for (int i = 0; i < run; ++i) { const float wv = w[i]; sa = fmaf(wv, avg[c0 + i], sa); sm = fmaf(wv, mx[c0 + i], sm); }
+        }
       }
     }
     part[tid] = sa;
@@ -113,7 +151,15 @@ __device__ __forceinline__ void cbam_gate_block(const CbamArgs& a, int img, floa
   for (int c = tid; c < a.C; c += CB_THREADS) {
     float s = 2.0f * a.b2[c];  // the MLP (bias included) is applied to both pooled vectors
     const float* w = a.w2 + (size_t)c * Hd;
-    for (int j = 0; j < Hd; ++j) s = fmaf(w[j], hid[j], s);
+    if (Hd >= 4 && ((uintptr_t)w & 15) == 0) {
+#pragma unroll 4
+      for (int j = 0; j < Hd; j += 4) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + j);
+        s = fmaf(wv.x, hid[j], s); s = fmaf(wv.y, hid[j + 1], s); s = fmaf(wv.z, hid[j + 2], s); s = fmaf(wv.w, hid[j + 3], s);
+      }
+    } else {
+      for (int j = 0; j < Hd; ++j) s = fmaf(w[j], hid[j], s);
+    }
     gate[c] = sigmoidf(s);
   }
   __syncthreads();
@@ -129,6 +175,10 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_gate_kernel(const CbamArgs a)
   float* gate = hid + a.C / 16;
   cbam_gate_block(a, blockIdx.x, avg, mx, part, hid, gate);
   for (int c = threadIdx.x; c < a.C; c += CB_THREADS) a.gate[(size_t)blockIdx.x * a.C + c] = gate[c];
+}
+
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
 // ---- pass 3 ----------------------------------------------------------------------------------------
@@ -158,19 +208,56 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_chanpool_kernel(const CbamArg
 #pragma unroll
     for (int i = 0; i < VEC; ++i) g[k][i] = gsh[(k * LPP + sub) * VEC + i];
   const float invC = 1.0f / (float)a.C;
-  for (int p = blockIdx.x * groups + tid / LPP; p < npix; p += gridDim.x * groups) {
-    const char* px = a.x + ((size_t)img * npix + p) * a.x_stride * sizeof(T);
-    float m = -INFINITY, s = 0.f;
+  // The loop is latency-bound (one 16-byte load per lane and pixel, then a shuffle reduction): U pixels per lane are
+  // processed together, their loads issued back to back and their reductions interleaved.  (x and map never overlap.)
+  const char* __restrict__ xsrc = a.x;
+  float* __restrict__ mdst = a.map;
+  constexpr int U = 2;   // (U = 4 measured slower on the 64x64 and 128x128 maps, U = 1 and 2 equal)
+  // a lane's U pixels are neighbours, so a block reads one contiguous run of U * groups pixels per iteration (U streams a
+  // power-of-two distance apart were measured SLOWER than U = 1 on the large maps)
+  const int pstep = gridDim.x * groups * U;
+  for (int p0 = (blockIdx.x * groups + tid / LPP) * U; p0 < npix; p0 += pstep) {
+    uint4 u[U][NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const uint4 u = *reinterpret_cast<const uint4*>(px + (size_t)(k * LPP + sub) * 16);
-      float f[VEC];
-      Vec16<T>::unpack(u, f);
+    for (int j = 0; j < U; ++j) {
+      const int p = p0 + j;
+      const char* px = xsrc + ((size_t)img * npix + (p < npix ? p : p0)) * a.x_stride * sizeof(T);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) { const float y = f[i] * g[k][i]; m = fmaxf(m, y); s += y; }
+      for (int k = 0; k < NV; ++k) u[j][k] = *reinterpret_cast<const uint4*>(px + (size_t)(k * LPP + sub) * 16);
     }
-    for (int d = LPP >> 1; d > 0; d >>= 1) { m = fmaxf(m, __shfl_xor(m, d)); s += __shfl_xor(s, d); }
-    if (sub == 0) *reinterpret_cast<float2*>(a.map + ((size_t)img * npix + p) * 2) = make_float2(m, s * invC);
+    float m[U], s[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      m[j] = -INFINITY; s[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        float f[VEC];
+        Vec16<T>::unpack(u[j][k], f);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { const float y = f[i] * g[k][i]; m[j] = fmaxf(m[j], y); s[j] += y; }
+      }
+    }
+    // all-reduce over the LPP lanes of a pixel: DPP lane swaps inside a 16-lane row (no LDS crossbar round trip per step),
+    // ds_bpermute only across rows.  After each step every lane of the reduced subgroup holds the same value, so the
+    // mirror swaps pair exactly the partial sums the xor butterfly pairs: bit-identical to a __shfl_xor tree.
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      float mm = m[j], ss = s[j];
+      if (LPP >= 2) { mm = fmaxf(mm, dpp_f<0xB1>(mm)); ss += dpp_f<0xB1>(ss); }     // quad_perm [1,0,3,2]
+      if (LPP >= 4) { mm = fmaxf(mm, dpp_f<0x4E>(mm)); ss += dpp_f<0x4E>(ss); }     // quad_perm [2,3,0,1]
+      if (LPP >= 8) { mm = fmaxf(mm, dpp_f<0x141>(mm)); ss += dpp_f<0x141>(ss); }   // row_half_mirror
+      if (LPP >= 16) { mm = fmaxf(mm, dpp_f<0x140>(mm)); ss += dpp_f<0x140>(ss); }  // row_mirror
+      if (LPP >= 32) { mm = fmaxf(mm, __shfl_xor(mm, 16)); ss += __shfl_xor(ss, 16); }
+      if (LPP >= 64) { mm = fmaxf(mm, __shfl_xor(mm, 32)); ss += __shfl_xor(ss, 32); }
+      m[j] = mm; s[j] = ss;
+    }
+    if (sub == 0) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int p = p0 + j;
+        if (p < npix) *reinterpret_cast<float2*>(mdst + ((size_t)img * npix + p) * 2) = make_float2(m[j], s[j] * invC);
+      }
+    }
   }
 }
 
@@ -188,6 +275,31 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_spatial_kernel(const CbamArgs
   const int tiles_x = cdiv(a.W, TS);
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, img = blockIdx.y;
   const int y0 = ty * TS, x0 = tx * TS;
+  // ---- the streaming part (x * gate * s [* mul] -> out) is a chain of memory round trips unless its loads are batched:
+  // U units (16 bytes of one pixel each) per thread are fetched together, clamped to the tile origin where a unit lies
+  // outside the image, and the first batch is requested before the gate / 7x7 phases so that it arrives under them.
+  // (out may coincide with x -- every unit is read before it is written by the same thread -- but not overlap it otherwise.)
+  constexpr int U = 4;
+  const int CV = a.C / VEC;
+  const int total = TS * TS * CV;
+  const char* __restrict__ xsrc = a.x;
+  const char* __restrict__ msrc = a.mul;
+  char* __restrict__ odst = a.out;
+  const size_t gp_origin = ((size_t)img * a.H + y0) * a.W + x0;
+  auto load_batch = [&](int u0, uint4 (&xv)[U], uint4 (&mv)[U]) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int u = u0 + j * CB_THREADS;
+      const int uu = u < total ? u : tid;
+      const int pix = uu / CV, v = uu - pix * CV;
+      const int gy = y0 + pix / TS, gx = x0 + pix % TS;
+      const size_t gp = (gy < a.H && gx < a.W) ? ((size_t)img * a.H + gy) * a.W + gx : gp_origin;
+      xv[j] = *reinterpret_cast<const uint4*>(xsrc + gp * a.x_stride * sizeof(T) + (size_t)v * 16);
+      if (msrc) mv[j] = *reinterpret_cast<const uint4*>(msrc + gp * a.mul_stride * sizeof(T) + (size_t)v * 16);
+    }
+  };
+  uint4 xv[U], mv[U];
+  load_batch(tid, xv, mv);
   for (int c = tid; c < a.C; c += CB_THREADS) gate[c] = a.gate[(size_t)img * a.C + c];
   if (a.spatial) {
     for (int i = tid; i < PW * PW; i += CB_THREADS) {
@@ -219,27 +331,37 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_spatial_kernel(const CbamArgs
     sg[tid] = s;
   }
   __syncthreads();
-  const int CV = a.C / VEC;
-  const int total = TS * TS * CV;
-  for (int u = tid; u < total; u += CB_THREADS) {
-    const int pix = u / CV, v = u - pix * CV;
-    const int gy = y0 + pix / TS, gx = x0 + pix % TS;
-    if (gy >= a.H || gx >= a.W) continue;
-    const size_t gp = ((size_t)img * a.H + gy) * a.W + gx;
-    const uint4 xv = *reinterpret_cast<const uint4*>(a.x + gp * a.x_stride * sizeof(T) + (size_t)v * 16);
-    float f[VEC];
-    Vec16<T>::unpack(xv, f);
-    const float s = sg[pix];
+  for (int u0 = tid; u0 < total; u0 += U * CB_THREADS) {
+    uint4 xn[U], mn[U];
+    const bool more = u0 + U * CB_THREADS < total;   // block-uniform
+    if (more) load_batch(u0 + U * CB_THREADS, xn, mn);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) f[i] = f[i] * gate[v * VEC + i] * s;
-    if (a.mul) {
-      const uint4 mv = *reinterpret_cast<const uint4*>(a.mul + gp * a.mul_stride * sizeof(T) + (size_t)v * 16);
-      float m[VEC];
-      Vec16<T>::unpack(mv, m);
+    for (int j = 0; j < U; ++j) {
+      const int u = u0 + j * CB_THREADS;
+      if (u < total) {
+        const int pix = u / CV, v = u - pix * CV;
+        const int gy = y0 + pix / TS, gx = x0 + pix % TS;
+        if (gy < a.H && gx < a.W) {
+          const size_t gp = ((size_t)img * a.H + gy) * a.W + gx;
+          float f[VEC];
+          Vec16<T>::unpack(xv[j], f);
+          const float sv = sg[pix];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) f[i] *= m[i];
+          for (int i = 0; i < VEC; ++i) f[i] = f[i] * gate[v * VEC + i] * sv;
+          if (msrc) {
+            float m[VEC];
+            Vec16<T>::unpack(mv[j], m);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] *= m[i];
+          }
+          *reinterpret_cast<uint4*>(odst + gp * a.out_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(f);
+        }
+      }
     }
-    *reinterpret_cast<uint4*>(a.out + gp * a.out_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(f);
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) { xv[j] = xn[j]; mv[j] = mn[j]; }
+    }
   }
 }
 

@@ -4,6 +4,11 @@
 //   layout kernels : fp32 NCHW (the nn.Module boundary) <-> internal NHWC
 #include "common.hpp"
 
+// No implicit FMA contraction in this file: its loops are unrolled, and the unrolled body and the remainder loop must
+// round identically -- which copy handles a pixel depends on the grid, i.e. on the batch size, and an image's result
+// must not (tests/test_gpu_parity.py::test_full_batch_properties).  Fused multiply-adds are written as fmaf() where wanted.
+#pragma clang fp contract(off)
+
 namespace mdie {
 
 constexpr int RS_THREADS = 256;
@@ -19,12 +24,13 @@ __device__ __forceinline__ void src_index(int dst, int in_size, int& i0, int& i1
 }
 
 template <typename T>
-__global__ __launch_bounds__(RS_THREADS) void upsample2x_add_kernel(int B, int H, int W, int C, const char* lo, int lo_stride,
-                                                                    const char* skip, int skip_stride, char* out, int out_stride) {
+__global__ __launch_bounds__(RS_THREADS) void upsample2x_add_kernel(int B, int H, int W, int C, const char* __restrict__ lo, int lo_stride,
+                                                                    const char* __restrict__ skip, int skip_stride, char* __restrict__ out, int out_stride) {
   constexpr int VEC = Traits<T>::VEC;
   const int CV = C / VEC;
   const int Ho = 2 * H, Wo = 2 * W;
   const size_t total = (size_t)B * Ho * Wo * CV;
+#pragma unroll 2
   for (size_t u = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * RS_THREADS) {
     const int v = (int)(u % CV);
     size_t p = u / CV;
@@ -54,8 +60,9 @@ __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_kernel(int B, int H
 // upsample + skip that also reduces what it writes (the next kernel is a CBAM whose first pass is exactly this
 // reduction): grid (slabs, B); thread = (channel vector v, pixel row r); per-slab sums / maxima -> partial[b][slab][2][C]
 template <typename T>
-__global__ __launch_bounds__(RS_THREADS) void upsample2x_add_pool_kernel(int H, int W, int C, const char* lo, int lo_stride, const char* skip,
-                                                                         int skip_stride, char* out, int out_stride, float* partial) {
+__global__ __launch_bounds__(RS_THREADS) void upsample2x_add_pool_kernel(int H, int W, int C, const char* __restrict__ lo, int lo_stride,
+                                                                         const char* __restrict__ skip, int skip_stride, char* __restrict__ out,
+                                                                         int out_stride, float* __restrict__ partial) {
   constexpr int VEC = Traits<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) char dyn[];
   const int CV = C / VEC;
@@ -72,6 +79,8 @@ __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_pool_kernel(int H, 
   for (int i = 0; i < VEC; ++i) { s[i] = 0.f; m[i] = -INFINITY; }
   const char* base = lo + (size_t)img * H * W * lo_stride * sizeof(T) + (size_t)v * 16;
   if (r < rows) {
+    // latency-bound loop (5 loads, then their use): two pixels' loads in flight per thread; lo/skip/out never overlap
+#pragma unroll 2
     for (int p = p_begin + r; p < p_end; p += rows) {
       const int oy = p / Wo, ox = p - oy * Wo;
       int y0, y1, x0, x1;
@@ -111,11 +120,12 @@ __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_pool_kernel(int H, 
 
 // last decoder stage: out[B,2H,2W,CST] = bilinear_x2(lo)[:, :3] + x (fp32 NCHW), one output pixel per thread
 template <typename T, int CST>
-__global__ __launch_bounds__(RS_THREADS) void upsample2x_add_nchw3_kernel(int B, int H, int W, const T* lo, int lo_stride,
-                                                                          const float* x, T* out) {
+__global__ __launch_bounds__(RS_THREADS) void upsample2x_add_nchw3_kernel(int B, int H, int W, const T* __restrict__ lo, int lo_stride,
+                                                                          const float* __restrict__ x, T* __restrict__ out) {
   const int Ho = 2 * H, Wo = 2 * W;
   const size_t plane = (size_t)Ho * Wo;
   const size_t total = (size_t)B * plane;
+#pragma unroll 2
   for (size_t p = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; p < total; p += (size_t)gridDim.x * RS_THREADS) {
     const size_t img = p / plane, hw = p - img * plane;
     const int oy = (int)(hw / Wo), ox = (int)(hw - (size_t)oy * Wo);
