@@ -6,6 +6,8 @@
 // The channel-scaled tensor x*gate is never written: passes 3 and 4 recompute it from x.
 // NHWC makes the channel reductions contiguous (one 16-byte vector per lane, wave shuffles to
 // finish), and the global pools are deterministic two-level reductions (no float atomics).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 // No implicit FMA contraction in this file: its loops are unrolled, and the unrolled body and the remainder loop must
@@ -33,6 +35,7 @@ struct CbamArgs {
   float* map;      // [B][H][W][2]  (max, mean)
   int nslab, slab;  // pool blocks per image, pixels per block
   int spatial;     // 0: channel gate only
+  int gate_ready;  // pass 3: the gate was computed by cbam_gate_kernel (wide tensors), do not re-derive it per block
 };
 
 // ---- pass 1 ----------------------------------------------------------------------------------------
@@ -78,12 +81,43 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_pool_kernel(const CbamArgs a)
 // part a contiguous run of C/parts channels for BOTH pooled vectors, so all weight loads of the block
 // are issued at once (a per-output loop serialises 2*Hd cold-miss round trips: 42 us at C=512).
 // gate[c] of image `img` into LDS (`gate`, [C]); scratch: avg[C], mx[C], part[2*CB_THREADS], hid[Hd]
+template <int W1V, int W2V>   // float4 of layer-1 / layer-2 weights a thread holds: <16, 8> covers C <= 512, <1, 2> C <= 128
 __device__ __forceinline__ void cbam_gate_block(const CbamArgs& a, int img, float* avg, float* mx, float* part, float* hid, float* gate) {
   const int Hd = a.C / 16;
   const int tid = threadIdx.x;
   const float inv = 1.0f / (float)(a.H * a.W);
-  // Every phase of this block is a chain of dependent L2 round trips unless its loads are issued together (the block ran
-  // 15-30 us of a 25-35 us launch that way), so each phase spreads its loads over all 256 threads and unrolls them.
+  // Every phase of this block is a chain of dependent memory round trips unless its loads are issued together (a C = 512 gate
+  // ran 17 us that way).  The MLP weights depend on nothing, so every thread requests ITS weights of both layers first --
+  // into registers, up to 16 + 16 float4 -- and the phases below consume them: what is left on the chain is one round trip
+  // for the pooled partials and the LDS exchanges.
+  //   layer 1: thread = (unit j, part q), 256/Hd parts per unit, each a contiguous run of C/parts channels of BOTH pooled vectors
+  //   layer 2: thread = channel c (+256 when C = 512), all Hd hidden units
+  const int parts = CB_THREADS / Hd;                   // 8 (C=512) .. 256 (C=16)
+  const int run = a.C / parts > 0 ? a.C / parts : 1;   // channels per part: 1 (C<=64), 4, 16, 64
+  const int j1 = tid / parts, q1 = tid - j1 * parts;
+  const int c01 = q1 * run;
+  const bool l1_live = j1 < Hd && c01 < a.C;
+  const float* w1p = a.w1 + (size_t)j1 * a.C + c01;
+  const bool vec1 = run >= 4 && ((uintptr_t)a.w1 & 15) == 0;
+  const bool vec2 = Hd >= 4 && ((uintptr_t)a.w2 & 15) == 0;
+  float4 w1r[W1V], w2r[2][W2V];
+  float w1s = 0.f;
+  if (l1_live) {
+    if (vec1) {
+#pragma unroll
+      for (int i = 0; i < W1V; ++i) if (i * 4 < run) w1r[i] = *reinterpret_cast<const float4*>(w1p + i * 4);
+    } else if (run == 1) w1s = w1p[0];
+  }
+  if (vec2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = tid + h * CB_THREADS;
+      if (c < a.C) {
+#pragma unroll
+        for (int i = 0; i < W2V; ++i) if (i * 4 < Hd) w2r[h][i] = *reinterpret_cast<const float4*>(a.w2 + (size_t)c * Hd + i * 4);
+      }
+    }
+  }
   // Phase 1: fold the pooled partials of the image's slabs.  Thread = (channel c, slab class q): class q sums slabs
   // q, q+P, q+2P, ... in order, then the classes are combined in order -- fixed by (C, nslab) alone, i.e. by the resolution.
   {
@@ -112,29 +146,25 @@ __device__ __forceinline__ void cbam_gate_block(const CbamArgs& a, int img, floa
     }
   }
   __syncthreads();
-  // Phase 2: hidden layer, split over (unit j, part q): 256/Hd parts per unit, each a contiguous run of C/parts channels for
-  // BOTH pooled vectors (a per-output loop serialises 2*Hd cold-miss round trips: 42 us at C=512)
-  const int parts = CB_THREADS / Hd;           // 8 (C=512) .. 256 (C=16)
-  const int run = a.C / parts > 0 ? a.C / parts : 1;  // channels per part: 1 (C<=64), 4, 16, 64
+  // Phase 2: hidden layer partial dot products
   {
-    const int j = tid / parts, q = tid - j * parts;
     float sa = 0.f, sm = 0.f;
-    if (j < Hd) {
-      const int c0 = q * run;
-      if (c0 < a.C) {
-        const float* w = a.w1 + (size_t)j * a.C + c0;
-        if (run >= 4 && ((uintptr_t)w & 15) == 0) {   // 16-byte aligned runs: all their loads in flight at once
-#pragma unroll 4
-          for (int i = 0; i < run; i += 4) {
-            const float4 wv = *reinterpret_cast<const float4*>(w + i);
-            sa = fmaf(wv.x, avg[c0 + i], sa); sm = fmaf(wv.x, mx[c0 + i], sm);
-            sa = fmaf(wv.y, avg[c0 + i + 1], sa); sm = fmaf(wv.y, mx[c0 + i + 1], sm);
-            sa = fmaf(wv.z, avg[c0 + i + 2], sa); sm = fmaf(wv.z, mx[c0 + i + 2], sm);
-            sa = fmaf(wv.w, avg[c0 + i + 3], sa); sm = fmaf(wv.w, mx[c0 + i + 3], sm);
+    if (l1_live) {
+      if (vec1) {
+#pragma unroll
+        for (int i = 0; i < W1V; ++i)
+          if (i * 4 < run) {
+            const float4 wv = w1r[i];
+            const int c = c01 + i * 4;
+            sa = fmaf(wv.x, avg[c], sa); sm = fmaf(wv.x, mx[c], sm);
+            sa = fmaf(wv.y, avg[c + 1], sa); sm = fmaf(wv.y, mx[c + 1], sm);
+            sa = fmaf(wv.z, avg[c + 2], sa); sm = fmaf(wv.z, mx[c + 2], sm);
+            sa = fmaf(wv.w, avg[c + 3], sa); sm = fmaf(wv.w, mx[c + 3], sm);
           }
-        } else {
-          for (int i = 0; i < run; ++i) { const float wv = w[i]; sa = fmaf(wv, avg[c0 + i], sa); sm = fmaf(wv, mx[c0 + i], sm); }
-        }
+      } else if (run == 1) {
+        sa = w1s * avg[c01]; sm = w1s * mx[c01];
+      } else {
+        for (int i = 0; i < run; ++i) { const float wv = w1p[i]; sa = fmaf(wv, avg[c01 + i], sa); sm = fmaf(wv, mx[c01 + i], sm); }
       }
     }
     part[tid] = sa;
@@ -148,19 +178,26 @@ __device__ __forceinline__ void cbam_gate_block(const CbamArgs& a, int img, floa
     hid[tid] = fmaxf(sa + b, 0.f) + fmaxf(sm + b, 0.f);
   }
   __syncthreads();
-  for (int c = tid; c < a.C; c += CB_THREADS) {
-    float s = 2.0f * a.b2[c];  // the MLP (bias included) is applied to both pooled vectors
-    const float* w = a.w2 + (size_t)c * Hd;
-    if (Hd >= 4 && ((uintptr_t)w & 15) == 0) {
-#pragma unroll 4
-      for (int j = 0; j < Hd; j += 4) {
-        const float4 wv = *reinterpret_cast<const float4*>(w + j);
-        s = fmaf(wv.x, hid[j], s); s = fmaf(wv.y, hid[j + 1], s); s = fmaf(wv.z, hid[j + 2], s); s = fmaf(wv.w, hid[j + 3], s);
+  // Phase 3: output layer (the MLP, bias included, is applied to both pooled vectors)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = tid + h * CB_THREADS;
+    if (c < a.C) {
+      float s = 2.0f * a.b2[c];
+      if (vec2) {
+#pragma unroll
+        for (int i = 0; i < W2V; ++i)
+          if (i * 4 < Hd) {
+            const float4 wv = w2r[h][i];
+            const int j = i * 4;
+            s = fmaf(wv.x, hid[j], s); s = fmaf(wv.y, hid[j + 1], s); s = fmaf(wv.z, hid[j + 2], s); s = fmaf(wv.w, hid[j + 3], s);
+          }
+      } else {
+        const float* w = a.w2 + (size_t)c * Hd;
+        for (int j = 0; j < Hd; ++j) s = fmaf(w[j], hid[j], s);
       }
-    } else {
-      for (int j = 0; j < Hd; ++j) s = fmaf(w[j], hid[j], s);
+      gate[c] = sigmoidf(s);
     }
-    gate[c] = sigmoidf(s);
   }
   __syncthreads();
 }
@@ -173,7 +210,7 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_gate_kernel(const CbamArgs a)
   float* part = mx + a.C;
   float* hid = part + 2 * CB_THREADS;
   float* gate = hid + a.C / 16;
-  cbam_gate_block(a, blockIdx.x, avg, mx, part, hid, gate);
+  cbam_gate_block<16, 8>(a, blockIdx.x, avg, mx, part, hid, gate);
   for (int c = threadIdx.x; c < a.C; c += CB_THREADS) a.gate[(size_t)blockIdx.x * a.C + c] = gate[c];
 }
 
@@ -199,9 +236,14 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_chanpool_kernel(const CbamArg
   float* part = mx + a.C;
   float* hid = part + 2 * CB_THREADS;
   float* gsh = hid + a.C / 16;
-  cbam_gate_block(a, img, avg, mx, part, hid, gsh);
-  if (blockIdx.x == 0)
-    for (int c = tid; c < a.C; c += CB_THREADS) a.gate[(size_t)img * a.C + c] = gsh[c];
+  if (a.gate_ready) {   // launch-uniform
+    for (int c = tid; c < a.C; c += CB_THREADS) gsh[c] = a.gate[(size_t)img * a.C + c];
+    __syncthreads();
+  } else {
+    cbam_gate_block<1, 2>(a, img, avg, mx, part, hid, gsh);   // folded only for C <= 128 (run <= 4 channels, Hd <= 8)
+    if (blockIdx.x == 0)
+      for (int c = tid; c < a.C; c += CB_THREADS) a.gate[(size_t)img * a.C + c] = gsh[c];
+  }
   float g[NV][VEC];
 #pragma unroll
   for (int k = 0; k < NV; ++k)
@@ -402,7 +444,11 @@ static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
     hipLaunchKernelGGL((cbam_pool_kernel<T>), dim3(a.nslab, d->B), dim3(CB_THREADS), lds, stream, a);
     MDIE_LAUNCH_CHECK("cbam_pool");
   }
-  if (!spatial) {
+  // Wide tensors (C >= 256: 32-128 KB of MLP weights): one gate block per image in its own launch.  Folded into pass 3,
+  // every one of its ~1000 blocks re-read those weights from L2 -- 4x the bytes of the tensor itself at C = 512.
+  const bool split_gate = spatial && d->C >= 256;
+  a.gate_ready = split_gate ? 1 : 0;
+  if (!spatial || split_gate) {
     TimedLaunch tl(MDIE_K_CBAM_GATE);
     hipLaunchKernelGGL(cbam_gate_kernel, dim3(d->B), dim3(CB_THREADS), gate_lds, stream, a);
     MDIE_LAUNCH_CHECK("cbam_gate");
@@ -414,7 +460,7 @@ static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
     int gx = cdiv(d->H * d->W, groups * 4);
     // every block re-derives the gate: keep the block count per image moderate for the wide tensors, whose MLP
     // weights are 32-128 KB (L2 reads per block)
-    int cap = d->C >= 256 ? 16 : 64;
+    int cap = (d->C >= 256 && !split_gate) ? 16 : 64;
     if (cap < 1024 / d->B) cap = 1024 / d->B;   // small batches: more blocks per image
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;

@@ -12,8 +12,8 @@ S = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 fused = os.environ.get("FUSED_TAIL", "0") == "1"
 NAMES = ["enc.conv1+pool"] + [f"dense1.l{i}" for i in range(4)] + ["dense1.tr", "enc.conv2+pool"] + \
         [f"dense2.l{i}" for i in range(4)] + ["dense2.tr", "enc.conv3+pool"] + [f"dense3.l{i}" for i in range(4)] + \
-        ["dense3.tr", "enc.conv4+pool-stats", "bott.gate+chanpool", "bott.spatial", "dec.conv1+skip+pool-stats",
-         "cbam1.gate+chanpool", "cbam1.spatial*d3", "dec.conv2", "up2+skip1+pool",
+        ["dense3.tr", "enc.conv4+pool-stats", "bott.gate", "bott.chanpool", "bott.spatial", "dec.conv1+skip+pool-stats",
+         "cbam1.gate", "cbam1.chanpool", "cbam1.spatial*d3", "dec.conv2", "up2+skip1+pool",
          "cbam2.gate+chanpool", "cbam2.spatial*d2", "dec.conv3", "up3+skip0+pool",
          "cbam3.gate+chanpool", "cbam3.spatial*d1", "dec.conv4"]
 NAMES += (["tail(fused)"] if fused else ["up4+x(nchw)"] + [f"final.l{i}" for i in range(4)] + ["final.tr+sigmoid->nchw"])
