@@ -102,6 +102,11 @@ __device__ __forceinline__ void cbam_gate_block(const CbamArgs& a, int img, floa
   const bool vec2 = Hd >= 4 && ((uintptr_t)a.w2 & 15) == 0;
   float4 w1r[W1V], w2r[2][W2V];
   float w1s = 0.f;
+  // the biases too: read where they are used they are two more dependent (cold, TLB-missing) round trips on the chain
+  const float b1r = tid < Hd ? a.b1[tid] : 0.f;
+  float b2r[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) b2r[h] = tid + h * CB_THREADS < a.C ? a.b2[tid + h * CB_THREADS] : 0.f;
   if (l1_live) {
     if (vec1) {
 #pragma unroll
@@ -174,8 +179,7 @@ __device__ __forceinline__ void cbam_gate_block(const CbamArgs& a, int img, floa
   if (tid < Hd) {
     float sa = 0.f, sm = 0.f;
     for (int q = 0; q < parts; ++q) { sa += part[tid * parts + q]; sm += part[CB_THREADS + tid * parts + q]; }
-    const float b = a.b1[tid];
-    hid[tid] = fmaxf(sa + b, 0.f) + fmaxf(sm + b, 0.f);
+    hid[tid] = fmaxf(sa + b1r, 0.f) + fmaxf(sm + b1r, 0.f);
   }
   __syncthreads();
   // Phase 3: output layer (the MLP, bias included, is applied to both pooled vectors)
@@ -183,7 +187,7 @@ __device__ __forceinline__ void cbam_gate_block(const CbamArgs& a, int img, floa
   for (int h = 0; h < 2; ++h) {
     const int c = tid + h * CB_THREADS;
     if (c < a.C) {
-      float s = 2.0f * a.b2[c];
+      float s = 2.0f * b2r[h];
       if (vec2) {
 #pragma unroll
         for (int i = 0; i < W2V; ++i)
@@ -236,6 +240,27 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_chanpool_kernel(const CbamArg
   float* part = mx + a.C;
   float* hid = part + 2 * CB_THREADS;
   float* gsh = hid + a.C / 16;
+  // The pixel loop is latency-bound (one 16-byte load per lane and pixel, then a lane reduction): U neighbouring pixels per
+  // lane are fetched together (a block reads one contiguous run of U * groups pixels per iteration; U = 4 and U streams a
+  // power-of-two distance apart both measured slower on the 64x64 / 128x128 maps), the first batch is requested BEFORE the
+  // gate is derived so that it arrives under that prelude, and each next batch before the current one is reduced.
+  // (x and map never overlap.)
+  const char* __restrict__ xsrc = a.x;
+  float* __restrict__ mdst = a.map;
+  constexpr int U = 2;
+  const int pstep = gridDim.x * groups * U;
+  auto load_batch = [&](int p0, uint4 (&u)[U][NV]) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int p = p0 + j;
+      const char* px = xsrc + ((size_t)img * npix + (p < npix ? p : 0)) * a.x_stride * sizeof(T);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) u[j][k] = *reinterpret_cast<const uint4*>(px + (size_t)(k * LPP + sub) * 16);
+    }
+  };
+  uint4 u[U][NV];
+  const int p_first = (blockIdx.x * groups + tid / LPP) * U;
+  load_batch(p_first, u);
   if (a.gate_ready) {   // launch-uniform
     for (int c = tid; c < a.C; c += CB_THREADS) gsh[c] = a.gate[(size_t)img * a.C + c];
     __syncthreads();
@@ -250,23 +275,10 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_chanpool_kernel(const CbamArg
 #pragma unroll
     for (int i = 0; i < VEC; ++i) g[k][i] = gsh[(k * LPP + sub) * VEC + i];
   const float invC = 1.0f / (float)a.C;
-  // The loop is latency-bound (one 16-byte load per lane and pixel, then a shuffle reduction): U pixels per lane are
-  // processed together, their loads issued back to back and their reductions interleaved.  (x and map never overlap.)
-  const char* __restrict__ xsrc = a.x;
-  float* __restrict__ mdst = a.map;
-  constexpr int U = 2;   // (U = 4 measured slower on the 64x64 and 128x128 maps, U = 1 and 2 equal)
-  // a lane's U pixels are neighbours, so a block reads one contiguous run of U * groups pixels per iteration (U streams a
-  // power-of-two distance apart were measured SLOWER than U = 1 on the large maps)
-  const int pstep = gridDim.x * groups * U;
-  for (int p0 = (blockIdx.x * groups + tid / LPP) * U; p0 < npix; p0 += pstep) {
-    uint4 u[U][NV];
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const int p = p0 + j;
-      const char* px = xsrc + ((size_t)img * npix + (p < npix ? p : p0)) * a.x_stride * sizeof(T);
-#pragma unroll
-      for (int k = 0; k < NV; ++k) u[j][k] = *reinterpret_cast<const uint4*>(px + (size_t)(k * LPP + sub) * 16);
-    }
+  for (int p0 = p_first; p0 < npix; p0 += pstep) {
+    uint4 un[U][NV];
+    const bool more = p0 + pstep < npix;
+    if (more) load_batch(p0 + pstep, un);
     float m[U], s[U];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
@@ -299,6 +311,12 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_chanpool_kernel(const CbamArg
         const int p = p0 + j;
         if (p < npix) *reinterpret_cast<float2*>(mdst + ((size_t)img * npix + p) * 2) = make_float2(m[j], s[j] * invC);
       }
+    }
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < U; ++j)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) u[j][k] = un[j][k];
     }
   }
 }

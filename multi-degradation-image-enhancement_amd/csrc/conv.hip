@@ -102,6 +102,15 @@ __device__ __forceinline__ float quad_max(float v) {
   return fmaxf(v, __int_as_float(b));
 }
 
+// the same for values known to be >= 0 (a ReLU output): non-negative floats order like their bit patterns, and an integer
+// max needs no NaN canonicalisation, so each lane swap folds into the max (v_max_i32_dpp): 2 instructions instead of 6
+__device__ __forceinline__ float quad_max_nonneg(float v) {
+  int a = __float_as_int(v);
+  a = max(a, __builtin_amdgcn_mov_dpp(a, 0xB1, 0xF, 0xF, true));
+  a = max(a, __builtin_amdgcn_mov_dpp(a, 0x4E, 0xF, 0xF, true));
+  return __int_as_float(a);
+}
+
 template <int ACT> __device__ __forceinline__ float act_fn(float v) {
   if constexpr (ACT == MDIE_ACT_RELU) return fmaxf(v, 0.0f);
   else if constexpr (ACT == MDIE_ACT_SIGMOID) return sigmoidf(v);
@@ -141,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
       v[3] = act_fn<ACT>(fmaf(acc[cs][ps][3], sc.w, sh.w));
       if constexpr (POOL) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = quad_max(v[i]);
+        for (int i = 0; i < 4; ++i) v[i] = ACT == MDIE_ACT_RELU ? quad_max_nonneg(v[i]) : quad_max(v[i]);
       }
       if (e.nchw3) {  // final tensor of the network: channels 0..2 straight to fp32 NCHW planes
         if (writer && cs == 0 && lq == 0 && n0 == 0) {

@@ -79,24 +79,33 @@ __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_pool_kernel(int H, 
   for (int i = 0; i < VEC; ++i) { s[i] = 0.f; m[i] = -INFINITY; }
   const char* base = lo + (size_t)img * H * W * lo_stride * sizeof(T) + (size_t)v * 16;
   if (r < rows) {
-    // latency-bound loop (5 loads, then their use): two pixels' loads in flight per thread; lo/skip/out never overlap
-#pragma unroll 2
-    for (int p = p_begin + r; p < p_end; p += rows) {
-      const int oy = p / Wo, ox = p - oy * Wo;
+    // Latency-bound loop (5 loads per pixel, then their use): the 5 loads of the NEXT pixel are requested before the current
+    // one is blended and stored, so two pixels' loads are always in flight per thread.  (lo / skip / out never overlap.)
+    struct Px { uint4 a00, a01, a10, a11, sk; float hy0, hy1, wx0, wx1; };
+    auto fetch = [&](int p, Px& q) {
+      const int pp = p < p_end ? p : p_begin;            // past the slab: a harmless in-range address, result unused
+      const int oy = pp / Wo, ox = pp - oy * Wo;
       int y0, y1, x0, x1;
-      float hy0, hy1, wx0, wx1;
-      src_index(oy, H, y0, y1, hy0, hy1);
-      src_index(ox, W, x0, x1, wx0, wx1);
+      src_index(oy, H, y0, y1, q.hy0, q.hy1);
+      src_index(ox, W, x0, x1, q.wx0, q.wx1);
       auto at = [&](int y, int x) { return *reinterpret_cast<const uint4*>(base + ((size_t)y * W + x) * lo_stride * sizeof(T)); };
+      q.a00 = at(y0, x0); q.a01 = at(y0, x1); q.a10 = at(y1, x0); q.a11 = at(y1, x1);
+      q.sk = *reinterpret_cast<const uint4*>(skip + ((size_t)img * npix + pp) * skip_stride * sizeof(T) + (size_t)v * 16);
+    };
+    Px cur, nxt;
+    if (p_begin + r < p_end) fetch(p_begin + r, cur);
+    for (int p = p_begin + r; p < p_end; p += rows) {
+      fetch(p + rows, nxt);
       float a00[VEC], a01[VEC], a10[VEC], a11[VEC], sk[VEC], rr[VEC];
-      Vec16<T>::unpack(at(y0, x0), a00);
-      Vec16<T>::unpack(at(y0, x1), a01);
-      Vec16<T>::unpack(at(y1, x0), a10);
-      Vec16<T>::unpack(at(y1, x1), a11);
+      Vec16<T>::unpack(cur.a00, a00);
+      Vec16<T>::unpack(cur.a01, a01);
+      Vec16<T>::unpack(cur.a10, a10);
+      Vec16<T>::unpack(cur.a11, a11);
+      Vec16<T>::unpack(cur.sk, sk);
       const size_t op = (size_t)img * npix + p;
-      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(skip + op * skip_stride * sizeof(T) + (size_t)v * 16), sk);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) rr[i] = hy0 * (wx0 * a00[i] + wx1 * a01[i]) + hy1 * (wx0 * a10[i] + wx1 * a11[i]) + sk[i];
+      for (int i = 0; i < VEC; ++i)
+        rr[i] = cur.hy0 * (cur.wx0 * a00[i] + cur.wx1 * a01[i]) + cur.hy1 * (cur.wx0 * a10[i] + cur.wx1 * a11[i]) + sk[i];
       const uint4 packed = Vec16<T>::pack(rr);
       *reinterpret_cast<uint4*>(out + op * out_stride * sizeof(T) + (size_t)v * 16) = packed;
       // reduce the STORED values (bf16-rounded), exactly what a separate pool pass over `out` would read
@@ -104,6 +113,7 @@ __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_pool_kernel(int H, 
       Vec16<T>::unpack(packed, q);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) { s[i] += q[i]; m[i] = fmaxf(m[i], q[i]); }
+      cur = nxt;
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { rsum[r * C + v * VEC + i] = s[i]; rmax[r * C + v * VEC + i] = m[i]; }
