@@ -567,45 +567,64 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv1x1_stream_kernel(const C
   __syncthreads();
 
   const int tpi = a.tiles_x * a.tiles_y;
-  for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
-    const int img = tile / tpi;
+  // Operand loads are UNCONDITIONAL: a pixel outside the image reads the tile's origin (its results are never stored), a
+  // channel column beyond the segments reads segment 0 (its weights are zero, and with PRE its scale and shift too).  A
+  // predicated load would hide its count from the s_waitcnt pass, which then drains vmcnt to 0 before the first use of the
+  // CURRENT chunk -- i.e. waits for the prefetch of the next one as well (each chunk then exposed a full memory round trip).
+  auto tile_pixels = [&](int tile, int& img, int& y0, int& x0, int (&gld)[NPS]) {
+    img = tile / tpi;
     const int trem = tile - img * tpi;
     const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
-    const int y0 = ty * TILE, x0 = tx * TILE;
-    int gpix[NPS];
+    y0 = ty * TILE; x0 = tx * TILE;
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
       int y, x;
       tile_pixel<TILE>(wave * NPS + ps, lp, y, x);
       const int gy = y0 + y, gx = x0 + x;
-      gpix[ps] = (gy < a.H && gx < a.W) ? (img * a.H + gy) * a.W + gx : -1;
+      gld[ps] = (gy < a.H && gx < a.W) ? (img * a.H + gy) * a.W + gx : (img * a.H + y0) * a.W + x0;
     }
+  };
+  auto load_chunk = [&](int chunk, const int (&gld)[NPS], uint4 (&xf)[NPS]) {
+    const int c0 = chunk * KC + lq * VEC;        // this lane's first stored channel of the chunk
+    const char* sbase = a.seg[0].ptr;
+    int sstride = a.seg[0].stride * (int)sizeof(T);
+#pragma unroll
+    for (int k = 0; k < MDIE_MAX_SEG; ++k)
+      if (k < a.nseg && c0 >= a.seg[k].ch_begin && c0 < a.seg[k].ch_end) {
+        sbase = a.seg[k].ptr + (size_t)(c0 - a.seg[k].ch_begin) * sizeof(T);
+        sstride = a.seg[k].stride * (int)sizeof(T);
+      }
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) xf[ps] = *reinterpret_cast<const uint4*>(sbase + (size_t)gld[ps] * sstride);
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= tiles_total) return;
+  int img, y0, x0, gld[NPS];
+  tile_pixels(tile, img, y0, x0, gld);
+  uint4 xf[NPS], xn[NPS];
+  load_chunk(0, gld, xf);
+  while (true) {
     f32x4 acc[NCS][NPS];
 #pragma unroll
     for (int i = 0; i < NCS; ++i)
 #pragma unroll
       for (int j = 0; j < NPS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // raw operands of one chunk: 16 bytes of each of this lane's 4 pixels (software-pipelined one chunk ahead)
-    auto load_chunk = [&](int chunk, uint4 (&xf)[NPS]) {
-      const int c0 = chunk * KC + lq * VEC;        // this lane's first stored channel of the chunk
-      const char* sbase = nullptr;
-      int sstride = 0;
+    const int tile_next = tile + gridDim.x;
+    int img_n = img, y0_n = y0, x0_n = x0, gld_n[NPS];
+    // next operands (next chunk of this tile, or chunk 0 of the workgroup's next tile): requested BEFORE this chunk's
+    // transform and MFMAs and pinned there (sched_barrier) -- two operand buffers in ping-pong, no register copies
+    // (branch-free: after the workgroup's last tile it re-reads that tile's chunk 0 -- a load under a branch would again
+    //  hide its count from the s_waitcnt pass)
+    tile_pixels(tile_next < tiles_total ? tile_next : tile, img_n, y0_n, x0_n, gld_n);
+    auto issue_next = [&](int chunk, uint4 (&dst)[NPS]) {
+      const bool in_tile = chunk + 1 < a.nchunk;
+      int g[NPS];
 #pragma unroll
-      for (int k = 0; k < MDIE_MAX_SEG; ++k)
-        if (k < a.nseg && c0 >= a.seg[k].ch_begin && c0 < a.seg[k].ch_end) {
-          sbase = a.seg[k].ptr + (size_t)(c0 - a.seg[k].ch_begin) * sizeof(T);
-          sstride = a.seg[k].stride * (int)sizeof(T);
-        }
-#pragma unroll
-      for (int ps = 0; ps < NPS; ++ps) {
-        xf[ps] = make_uint4(0, 0, 0, 0);
-        if (sbase && gpix[ps] >= 0) xf[ps] = *reinterpret_cast<const uint4*>(sbase + (size_t)gpix[ps] * sstride);
-      }
+      for (int ps = 0; ps < NPS; ++ps) g[ps] = in_tile ? gld[ps] : gld_n[ps];
+      load_chunk(in_tile ? chunk + 1 : 0, g, dst);
     };
-    uint4 xf[NPS], xn[NPS];
-    load_chunk(0, xf);
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-      if (chunk + 1 < a.nchunk) load_chunk(chunk + 1, xn);      // in flight during this chunk's MFMAs
+    auto compute = [&](int chunk, uint4 (&x)[NPS]) {
       if (PRE) {
         const int c0 = chunk * KC + lq * VEC;
         f32x2 psc[VEC / 2], psh[VEC / 2];
@@ -616,7 +635,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv1x1_stream_kernel(const C
           psh[i / 2] = f32x2{b4.x, b4.y}; psh[i / 2 + 1] = f32x2{b4.z, b4.w};
         }
 #pragma unroll
-        for (int ps = 0; ps < NPS; ++ps) xf[ps] = PreAct<T>::apply(xf[ps], psc, psh);   // (channels beyond cin have scale = shift = 0 and zero weights)
+        for (int ps = 0; ps < NPS; ++ps) x[ps] = PreAct<T>::apply(x[ps], psc, psh);   // (channels beyond cin have scale = shift = 0 and zero weights)
       }
       uint4 wf[NCS];
 #pragma unroll
@@ -624,11 +643,28 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv1x1_stream_kernel(const C
 #pragma unroll
       for (int cs = 0; cs < NCS; ++cs)
 #pragma unroll
-        for (int ps = 0; ps < NPS; ++ps) acc[cs][ps] = mma16<T>(wf[cs], xf[ps], acc[cs][ps]);
+        for (int ps = 0; ps < NPS; ++ps) acc[cs][ps] = mma16<T>(wf[cs], x[ps], acc[cs][ps]);
+    };
+    for (int chunk = 0; chunk < a.nchunk; chunk += 2) {
+      issue_next(chunk, xn);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(chunk, xf);
+      __builtin_amdgcn_sched_barrier(0);
+      if (chunk + 1 < a.nchunk) {
+        issue_next(chunk + 1, xf);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(chunk + 1, xn);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {   // odd chunk count: the next tile's first operands sit in the other buffer
 #pragma unroll
-      for (int ps = 0; ps < NPS; ++ps) xf[ps] = xn[ps];
+        for (int ps = 0; ps < NPS; ++ps) xf[ps] = xn[ps];
+      }
     }
     conv_epilogue<T, NCS, NPS, TILE>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp);
+    if (tile_next >= tiles_total) break;
+    tile = tile_next; img = img_n; y0 = y0_n; x0 = x0_n;
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) gld[ps] = gld_n[ps];
   }
 }
 
