@@ -70,7 +70,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(long N, const char
   for (int i = 0; i < VEC; ++i) s[0][i] = s[1][i] = 0.f;
   if (m.active) {
     const long b = (long)blockIdx.x * chunk, e = min(N, b + chunk);
-    for (long p = b + m.row; p < e; p += m.rows) {
+#pragma unroll 4
+    for (long p = b + m.row; p < e; p += m.rows) {   // (unrolled: a read-only loop, 4 loads in flight per thread)
       float f[VEC];
       Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + ((size_t)p * stride) * sizeof(T) + (size_t)m.cv * 16), f);
 #pragma unroll
@@ -439,7 +440,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const BnBwdAr
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { sc[i] = a.scale[c0 + i]; sh[i] = a.shift[c0 + i]; mu[i] = a.mean[c0 + i]; is[i] = a.invstd[c0 + i]; }
     const long b = (long)blockIdx.x * a.chunk, e = min(a.N, b + a.chunk);
-    for (long p = b + m.row; p < e; p += m.rows) {
+#pragma unroll 4
+    for (long p = b + m.row; p < e; p += m.rows) {   // (unrolled: a read-only loop, 8 loads in flight per thread)
       float xv[VEC], d[VEC];
       Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + (size_t)p * xs * sizeof(T)), xv);
       Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.da + (size_t)p * a.da_stride * sizeof(T) + (size_t)v * 16), d);
@@ -495,12 +497,24 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnBwdArg
     k2[i] = a.coef[c0 + i]; k3[i] = a.coef[a.C + c0 + i];
   }
   const long b = (long)blockIdx.x * a.chunk, e = min(a.N, b + a.chunk);
-  for (long p = b + m.row; p < e; p += m.rows) {
+  // Streaming loop, software-pipelined: the 2-3 loads of the NEXT pixel are requested before the current one is combined and
+  // stored (past the end they re-read the thread's first pixel; the result is unused), so two pixels are in flight per thread.
+  struct It { uint4 x, d, g; };
+  const long p_first = b + m.row;
+  auto fetch = [&](long p, It& t) {
+    const long pp = p < e ? p : p_first;
+    t.x = *reinterpret_cast<const uint4*>(xb + (size_t)pp * xs * sizeof(T));
+    t.d = *reinterpret_cast<const uint4*>(a.da + (size_t)pp * a.da_stride * sizeof(T) + (size_t)v * 16);
+    if (acc) t.g = *reinterpret_cast<const uint4*>(gb + (size_t)pp * gs * sizeof(T));
+  };
+  It cur, nxt;
+  if (p_first < e) fetch(p_first, cur);
+  for (long p = p_first; p < e; p += m.rows) {
+    fetch(p + m.rows, nxt);
     float xv[VEC], d[VEC], r[VEC];
-    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + (size_t)p * xs * sizeof(T)), xv);
-    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.da + (size_t)p * a.da_stride * sizeof(T) + (size_t)v * 16), d);
-    uint4* dst = reinterpret_cast<uint4*>(gb + (size_t)p * gs * sizeof(T));
-    if (acc) Vec16<T>::unpack(*dst, r);
+    Vec16<T>::unpack(cur.x, xv);
+    Vec16<T>::unpack(cur.d, d);
+    if (acc) Vec16<T>::unpack(cur.g, r);
     else {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) r[i] = 0.f;
@@ -510,11 +524,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnBwdArg
       const float dd = (!a.relu || fmaf(xv[i], sc[i], sh[i]) > 0.f) ? d[i] : 0.f;
       r[i] += sc[i] * (dd - k2[i] - (xv[i] - mu[i]) * is[i] * k3[i]);
     }
-    *dst = Vec16<T>::pack(r);
+    *reinterpret_cast<uint4*>(gb + (size_t)p * gs * sizeof(T)) = Vec16<T>::pack(r);
+    cur = nxt;
   }
 }
 
-// ---- final sigmoid: dz[NHWC16] = g[NCHW3] * y * (1 - y) -----------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void sigmoid_bwd_nchw3_kernel(int B, int HW, const float* g, const float* y, T* dz, int dz_stride) {
   const size_t total = (size_t)B * HW;
