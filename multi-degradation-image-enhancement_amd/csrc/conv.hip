@@ -319,14 +319,18 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
 
   auto load_chunk = [&](int chunk) {
     const int c0 = chunk * KC + q * VEC;  // first stored channel of this thread's column
+    // branch-free over ALL segment slots (unused ones are zero): every field is read unconditionally, so the kernel-argument
+    // loads batch into a few wide s_loads with one wait -- under `if (hit)` each slot cost its own scalar round trip
+    // (8 dependent s_waitcnt in the prologue, ~1.5 k cycles of a 12 k-cycle tile)
     const char* sbase = nullptr;
     int sstride = 0;
 #pragma unroll
     for (int s = 0; s < MDIE_MAX_SEG; ++s) {
-      if (s < a.nseg && c0 >= a.seg[s].ch_begin && c0 < a.seg[s].ch_end) {
-        sbase = a.seg[s].ptr + (size_t)(c0 - a.seg[s].ch_begin) * sizeof(T);
-        sstride = a.seg[s].stride * (int)sizeof(T);
-      }
+      const int cb = a.seg[s].ch_begin, ce = a.seg[s].ch_end, st = a.seg[s].stride;
+      const char* sp = a.seg[s].ptr;
+      const bool hit = (s < a.nseg) & (c0 >= cb) & (c0 < ce);
+      sbase = hit ? sp + (size_t)(c0 - cb) * sizeof(T) : sbase;
+      sstride = hit ? st * (int)sizeof(T) : sstride;
     }
     chunk_live = sbase != nullptr;
     int gp = gpix0;
@@ -589,11 +593,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv1x1_stream_kernel(const C
     const char* sbase = a.seg[0].ptr;
     int sstride = a.seg[0].stride * (int)sizeof(T);
 #pragma unroll
-    for (int k = 0; k < MDIE_MAX_SEG; ++k)
-      if (k < a.nseg && c0 >= a.seg[k].ch_begin && c0 < a.seg[k].ch_end) {
-        sbase = a.seg[k].ptr + (size_t)(c0 - a.seg[k].ch_begin) * sizeof(T);
-        sstride = a.seg[k].stride * (int)sizeof(T);
-      }
+    for (int k = 0; k < MDIE_MAX_SEG; ++k) {   // branch-free: see conv_kernel
+      const int cb = a.seg[k].ch_begin, ce = a.seg[k].ch_end, st = a.seg[k].stride;
+      const char* sp = a.seg[k].ptr;
+      const bool hit = (k < a.nseg) & (c0 >= cb) & (c0 < ce);
+      sbase = hit ? sp + (size_t)(c0 - cb) * sizeof(T) : sbase;
+      sstride = hit ? st * (int)sizeof(T) : sstride;
+    }
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) xf[ps] = *reinterpret_cast<const uint4*>(sbase + (size_t)gld[ps] * sstride);
   };
