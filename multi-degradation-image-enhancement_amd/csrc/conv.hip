@@ -140,6 +140,38 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
     const int dpix = (TS::dy(ps) >> SH) * Wo + (TS::dx(ps) >> SH);   // wave-uniform
     T* orow = orow0 + (ptrdiff_t)dpix * e.out_stride;
     const T* rrow = rrow0 ? rrow0 + (ptrdiff_t)dpix * e.res_stride : nullptr;
+    if constexpr (POOL && NCS == 4 && NPS == 4 && !STATS) {   // (conv_kernel's 16x16 tiles; conv_first_kernel, one subtile per call at 128 VGPRs, spills with it)
+      // Pooled 64-wide tile: after the lane max all 4 lanes of a quad hold the pooled pixel, so instead of lane 0 storing
+      // its 4 channels once per 16-channel subtile (4 store instructions with a quarter of the lanes active), lane j of the
+      // quad stores subtile j: ONE store instruction with every lane active writes the pixel's 64 channels.
+      if (!e.nchw3) {   // launch-uniform
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        const int j = lp & 3;
+#pragma unroll
+        for (int cs = 0; cs < NCS; ++cs) {
+          const float4 sc = esc[cs], sh = esh[cs];
+          float v[4];
+          v[0] = act_fn<ACT>(fmaf(acc[cs][ps][0], sc.x, sh.x));
+          v[1] = act_fn<ACT>(fmaf(acc[cs][ps][1], sc.y, sh.y));
+          v[2] = act_fn<ACT>(fmaf(acc[cs][ps][2], sc.z, sh.z));
+          v[3] = act_fn<ACT>(fmaf(acc[cs][ps][3], sc.w, sh.w));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = ACT == MDIE_ACT_RELU ? quad_max_nonneg(v[i]) : quad_max(v[i]);
+            o[i] = j == cs ? v[i] : o[i];
+          }
+        }
+        if (inside) {
+          if (rrow) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] += ld(rrow + j * 16 + i);
+          }
+          if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(orow + j * 16) = make_float4(o[0], o[1], o[2], o[3]);
+          else *reinterpret_cast<uint2*>(orow + j * 16) = make_uint2(bf_pack(o[0], o[1]), bf_pack(o[2], o[3]));
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs) {
       const float4 sc = esc[cs], sh = esh[cs];
