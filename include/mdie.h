@@ -242,7 +242,8 @@ int mdie_upsample2x_add_pool(int dtype, int B, int H, int W, int C, const void* 
                              int pool_slabs, void* stream);
 
 /* Same, for the last decoder stage where the skip is the network input itself (`torch.add(out, x)`,
- * models/cdan.py:153-154): lo NHWC [B,H,W,lo_stride] (channels 0..2), x fp32 NCHW [B,3,2H,2W],
+ * models/cdan.py:153-154): lo NHWC [B,H,W,lo_stride] (channels 0..2; 16-byte aligned, lo_stride a multiple of 4:
+ * channels 0..3 of a tap are read with one load), x fp32 NCHW [B,3,2H,2W],
  * out NHWC [B,2H,2W,out_channels] (channels 3.. zero); out_channels = 16, or one 16-byte group per pixel (8 bf16 /
  * 4 f32): the engine stores this 3-channel tensor -- read five times by decoder.final_dense -- that narrow. */
 int mdie_upsample2x_add_nchw3(int dtype, int B, int H, int W, const void* lo, int lo_stride, const float* x_nchw,

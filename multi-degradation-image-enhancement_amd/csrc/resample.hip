@@ -150,9 +150,22 @@ __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_nchw3_kernel(int B,
     float f[CST];
 #pragma unroll
     for (int i = 0; i < CST; ++i) f[i] = 0.f;
+    // the 4 taps: channels 0..3 of each with ONE load (8 bytes bf16 / 16 bytes f32; pixels are at least 16 bytes apart and
+    // 16-byte aligned) instead of three 2- or 4-byte loads per tap
+    float t00[4], t01[4], t10[4], t11[4];
+    auto tap = [](const T* q, float (&t)[4]) {
+      if constexpr (sizeof(T) == 2) {
+        const uint2 u = *reinterpret_cast<const uint2*>(q);
+        t[0] = bf_lo(u.x); t[1] = bf_hi(u.x); t[2] = bf_lo(u.y); t[3] = bf_hi(u.y);
+      } else {
+        const float4 u = *reinterpret_cast<const float4*>(q);
+        t[0] = u.x; t[1] = u.y; t[2] = u.z; t[3] = u.w;
+      }
+    };
+    tap(p00, t00); tap(p01, t01); tap(p10, t10); tap(p11, t11);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      f[c] = hy0 * (wx0 * ld(p00 + c) + wx1 * ld(p01 + c)) + hy1 * (wx0 * ld(p10 + c) + wx1 * ld(p11 + c)) + xp[c * plane];
+      f[c] = hy0 * (wx0 * t00[c] + wx1 * t01[c]) + hy1 * (wx0 * t10[c] + wx1 * t11[c]) + xp[c * plane];
     uint4* o = reinterpret_cast<uint4*>(out + p * CST);
     constexpr int VEC = Traits<T>::VEC;
 #pragma unroll
@@ -290,7 +303,8 @@ extern "C" int mdie_upsample2x_add_pool(int dtype, int B, int H, int W, int C, c
 extern "C" int mdie_upsample2x_add_nchw3(int dtype, int B, int H, int W, const void* lo, int lo_stride, const float* x_nchw, void* out,
                                          int out_channels, void* stream) {
   if (int e = check_layout("mdie_upsample2x_add_nchw3", dtype, B, 3, H, W, lo, out)) return e;
-  MDIE_REQUIRE(x_nchw != nullptr && lo_stride >= 3, "mdie_upsample2x_add_nchw3: null x or lo_stride < 3");
+  MDIE_REQUIRE(x_nchw != nullptr && lo_stride >= 4 && lo_stride % 4 == 0 && ((uintptr_t)lo & 15) == 0,
+               "mdie_upsample2x_add_nchw3: null x, or lo not 16-byte aligned with a pixel stride that is a multiple of 4 channels (%d)", lo_stride);
   MDIE_REQUIRE(((uintptr_t)out & 15) == 0, "mdie_upsample2x_add_nchw3: alignment");
   const int vec = dtype == MDIE_F32 ? 4 : 8;
   MDIE_REQUIRE(out_channels == 16 || out_channels == vec, "mdie_upsample2x_add_nchw3: out_channels %d (16 or %d)", out_channels, vec);
