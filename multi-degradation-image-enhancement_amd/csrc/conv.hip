@@ -131,8 +131,8 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
   const size_t opix0 = ((size_t)img * Ho + oy0) * Wo + ox0;
   T* const orow0 = reinterpret_cast<T*>(e.out) + opix0 * e.out_stride + n0 + lq * 4;
   const T* const rrow0 = e.residual ? reinterpret_cast<const T*>(e.residual) + opix0 * e.res_stride + n0 + lq * 4 : nullptr;
-  if constexpr (sizeof(T) == 2 && ACT == MDIE_ACT_RELU && !STATS) {
-    // bf16 + ReLU, no residual: the whole epilogue in packed form -- v_pk_fma_f32 for the affine, one v_cvt_pk_bf16_f32 per pair,
+  if constexpr (sizeof(T) == 2 && (ACT == MDIE_ACT_RELU || (ACT == MDIE_ACT_NONE && !POOL)) && !STATS) {
+    // bf16 + ReLU (or no activation, unpooled: the DenseLayers), no residual: the whole epilogue in packed form -- v_pk_fma_f32 for the affine, one v_cvt_pk_bf16_f32 per pair,
     // ReLU and the 2x2 max on the ROUNDED halves as packed 16-bit integer maxima (rounding is monotonic and keeps the sign, so
     // this equals rounding relu(max(...)) of the fp32 values): 14 instead of 18 vector instructions per 4 channels when
     // pooling, 6 instead of 10 without
@@ -148,8 +148,9 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
         for (int cs = 0; cs < NCS; ++cs) {
           const f32x2 lo = __builtin_elementwise_fma(f32x2{acc[cs][ps][0], acc[cs][ps][1]}, f32x2{esc[cs].x, esc[cs].y}, f32x2{esh[cs].x, esh[cs].y});
           const f32x2 hi = __builtin_elementwise_fma(f32x2{acc[cs][ps][2], acc[cs][ps][3]}, f32x2{esc[cs].z, esc[cs].w}, f32x2{esh[cs].z, esh[cs].w});
-          i16x2 p0 = __builtin_elementwise_max(__builtin_bit_cast(i16x2, __builtin_convertvector(lo, bf16x2)), i16x2{0, 0});
-          i16x2 p1 = __builtin_elementwise_max(__builtin_bit_cast(i16x2, __builtin_convertvector(hi, bf16x2)), i16x2{0, 0});
+          i16x2 p0 = __builtin_bit_cast(i16x2, __builtin_convertvector(lo, bf16x2));
+          i16x2 p1 = __builtin_bit_cast(i16x2, __builtin_convertvector(hi, bf16x2));
+          if constexpr (ACT == MDIE_ACT_RELU) { p0 = __builtin_elementwise_max(p0, i16x2{0, 0}); p1 = __builtin_elementwise_max(p1, i16x2{0, 0}); }
           if constexpr (POOL) {   // non-negative bf16 order like their bit patterns
             p0 = __builtin_elementwise_max(p0, __builtin_bit_cast(i16x2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, p0), 0xB1, 0xF, 0xF, true)));
             p1 = __builtin_elementwise_max(p1, __builtin_bit_cast(i16x2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, p1), 0xB1, 0xF, 0xF, true)));
