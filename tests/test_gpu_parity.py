@@ -310,6 +310,24 @@ def test_up2_add_with_fused_pool(E, L):
         assert torch.equal(part[:, :, 1].amax(1), o.amax(1))
 
 
+def test_upsample_nchw3_last_stage(E, L):
+    """Last decoder stage (models/cdan.py:153-154): bilinear x2 of channels 0..2 of an NHWC tensor + the fp32 NCHW network
+    input, written as one 16-byte channel group per pixel; taps are read 4 channels at a time, so the source must be
+    16-byte aligned with a pixel stride that is a multiple of 4 channels -- anything else is rejected, not mis-read."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    for dt, td, oc, tol in ((L.F32, torch.float32, 4, 1e-6), (L.BF16, torch.bfloat16, 8, 8e-3)):
+        lo = torch.randn(2, 9, 7, 16, generator=g).cuda().to(td)
+        x = torch.rand(2, 3, 18, 14, generator=g).cuda()
+        out = torch.full((2, 18, 14, oc), 5.0, device="cuda", dtype=td)
+        L.check(L.lib.mdie_upsample2x_add_nchw3(dt, 2, 9, 7, lo.data_ptr(), 16, x.data_ptr(), out.data_ptr(), oc, None), "nchw3")
+        ref = F.interpolate(lo[..., :3].float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False) + x
+        assert rel_to_max(out[..., :3].float().permute(0, 3, 1, 2), ref) <= tol
+        assert (out[..., 3:] == 0).all()
+        assert L.lib.mdie_upsample2x_add_nchw3(dt, 2, 9, 7, lo.data_ptr(), 6, x.data_ptr(), out.data_ptr(), oc, None) != 0
+        assert L.lib.mdie_upsample2x_add_nchw3(dt, 2, 9, 7, lo.data_ptr() + 8, 16, x.data_ptr(), out.data_ptr(), oc, None) != 0
+
+
 def test_conv_rejects_bad_arguments(E, L):
     x = torch.zeros(1, 4, 4, 16, device="cuda")
     w = torch.zeros(L.lib.mdie_conv_weight_bytes(L.F32, 3, 16, 16), dtype=torch.uint8, device="cuda")
