@@ -173,6 +173,8 @@ int mdie_pack_conv_first_weight(int dtype, const float* w, int cout, int cout_st
  *   3. mdie_cbam_chanpool  y = x*gate; map = (max_c y, mean_c y)            (cbam.py:59,68-70)
  *   4. mdie_cbam_spatial   s = sigmoid(BN(conv7x7(map))); out = x*gate*s [* mul]
  *                          (cbam.py:72-82; `out *= denses[k]`, models/cdan.py:133,141,149)
+ * `out` may be `x` itself (in place); otherwise it must not overlap `x` or `mul` (pass 4 batches its loads ahead of
+ * its stores).  C >= 256 runs pass 2 as its own launch, smaller C folds it into pass 3.
  * --------------------------------------------------------------------------------- */
 typedef struct {
   int dtype;
