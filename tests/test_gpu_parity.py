@@ -267,6 +267,37 @@ def test_cbam(E, L, golden_dir, c, precision):
     assert err <= tol_for(precision), f"channel gate: {err:.3e}"
 
 
+@pytest.mark.parametrize("c,hw", [(64, (24, 40)), (256, (8, 8))])
+def test_cbam_in_place_equals_out_of_place(E, L, c, hw):
+    """include/mdie.h: `out` of mdie_cbam_fwd may be `x` itself.  Pass 4 batches and prefetches its loads ahead of its stores,
+    so this pins that every 16-byte unit is read before the same thread overwrites it: in-place == out-of-place, bit for bit
+    (folded gate at C=64, separate gate launch at C=256; with and without the multiplicand)."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(c)
+    for dt, td in ((L.BF16, torch.bfloat16), (L.F32, torch.float32)):
+        x = torch.randn(2, *hw, c, generator=g).cuda().to(td)
+        mul = torch.randn(2, *hw, c, generator=g).cuda().to(td)
+        w1, b1 = torch.randn(c // 16, c, generator=g).cuda() * 0.1, torch.randn(c // 16, generator=g).cuda() * 0.1
+        w2, b2 = torch.randn(c, c // 16, generator=g).cuda() * 0.1, torch.randn(c, generator=g).cuda() * 0.1
+        w7, bn = torch.randn(2, 7, 7, generator=g).cuda() * 0.1, torch.tensor([0.9, 0.05]).cuda()
+        for m in (None, mul):
+            ref = E.cbam_fwd(x, w1, b1, w2, b2, w7, bn, dtype=dt, mul=m)
+            xi = x.clone()
+            n = L.lib.mdie_cbam_workspace_bytes(2, hw[0], hw[1], c)
+            ws = torch.empty(n, dtype=torch.uint8, device="cuda")
+            d = L.CbamDesc()
+            d.dtype, d.B, d.H, d.W, d.C = dt, 2, hw[0], hw[1], c
+            d.x, d.x_stride = xi.data_ptr(), c
+            d.w1, d.b1, d.w2, d.b2, d.w7, d.bn = (t.data_ptr() for t in (w1, b1, w2, b2, w7, bn))
+            d.mul, d.mul_stride = (m.data_ptr(), c) if m is not None else (None, 0)
+            d.out, d.out_stride = xi.data_ptr(), c
+            d.workspace, d.workspace_bytes = ws.data_ptr(), n
+            d.pool_partial, d.pool_slabs = None, 0
+            L.check(L.lib.mdie_cbam_fwd(C.byref(d), None), "mdie_cbam_fwd")
+            torch.cuda.synchronize()
+            assert torch.equal(xi, ref)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("cin,cout", [(32, 16), (64, 3)])
 def test_conv_transpose(E, L, golden_dir, cin, cout, precision):
