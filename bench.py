@@ -26,7 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3}
+MFMA_PEAK_TF = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}
 
 
 def kind_model(B, H, W, esz):
@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="enqueue launches eagerly instead of replaying a hipGraph (= --launch eager)")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
                     help="how a step is enqueued: one hipGraph replay, 41 eager launches from one host call, or (auto) whichever "
@@ -222,7 +222,7 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
-    esz = 2 if args.precision == "bf16" else 4
+    esz = 4 if args.precision == "fp32" else 2
     alg_bytes = L.lib.mdie_cdan_algorithmic_bytes(B, S, S, esz)
     flops = L.lib.mdie_cdan_flops(B, S, S)
     model = kind_model(B, S, S, esz)

@@ -11,7 +11,7 @@
  *
  * Conventions
  *   - All device tensors are NHWC ("channels last"), element type `dtype`
- *     (MDIE_F32 or MDIE_BF16), pixel stride given in ELEMENTS.  Channel counts
+ *     (MDIE_F32, MDIE_BF16 or MDIE_F16), pixel stride given in ELEMENTS.  Channel counts
  *     of internal tensors are multiples of 16; the 3-channel tensors of the path
  *     (input x, decoder.conv4 output, final output) are stored with 16 channels,
  *     channels 3..15 zero.
@@ -20,7 +20,9 @@
  *   - Return 0 on success, a negative MDIE_E* code on error;
  *     mdie_last_error() returns a thread-local message.
  *   - Accumulation is always fp32.  MDIE_F32 uses the exact-f32 MFMA
- *     (v_mfma_f32_16x16x4_f32), MDIE_BF16 the bf16 MFMA (v_mfma_f32_16x16x32_bf16).
+ *     (v_mfma_f32_16x16x4_f32), MDIE_BF16 the bf16 MFMA (v_mfma_f32_16x16x32_bf16),
+ *     MDIE_F16 the fp16 MFMA (v_mfma_f32_16x16x32_f16); the two 16-bit types share every
+ *     layout rule stated for "bf16" below (8 elements per 16 bytes, 32-channel K chunks).
  */
 #ifndef MDIE_H
 #define MDIE_H
@@ -32,9 +34,10 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 15
+#define MDIE_ABI_VERSION 16
 
-enum { MDIE_F32 = 0, MDIE_BF16 = 1 };
+enum { MDIE_F32 = 0, MDIE_BF16 = 1,
+       MDIE_F16 = 2 /* IEEE half: the reference's mixed-precision dtype (torch.cuda.amp.autocast, models/model.py:15,159) */ };
 enum { MDIE_ACT_NONE = 0, MDIE_ACT_RELU = 1, MDIE_ACT_SIGMOID = 2 };
 enum {
   MDIE_OK = 0,

@@ -565,9 +565,9 @@ static RedPlan red_plan(long N, int CV) {
 }
 
 static int bn_check(const char* what, int dtype, long N, int C) {
-  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "%s: bad dtype %d", what, dtype);
+  MDIE_REQUIRE(dtype_valid(dtype), "%s: bad dtype %d", what, dtype);
   MDIE_REQUIRE(N > 0, "%s: empty tensor", what);
-  const int vec = dtype == MDIE_F32 ? 4 : 8;
+  const int vec = dtype_vec(dtype);
   MDIE_REQUIRE(C > 0 && C % 16 == 0 && C / vec <= BN_THREADS, "%s: C = %d must be a multiple of 16 and <= %d", what, C, BN_THREADS * vec);
   return MDIE_OK;
 }
@@ -587,12 +587,11 @@ extern "C" int mdie_bn_stats(int dtype, long N, const void* x, int C, int stride
   MDIE_REQUIRE(x && mean && var && workspace && stride >= C, "mdie_bn_stats: null pointer / stride %d < C %d", stride, C);
   if (workspace_bytes < mdie_bn_workspace_bytes(C)) { set_error("mdie_bn_stats: workspace %zu < %zu", workspace_bytes, mdie_bn_workspace_bytes(C)); return MDIE_ENOSPC; }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int vec = dtype == MDIE_F32 ? 4 : 8;
+  const int vec = dtype_vec(dtype);
   const RedPlan p = red_plan(N, C / vec);
   const size_t lds = (size_t)p.rows * 2 * C * sizeof(float);
   float* partial = reinterpret_cast<float*>(workspace);
-  if (dtype == MDIE_F32) hipLaunchKernelGGL((bn_stats_kernel<float>), dim3(p.blocks), dim3(BN_THREADS), lds, s, N, (const char*)x, C, stride, p.chunk, partial);
-  else hipLaunchKernelGGL((bn_stats_kernel<mdie::bf16>), dim3(p.blocks), dim3(BN_THREADS), lds, s, N, (const char*)x, C, stride, p.chunk, partial);
+  MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(p.blocks), dim3(BN_THREADS), lds, s, N, (const char*)x, C, stride, p.chunk, partial));
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, s, p.blocks, C, (double)N, partial, mean, var);
   MDIE_LAUNCH_CHECK("mdie_bn_stats");
   return MDIE_OK;
@@ -618,13 +617,12 @@ extern "C" int mdie_bn_act_pool_fwd(int dtype, int B, int H, int W, int C, const
   MDIE_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), "mdie_bn_act_pool_fwd: pooling needs even H, W (got %dx%d)", H, W);
   MDIE_REQUIRE(p >= 0.f && p < 1.f, "mdie_bn_act_pool_fwd: dropout p = %f", (double)p);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int vec = dtype == MDIE_F32 ? 4 : 8;
+  const int vec = dtype_vec(dtype);
   const size_t total = (size_t)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C / vec);
   const dim3 grid(bn_grid(total)), blk(BN_THREADS);
 #define MDIE_BN_FWD(T, P) hipLaunchKernelGGL((bn_act_pool_fwd_kernel<T, P>), grid, blk, 0, s, B, H, W, C, (const char*)y, y_stride, scale, shift, (char*)out, \
                                              out_stride, (char*)out_drop, drop_stride, p, (uint32_t)seed)
-  if (dtype == MDIE_F32) { if (pool) MDIE_BN_FWD(float, true); else MDIE_BN_FWD(float, false); }
-  else { if (pool) MDIE_BN_FWD(mdie::bf16, true); else MDIE_BN_FWD(mdie::bf16, false); }
+  MDIE_SWITCH_T(dtype, if (pool) MDIE_BN_FWD(T, true); else MDIE_BN_FWD(T, false));
 #undef MDIE_BN_FWD
   MDIE_LAUNCH_CHECK("mdie_bn_act_pool_fwd");
   return MDIE_OK;
@@ -646,7 +644,7 @@ extern "C" int mdie_bn_act_pool_bwd(const mdie_bn_pool_bwd_desc* d, void* stream
   MDIE_REQUIRE(!d->pool || (d->H % 2 == 0 && d->W % 2 == 0), "mdie_bn_act_pool_bwd: pooling needs even H, W");
   if (d->workspace_bytes < mdie_bn_workspace_bytes(d->C)) { set_error("mdie_bn_act_pool_bwd: workspace too small"); return MDIE_ENOSPC; }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int vec = d->dtype == MDIE_F32 ? 4 : 8;
+  const int vec = dtype_vec(d->dtype);
   const long NO = (long)d->B * (d->pool ? d->H / 2 : d->H) * (d->pool ? d->W / 2 : d->W);
   const RedPlan p = red_plan(NO, d->C / vec);
   BnBwdPoolArgs a{};
@@ -661,8 +659,7 @@ extern "C" int mdie_bn_act_pool_bwd(const mdie_bn_pool_bwd_desc* d, void* stream
   a.chunk = p.chunk;
   const size_t lds = (size_t)p.rows * 2 * d->C * sizeof(float);
 #define MDIE_BN_BWD(T, P) hipLaunchKernelGGL((bn_act_pool_bwd_kernel<T, P>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a)
-  if (d->dtype == MDIE_F32) { if (d->pool) MDIE_BN_BWD(float, true); else MDIE_BN_BWD(float, false); }
-  else { if (d->pool) MDIE_BN_BWD(mdie::bf16, true); else MDIE_BN_BWD(mdie::bf16, false); }
+  MDIE_SWITCH_T(d->dtype, if (d->pool) MDIE_BN_BWD(T, true); else MDIE_BN_BWD(T, false));
 #undef MDIE_BN_BWD
   return bn_bwd_finish("mdie_bn_act_pool_bwd", p.blocks, d->C, d->c_real, d->C, 0, (double)d->B * d->H * d->W, a.partial, d->dgamma, d->dbeta, d->coef, s);
 }
@@ -672,13 +669,12 @@ extern "C" int mdie_bn_act_up_add_fwd(int dtype, int B, int H, int W, int C, con
   if (int e = bn_check("mdie_bn_act_up_add_fwd", dtype, (long)B * H * W, C)) return e;
   MDIE_REQUIRE(y && scale && shift && out, "mdie_bn_act_up_add_fwd: null pointer");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int vec = dtype == MDIE_F32 ? 4 : 8;
+  const int vec = dtype_vec(dtype);
   const size_t total = (size_t)B * H * W * (up ? 4 : 1) * (C / vec);
   const dim3 grid(bn_grid(total)), blk(BN_THREADS);
 #define MDIE_BN_UP(T, U) hipLaunchKernelGGL((bn_act_up_add_fwd_kernel<T, U>), grid, blk, 0, s, B, H, W, C, (const char*)y, y_stride, scale, shift, \
                                             (const char*)skip, skip_stride, (char*)out, out_stride)
-  if (dtype == MDIE_F32) { if (up) MDIE_BN_UP(float, true); else MDIE_BN_UP(float, false); }
-  else { if (up) MDIE_BN_UP(mdie::bf16, true); else MDIE_BN_UP(mdie::bf16, false); }
+  MDIE_SWITCH_T(dtype, if (up) MDIE_BN_UP(T, true); else MDIE_BN_UP(T, false));
 #undef MDIE_BN_UP
   MDIE_LAUNCH_CHECK("mdie_bn_act_up_add_fwd");
   return MDIE_OK;
@@ -691,7 +687,7 @@ extern "C" int mdie_bn_act_up_bwd(const mdie_bn_up_bwd_desc* d, void* stream) {
                "mdie_bn_act_up_bwd: null pointer");
   if (d->workspace_bytes < mdie_bn_workspace_bytes(d->C)) { set_error("mdie_bn_act_up_bwd: workspace too small"); return MDIE_ENOSPC; }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int vec = d->dtype == MDIE_F32 ? 4 : 8;
+  const int vec = dtype_vec(d->dtype);
   const long N = (long)d->B * d->H * d->W;
   const RedPlan p = red_plan(N, d->C / vec);
   BnBwdUpArgs a{};
@@ -703,8 +699,7 @@ extern "C" int mdie_bn_act_up_bwd(const mdie_bn_up_bwd_desc* d, void* stream) {
   a.partial = reinterpret_cast<float*>(d->workspace);
   a.chunk = p.chunk;
   const size_t lds = (size_t)p.rows * 2 * d->C * sizeof(float);
-  if (d->dtype == MDIE_F32) hipLaunchKernelGGL((bn_act_up_bwd_kernel<float>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a);
-  else hipLaunchKernelGGL((bn_act_up_bwd_kernel<mdie::bf16>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a);
+  MDIE_SWITCH_T(d->dtype, hipLaunchKernelGGL((bn_act_up_bwd_kernel<T>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a));
   return bn_bwd_finish("mdie_bn_act_up_bwd", p.blocks, d->C, d->c_real, d->C, 0, (double)N, a.partial, d->dgamma, d->dbeta, d->coef, s);
 }
 
@@ -736,13 +731,12 @@ extern "C" int mdie_bn_bwd_reduce(const mdie_bn_bwd_desc* d, void* stream) {
   MDIE_REQUIRE(d->dgamma && d->dbeta && d->workspace, "mdie_bn_bwd_reduce: null pointer");
   if (d->workspace_bytes < mdie_bn_workspace_bytes(a.C)) { set_error("mdie_bn_bwd_reduce: workspace too small"); return MDIE_ENOSPC; }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int vec = d->dtype == MDIE_F32 ? 4 : 8;
+  const int vec = dtype_vec(d->dtype);
   const RedPlan p = red_plan(a.N, a.C / vec);
   a.partial = reinterpret_cast<float*>(d->workspace);
   a.chunk = p.chunk;
   const size_t lds = (size_t)p.rows * 2 * a.C * sizeof(float);
-  if (d->dtype == MDIE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a);
-  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<mdie::bf16>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a);
+  MDIE_SWITCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a));
   return bn_bwd_finish("mdie_bn_bwd_reduce", p.blocks, a.C, d->c_real, d->split, d->gap, (double)a.N, a.partial, d->dgamma, d->dbeta, d->coef, s);
 }
 
@@ -750,25 +744,23 @@ extern "C" int mdie_bn_bwd_apply(const mdie_bn_bwd_desc* d, void* stream) {
   BnBwdArgs a{};
   if (int e = fill_bwd_args("mdie_bn_bwd_apply", d, a, true)) return e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int vec = d->dtype == MDIE_F32 ? 4 : 8;
+  const int vec = dtype_vec(d->dtype);
   const int rows = BN_THREADS / (a.C / vec);
   long blocks = (a.N + (long)rows * 4 - 1) / ((long)rows * 4);          // >= 4 pixels per thread
   if (blocks > 4096) blocks = 4096;
   a.chunk = (a.N + blocks - 1) / blocks;
   blocks = (a.N + a.chunk - 1) / a.chunk;
-  if (d->dtype == MDIE_F32) hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3((int)blocks), dim3(BN_THREADS), 0, s, a);
-  else hipLaunchKernelGGL((bn_bwd_apply_kernel<mdie::bf16>), dim3((int)blocks), dim3(BN_THREADS), 0, s, a);
+  MDIE_SWITCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3((int)blocks), dim3(BN_THREADS), 0, s, a));
   MDIE_LAUNCH_CHECK("mdie_bn_bwd_apply");
   return MDIE_OK;
 }
 
 extern "C" int mdie_sigmoid_bwd_nchw3(int dtype, int B, int H, int W, const float* grad_nchw, const float* y_nchw, void* dz_nhwc16, int dz_stride, void* stream) {
-  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_sigmoid_bwd_nchw3: bad dtype %d", dtype);
+  MDIE_REQUIRE(dtype_valid(dtype), "mdie_sigmoid_bwd_nchw3: bad dtype %d", dtype);
   MDIE_REQUIRE(B > 0 && H > 0 && W > 0 && grad_nchw && y_nchw && dz_nhwc16 && dz_stride >= 16, "mdie_sigmoid_bwd_nchw3: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t total = (size_t)B * H * W;
-  if (dtype == MDIE_F32) hipLaunchKernelGGL((sigmoid_bwd_nchw3_kernel<float>), dim3(bn_grid(total)), dim3(BN_THREADS), 0, s, B, H * W, grad_nchw, y_nchw, (float*)dz_nhwc16, dz_stride);
-  else hipLaunchKernelGGL((sigmoid_bwd_nchw3_kernel<mdie::bf16>), dim3(bn_grid(total)), dim3(BN_THREADS), 0, s, B, H * W, grad_nchw, y_nchw, (mdie::bf16*)dz_nhwc16, dz_stride);
+  MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((sigmoid_bwd_nchw3_kernel<T>), dim3(bn_grid(total)), dim3(BN_THREADS), 0, s, B, H * W, grad_nchw, y_nchw, (T*)dz_nhwc16, dz_stride));
   MDIE_LAUNCH_CHECK("mdie_sigmoid_bwd_nchw3");
   return MDIE_OK;
 }

@@ -503,7 +503,7 @@ static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
 
 static int check_cbam(const mdie_cbam_desc* d) {
   MDIE_REQUIRE(d != nullptr, "mdie_cbam_fwd: null descriptor");
-  MDIE_REQUIRE(d->dtype == MDIE_F32 || d->dtype == MDIE_BF16, "mdie_cbam_fwd: bad dtype %d", d->dtype);
+  MDIE_REQUIRE(dtype_valid(d->dtype), "mdie_cbam_fwd: bad dtype %d", d->dtype);
   MDIE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "mdie_cbam_fwd: empty extent");
   MDIE_REQUIRE(d->C >= 16 && d->C <= 512 && (d->C & (d->C - 1)) == 0, "mdie_cbam_fwd: C = %d must be a power of two in [16, 512]", d->C);
   MDIE_REQUIRE(d->x && d->out && d->w1 && d->b1 && d->w2 && d->b2 && d->w7 && d->bn && d->workspace, "mdie_cbam_fwd: null pointer");
@@ -529,12 +529,12 @@ extern "C" int mdie_cbam_fwd(const mdie_cbam_desc* d, void* stream) {
   using namespace mdie;
   if (int e = check_cbam(d)) return e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return d->dtype == MDIE_F32 ? run_cbam<float>(d, true, s) : run_cbam<mdie::bf16>(d, true, s);
+  MDIE_SWITCH_T(d->dtype, return run_cbam<T>(d, true, s));
 }
 
 extern "C" int mdie_cbam_channel_only_fwd(const mdie_cbam_desc* d, void* stream) {
   using namespace mdie;
   if (int e = check_cbam(d)) return e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return d->dtype == MDIE_F32 ? run_cbam<float>(d, false, s) : run_cbam<mdie::bf16>(d, false, s);
+  MDIE_SWITCH_T(d->dtype, return run_cbam<T>(d, false, s));
 }

@@ -582,7 +582,7 @@ static CtWs ct_ws(int B, int H, int W, int C) {
 
 static int ct_fill(const char* what, const mdie_cbam_train_desc* d, CbtArgs& a) {
   MDIE_REQUIRE(d != nullptr, "%s: null descriptor", what);
-  MDIE_REQUIRE(d->dtype == MDIE_F32 || d->dtype == MDIE_BF16, "%s: bad dtype %d", what, d->dtype);
+  MDIE_REQUIRE(dtype_valid(d->dtype), "%s: bad dtype %d", what, d->dtype);
   MDIE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "%s: empty extent", what);
   MDIE_REQUIRE(d->C >= 16 && d->C <= 512 && (d->C & (d->C - 1)) == 0, "%s: C = %d must be a power of two in [16, 512]", what, d->C);
   MDIE_REQUIRE(d->x && d->w1 && d->b1 && d->w2 && d->b2 && d->w7 && d->gamma && d->beta && d->workspace, "%s: null pointer", what);
@@ -668,7 +668,7 @@ extern "C" int mdie_cbam_train_fwd(const mdie_cbam_train_desc* d, void* stream) 
   MDIE_REQUIRE(d->out && d->out_stride % 16 == 0, "mdie_cbam_train_fwd: out");
   MDIE_REQUIRE((d->running_mean == nullptr) == (d->running_var == nullptr), "mdie_cbam_train_fwd: running_mean / running_var");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return d->dtype == MDIE_F32 ? ct_forward<float>(d, a, s) : ct_forward<mdie::bf16>(d, a, s);
+  MDIE_SWITCH_T(d->dtype, return ct_forward<T>(d, a, s));
 }
 
 extern "C" int mdie_cbam_train_bwd(const mdie_cbam_train_desc* d, void* stream) {
@@ -682,5 +682,5 @@ extern "C" int mdie_cbam_train_bwd(const mdie_cbam_train_desc* d, void* stream) 
   a.dmul = (char*)d->dmul; a.dmul_stride = d->dmul_stride;
   a.dw1 = d->dw1; a.db1 = d->db1; a.dw2 = d->dw2; a.db2 = d->db2; a.dw7 = d->dw7; a.dgamma = d->dgamma; a.dbeta = d->dbeta;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return d->dtype == MDIE_F32 ? ct_backward<float>(d, a, s) : ct_backward<mdie::bf16>(d, a, s);
+  MDIE_SWITCH_T(d->dtype, return ct_backward<T>(d, a, s));
 }

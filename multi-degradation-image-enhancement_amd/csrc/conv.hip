@@ -67,6 +67,9 @@ template <typename T> __device__ __forceinline__ f32x4 mma16(const uint4& w, con
 template <> __device__ __forceinline__ f32x4 mma16<bf16>(const uint4& w, const uint4& x, f32x4 acc) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
 }
+template <> __device__ __forceinline__ f32x4 mma16<f16>(const uint4& w, const uint4& x, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+}
 template <> __device__ __forceinline__ f32x4 mma16<float>(const uint4& w, const uint4& x, f32x4 acc) {
   // lane group g = lane>>4 holds channels 4g..4g+3; MFMA j pairs channel 4g+j of both operands
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
@@ -132,7 +135,7 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
   T* const orow0 = reinterpret_cast<T*>(e.out) + opix0 * e.out_stride + n0 + lq * 4;
   const T* const rrow0 = e.residual ? reinterpret_cast<const T*>(e.residual) + opix0 * e.res_stride + n0 + lq * 4 : nullptr;
   if constexpr (sizeof(T) == 2 && (ACT == MDIE_ACT_RELU || (ACT == MDIE_ACT_NONE && !POOL)) && !STATS) {
-    // bf16 + ReLU (or no activation, unpooled: the DenseLayers), no residual: the whole epilogue in packed form -- v_pk_fma_f32 for the affine, one v_cvt_pk_bf16_f32 per pair,
+    // 16-bit output + ReLU (or no activation, unpooled: the DenseLayers), no residual: the whole epilogue in packed form -- v_pk_fma_f32 for the affine, one v_cvt_pk_{bf16,f16}_f32 per pair,
     // ReLU and the 2x2 max on the ROUNDED halves as packed 16-bit integer maxima (rounding is monotonic and keeps the sign, so
     // this equals rounding relu(max(...)) of the fp32 values): 14 instead of 18 vector instructions per 4 channels when
     // pooling, 6 instead of 10 without
@@ -148,8 +151,8 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
         for (int cs = 0; cs < NCS; ++cs) {
           const f32x2 lo = __builtin_elementwise_fma(f32x2{acc[cs][ps][0], acc[cs][ps][1]}, f32x2{esc[cs].x, esc[cs].y}, f32x2{esh[cs].x, esh[cs].y});
           const f32x2 hi = __builtin_elementwise_fma(f32x2{acc[cs][ps][2], acc[cs][ps][3]}, f32x2{esc[cs].z, esc[cs].w}, f32x2{esh[cs].z, esh[cs].w});
-          i16x2 p0 = __builtin_bit_cast(i16x2, __builtin_convertvector(lo, bf16x2));
-          i16x2 p1 = __builtin_bit_cast(i16x2, __builtin_convertvector(hi, bf16x2));
+          i16x2 p0 = half_bits<T>(lo);
+          i16x2 p1 = half_bits<T>(hi);
           if constexpr (ACT == MDIE_ACT_RELU) { p0 = __builtin_elementwise_max(p0, i16x2{0, 0}); p1 = __builtin_elementwise_max(p1, i16x2{0, 0}); }
           if constexpr (POOL) {   // non-negative bf16 order like their bit patterns
             p0 = __builtin_elementwise_max(p0, __builtin_bit_cast(i16x2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, p0), 0xB1, 0xF, 0xF, true)));
@@ -208,7 +211,7 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
             for (int i = 0; i < 4; ++i) o[i] += ld(rrow + j * 16 + i);
           }
           if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(orow + j * 16) = make_float4(o[0], o[1], o[2], o[3]);
-          else *reinterpret_cast<uint2*>(orow + j * 16) = make_uint2(bf_pack(o[0], o[1]), bf_pack(o[2], o[3]));
+          else *reinterpret_cast<uint2*>(orow + j * 16) = make_uint2(Half<T>::pack(o[0], o[1]), Half<T>::pack(o[2], o[3]));
         }
         continue;
       }
@@ -245,7 +248,7 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float qv = v[i];
-            if constexpr (sizeof(T) == 2) qv = (float)(bf16)qv;
+            if constexpr (sizeof(T) == 2) qv = (float)(T)qv;
             st_sum[cs][i] += qv;
             st_max[cs][i] = fmaxf(st_max[cs][i], qv);
           }
@@ -253,7 +256,7 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
         if constexpr (sizeof(T) == 4) {
           *reinterpret_cast<float4*>(orow + cs * 16) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          *reinterpret_cast<uint2*>(orow + cs * 16) = make_uint2(bf_pack(v[0], v[1]), bf_pack(v[2], v[3]));
+          *reinterpret_cast<uint2*>(orow + cs * 16) = make_uint2(Half<T>::pack(v[0], v[1]), Half<T>::pack(v[2], v[3]));
         }
       }
     }
@@ -759,12 +762,12 @@ static int launch_conv1x1_stream(ConvArgs& a, hipStream_t stream) {
   const dim3 grid(gx, a.n_tiles);
   TimedLaunch tl(MDIE_K_CONV1);
   if (a.pre_scale) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel<T, NCS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+    static LdsOptIn opt;
+    if (!opt.ensure(reinterpret_cast<const void*>(&conv1x1_stream_kernel<T, NCS, true>), 96 * 1024)) return MDIE_ELAUNCH;
     hipLaunchKernelGGL((conv1x1_stream_kernel<T, NCS, true>), grid, dim3(CONV_THREADS), lds, stream, a, tiles_total);
   } else {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel<T, NCS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+    static LdsOptIn opt;
+    if (!opt.ensure(reinterpret_cast<const void*>(&conv1x1_stream_kernel<T, NCS, false>), 96 * 1024)) return MDIE_ELAUNCH;
     hipLaunchKernelGGL((conv1x1_stream_kernel<T, NCS, false>), grid, dim3(CONV_THREADS), lds, stream, a, tiles_total);
   }
   MDIE_LAUNCH_CHECK("mdie_conv_fwd");
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_kernel(const First
     const int p = tid + it * CONV_THREADS;
     if (p < PW * PW) {
       T* d = patch + p * 4;
-      if constexpr (E == 2) *reinterpret_cast<uint2*>(d) = make_uint2(bf_pack(xin[it][0], xin[it][1]), bf_pack(xin[it][2], 0.f));
+      if constexpr (E == 2) *reinterpret_cast<uint2*>(d) = make_uint2(Half<T>::pack(xin[it][0], xin[it][1]), Half<T>::pack(xin[it][2], 0.f));
       else *reinterpret_cast<float4*>(d) = make_float4(xin[it][0], xin[it][1], xin[it][2], 0.f);
     }
   }
@@ -917,12 +920,8 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   // vs 48.2/50.8 us), as did the same launch with its stores compiled out (43/52 us): per tile these layers cost
   // ~13 k cycles of a CU slot whether or not setup, weight staging, load latency or stores are on the path.)
   const dim3 grid(8, a.n_tiles, cdiv(a.tiles_x * a.tiles_y * a.B, 8));
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, BN, TILE, STATS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G::BUF_BYTES + 8 * 1024);
-    attr_set = true;
-  }
+  static LdsOptIn opt;
+  if (!opt.ensure(reinterpret_cast<const void*>(&conv_kernel<T, KS, BN, TILE, STATS>), G::BUF_BYTES + 8 * 1024)) return MDIE_ELAUNCH;
   TimedLaunch tl(KS == 3 ? MDIE_K_CONV3 : MDIE_K_CONV1);
   const size_t lds = G::BUF_BYTES + 2 * BN * sizeof(float) + (a.pre_scale ? (size_t)2 * a.nchunk * Traits<T>::KC * sizeof(float) : 0);
   hipLaunchKernelGGL((conv_kernel<T, KS, BN, TILE, STATS>), grid, dim3(CONV_THREADS), lds, stream, a);
@@ -1040,7 +1039,7 @@ __global__ __launch_bounds__(CONV_THREADS) void stem7_kernel(const StemArgs a) {
       v0 = (xp[0] - a.mean[0]) * a.inv_std[0]; v1 = (xp[plane] - a.mean[1]) * a.inv_std[1]; v2 = (xp[2 * plane] - a.mean[2]) * a.inv_std[2];
     }
     T* d = patch + p * 4;
-    if constexpr (E == 2) *reinterpret_cast<uint2*>(d) = make_uint2(bf_pack(v0, v1), bf_pack(v2, 0.f));
+    if constexpr (E == 2) *reinterpret_cast<uint2*>(d) = make_uint2(Half<T>::pack(v0, v1), Half<T>::pack(v2, 0.f));
     else *reinterpret_cast<float4*>(d) = make_float4(v0, v1, v2, 0.f);
   }
   __syncthreads();
@@ -1115,7 +1114,7 @@ static int dispatch_first(const mdie_conv_first_desc* d, hipStream_t stream) {
 extern "C" int mdie_conv_fwd(const mdie_conv_desc* d, void* stream) {
   using namespace mdie;
   MDIE_REQUIRE(d != nullptr, "mdie_conv_fwd: null descriptor");
-  MDIE_REQUIRE(d->dtype == MDIE_F32 || d->dtype == MDIE_BF16, "mdie_conv_fwd: bad dtype %d", d->dtype);
+  MDIE_REQUIRE(dtype_valid(d->dtype), "mdie_conv_fwd: bad dtype %d", d->dtype);
   MDIE_REQUIRE(d->ksize == 3 || d->ksize == 1, "mdie_conv_fwd: ksize %d (3 or 1)", d->ksize);
   MDIE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "mdie_conv_fwd: empty extent %dx%dx%d", d->B, d->H, d->W);
   MDIE_REQUIRE(d->nseg >= 1 && d->nseg <= MDIE_MAX_SEG, "mdie_conv_fwd: nseg %d", d->nseg);
@@ -1132,7 +1131,7 @@ extern "C" int mdie_conv_fwd(const mdie_conv_desc* d, void* stream) {
   MDIE_REQUIRE(!d->pool_partial || (d->ksize == 3 && d->cout % 64 == 0 && d->act == MDIE_ACT_RELU && !d->pool && !d->out_nchw3),
                "mdie_conv_fwd: pool_partial needs a 3x3 convolution with cout %% 64 == 0, ReLU and no max-pool");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return d->dtype == MDIE_F32 ? dispatch_conv<float>(d, s) : dispatch_conv<mdie::bf16>(d, s);
+  MDIE_SWITCH_T(d->dtype, return dispatch_conv<T>(d, s));
 }
 
 extern "C" int mdie_conv_tile(int B, int H, int W, int cout) {
@@ -1145,7 +1144,7 @@ extern "C" int mdie_conv_tile(int B, int H, int W, int cout) {
 extern "C" int mdie_conv_first_fwd(const mdie_conv_first_desc* d, void* stream) {
   using namespace mdie;
   MDIE_REQUIRE(d != nullptr, "mdie_conv_first_fwd: null descriptor");
-  MDIE_REQUIRE(d->dtype == MDIE_F32 || d->dtype == MDIE_BF16, "mdie_conv_first_fwd: bad dtype %d", d->dtype);
+  MDIE_REQUIRE(dtype_valid(d->dtype), "mdie_conv_first_fwd: bad dtype %d", d->dtype);
   MDIE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "mdie_conv_first_fwd: empty extent");
   MDIE_REQUIRE(d->cout > 0 && d->cout % 16 == 0, "mdie_conv_first_fwd: cout %d must be a multiple of 16", d->cout);
   MDIE_REQUIRE(d->x && d->weight && d->post_scale && d->post_shift && d->out, "mdie_conv_first_fwd: null pointer");
@@ -1153,17 +1152,17 @@ extern "C" int mdie_conv_first_fwd(const mdie_conv_first_desc* d, void* stream) 
   MDIE_REQUIRE(d->out_stride % 4 == 0 && d->out_stride >= d->cout, "mdie_conv_first_fwd: out_stride %d", d->out_stride);
   MDIE_REQUIRE(((uintptr_t)d->out & 15) == 0 && ((uintptr_t)d->weight & 15) == 0, "mdie_conv_first_fwd: out/weight alignment");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return d->dtype == MDIE_F32 ? dispatch_first<float>(d, s) : dispatch_first<mdie::bf16>(d, s);
+  MDIE_SWITCH_T(d->dtype, return dispatch_first<T>(d, s));
 }
 
-extern "C" size_t mdie_stem7_weight_bytes(int dtype) { return (dtype == MDIE_F32 || dtype == MDIE_BF16) ? (size_t)(160 / (dtype == MDIE_F32 ? 16 : 32)) * 64 * 64 : 0; }
+extern "C" size_t mdie_stem7_weight_bytes(int dtype) { return mdie::dtype_valid(dtype) ? (size_t)(160 / mdie::dtype_kc(dtype)) * 64 * 64 : 0; }
 
 extern "C" int mdie_pack_stem7_weight(int dtype, const float* w, void* dst) {
   using namespace mdie;
-  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_pack_stem7_weight: bad dtype %d", dtype);
+  MDIE_REQUIRE(dtype_valid(dtype), "mdie_pack_stem7_weight: bad dtype %d", dtype);
   MDIE_REQUIRE(w && dst, "mdie_pack_stem7_weight: null pointer");
   // w: [64][3][7][7] (torchvision resnet conv1).  dst[step][cout][kl], k = step * KS + kl = (kh*7 + kw)*3 + c
-  const int KS = dtype == MDIE_F32 ? 16 : 32, steps = 160 / KS;
+  const int KS = dtype_kc(dtype), steps = 160 / KS;
   for (int s = 0; s < steps; ++s)
     for (int o = 0; o < 64; ++o)
       for (int kl = 0; kl < KS; ++kl) {
@@ -1172,11 +1171,7 @@ extern "C" int mdie_pack_stem7_weight(int dtype, const float* w, void* dst) {
         if (k < 147) { const int tap = k / 3, c = k % 3; v = w[((o * 3 + c) * 7 + tap / 7) * 7 + tap % 7]; }
         const size_t idx = ((size_t)s * 64 + o) * KS + kl;
         if (dtype == MDIE_F32) reinterpret_cast<float*>(dst)[idx] = v;
-        else {   // round to nearest even, as the device conversion does
-          uint32_t u; memcpy(&u, &v, 4);
-          u += 0x7fffu + ((u >> 16) & 1u);
-          reinterpret_cast<uint16_t*>(dst)[idx] = (uint16_t)(u >> 16);
-        }
+        else reinterpret_cast<uint16_t*>(dst)[idx] = f32_to_half_bits(dtype, v);   // round to nearest even, as the device conversion does
       }
   return MDIE_OK;
 }
@@ -1184,7 +1179,7 @@ extern "C" int mdie_pack_stem7_weight(int dtype, const float* w, void* dst) {
 extern "C" int mdie_stem7_fwd(int dtype, int B, int H, int W, const float* x_nchw, const float* mean3, const float* std3, const void* weight,
                               const float* post_scale, const float* post_shift, void* out, int out_stride, void* stream) {
   using namespace mdie;
-  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_stem7_fwd: bad dtype %d", dtype);
+  MDIE_REQUIRE(dtype_valid(dtype), "mdie_stem7_fwd: bad dtype %d", dtype);
   MDIE_REQUIRE(B > 0 && H > 0 && W > 0 && x_nchw && weight && post_scale && post_shift && out, "mdie_stem7_fwd: bad argument");
   MDIE_REQUIRE(out_stride >= 64 && out_stride % 4 == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)weight & 15) == 0, "mdie_stem7_fwd: out_stride / alignment");
   StemArgs a{};
@@ -1196,8 +1191,7 @@ extern "C" int mdie_stem7_fwd(int dtype, int B, int H, int W, const float* x_nch
   fill_epi(a.e, Ho, Wo, post_scale, post_shift, MDIE_ACT_RELU, 0, nullptr, 0, out, out_stride);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int grid = a.tiles_x * a.tiles_y * B;
-  if (dtype == MDIE_F32) hipLaunchKernelGGL((stem7_kernel<float>), dim3(grid), dim3(CONV_THREADS), 0, s, a);
-  else hipLaunchKernelGGL((stem7_kernel<mdie::bf16>), dim3(grid), dim3(CONV_THREADS), 0, s, a);
+  MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((stem7_kernel<T>), dim3(grid), dim3(CONV_THREADS), 0, s, a));
   MDIE_LAUNCH_CHECK("mdie_stem7_fwd");
   return MDIE_OK;
 }

@@ -55,7 +55,7 @@ struct Arch {
   int base3;   // stored channels of the 3-channel input of decoder.final_dense: ONE 16-byte K group per pixel
                // (8 bf16 / 4 f32), not 16 -- the five layers of the block read it five times at 256x256
   explicit Arch(int dtype) {
-    base3 = dtype == MDIE_F32 ? 4 : 8;
+    base3 = dtype_vec(dtype);
     conv.resize(CV_COUNT);
     const int enc[5] = {3, 64, 128, 256, 512};
     for (int i = 0; i < 4; ++i) {
@@ -82,7 +82,7 @@ struct Arch {
   }
 };
 static const Arch& arch(int dtype) {
-  static const Arch f32(MDIE_F32), b16(MDIE_BF16);
+  static const Arch f32(MDIE_F32), b16(MDIE_BF16);   // the two 16-bit types share one table (same channel grouping)
   return dtype == MDIE_F32 ? f32 : b16;
 }
 
@@ -99,7 +99,7 @@ struct BlobLayout {
 };
 
 static size_t conv_weight_bytes(int dtype, int ks, int cin_st, int cout_st) {
-  const int kc = dtype == MDIE_F32 ? 16 : 32;
+  const int kc = dtype_kc(dtype);
   return (size_t)cdiv(cin_st, kc) * ks * ks * cout_st * 64;
 }
 
@@ -133,17 +133,9 @@ static BlobLayout blob_layout(int dtype) {
 }
 
 // ---- host-side packing ----------------------------------------------------------------------------------------
-static uint16_t f32_to_bf16_rne(float f) {
-  uint32_t u;
-  memcpy(&u, &f, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-
 static int pack_conv_weight(int dtype, int ks, int transposed, const float* w, int cout, int cin, int cout_st, int cin_st, int split,
                             int gap, void* dst) {
-  const int kc = dtype == MDIE_F32 ? 16 : 32;
+  const int kc = dtype_kc(dtype);
   const int ntap = ks * ks;
   const size_t esz = dtype_size(dtype);
   memset(dst, 0, conv_weight_bytes(dtype, ks, cin_st, cout_st));
@@ -159,7 +151,7 @@ static int pack_conv_weight(int dtype, int ks, int transposed, const float* w, i
           const int vec = kc / 4, q = k / vec, i = k % vec;  // 16-byte quarter q of the chunk, element i in it
           const size_t idx = ((((size_t)chunk * 4 + q) * ntap + kh * ks + kw) * cout_st + o) * vec + i;
           if (esz == 4) reinterpret_cast<float*>(dst)[idx] = v;
-          else reinterpret_cast<uint16_t*>(dst)[idx] = f32_to_bf16_rne(v);
+          else reinterpret_cast<uint16_t*>(dst)[idx] = f32_to_half_bits(dtype, v);
         }
     }
   return MDIE_OK;
@@ -174,7 +166,7 @@ static void pack_first_weight(int dtype, const float* w, int cout, int cout_st, 
       const int tap = k / 3, c = k % 3;
       const float v = w[((size_t)o * 3 + c) * 9 + tap];
       if (dtype == MDIE_F32) reinterpret_cast<float*>(dst)[((size_t)(k / 16) * cout_st + o) * 16 + k % 16] = v;
-      else reinterpret_cast<uint16_t*>(dst)[(size_t)o * 32 + k] = f32_to_bf16_rne(v);
+      else reinterpret_cast<uint16_t*>(dst)[(size_t)o * 32 + k] = f32_to_half_bits(dtype, v);
     }
 }
 
@@ -267,34 +259,34 @@ extern "C" size_t mdie_conv_weight_bytes(int dtype, int ksize, int cin_stored, i
 
 extern "C" int mdie_pack_conv_weight(int dtype, int ksize, int transposed, const float* w, int cout, int cin, int cout_stored,
                                      int cin_stored, int split, int gap, void* dst) {
-  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_pack_conv_weight: bad dtype %d", dtype);
+  MDIE_REQUIRE(dtype_valid(dtype), "mdie_pack_conv_weight: bad dtype %d", dtype);
   MDIE_REQUIRE(ksize == 1 || ksize == 3, "mdie_pack_conv_weight: ksize %d", ksize);
   MDIE_REQUIRE(w && dst && cout > 0 && cin > 0, "mdie_pack_conv_weight: null/empty");
   MDIE_REQUIRE(cout_stored >= cout && cout_stored % 16 == 0, "mdie_pack_conv_weight: cout_stored %d", cout_stored);
-  MDIE_REQUIRE(cin_stored % (dtype == MDIE_F32 ? 4 : 8) == 0 && cin_stored >= cin + (split < cin ? gap : 0) && gap >= 0 && split >= 0,
+  MDIE_REQUIRE(cin_stored % dtype_vec(dtype) == 0 && cin_stored >= cin + (split < cin ? gap : 0) && gap >= 0 && split >= 0,
                "mdie_pack_conv_weight: cin_stored %d invalid / too small for cin %d split %d gap %d", cin_stored, cin, split, gap);
   return pack_conv_weight(dtype, ksize, transposed, w, cout, cin, cout_stored, cin_stored, split, gap, dst);
 }
 
 extern "C" size_t mdie_conv_first_weight_bytes(int dtype, int cout_stored) {
-  if ((dtype != MDIE_F32 && dtype != MDIE_BF16) || cout_stored <= 0) return 0;
+  if ((!dtype_valid(dtype)) || cout_stored <= 0) return 0;
   return first_weight_bytes(dtype, cout_stored);
 }
 
 extern "C" int mdie_pack_conv_first_weight(int dtype, const float* w, int cout, int cout_stored, void* dst) {
-  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_pack_conv_first_weight: bad dtype %d", dtype);
+  MDIE_REQUIRE(dtype_valid(dtype), "mdie_pack_conv_first_weight: bad dtype %d", dtype);
   MDIE_REQUIRE(w && dst && cout > 0 && cout_stored >= cout && cout_stored % 16 == 0, "mdie_pack_conv_first_weight: bad argument");
   pack_first_weight(dtype, w, cout, cout_stored, dst);
   return MDIE_OK;
 }
 
 extern "C" size_t mdie_cdan_param_bytes(int dtype) {
-  if (dtype != MDIE_F32 && dtype != MDIE_BF16) return 0;
+  if (!dtype_valid(dtype)) return 0;
   return blob_layout(dtype).total;
 }
 
 extern "C" int mdie_cdan_pack_params(int dtype, const mdie_tensor* tensors, int n, void* blob_host, size_t blob_bytes) {
-  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_cdan_pack_params: bad dtype %d", dtype);
+  MDIE_REQUIRE(dtype_valid(dtype), "mdie_cdan_pack_params: bad dtype %d", dtype);
   MDIE_REQUIRE(tensors && n > 0 && blob_host, "mdie_cdan_pack_params: null argument");
   const BlobLayout L = blob_layout(dtype);
   if (blob_bytes < L.total) { set_error("mdie_cdan_pack_params: blob %zu < %zu bytes", blob_bytes, L.total); return MDIE_ENOSPC; }
@@ -353,7 +345,7 @@ extern "C" int mdie_cdan_pack_params(int dtype, const mdie_tensor* tensors, int 
 }
 
 extern "C" size_t mdie_cdan_workspace_bytes(int dtype, int B, int H, int W) {
-  if ((dtype != MDIE_F32 && dtype != MDIE_BF16) || B <= 0 || H <= 0 || W <= 0 || H % 8 || W % 8) return 0;
+  if ((!dtype_valid(dtype)) || B <= 0 || H <= 0 || W <= 0 || H % 8 || W % 8) return 0;
   return make_plan(dtype, B, H, W).total;
 }
 
@@ -589,7 +581,7 @@ extern "C" void mdie_aux_destroy(void* aux) {
 
 extern "C" int mdie_cdan_forward(const mdie_cdan_fwd_desc* d, void* stream) {
   MDIE_REQUIRE(d != nullptr, "mdie_cdan_forward: null descriptor");
-  MDIE_REQUIRE(d->dtype == MDIE_F32 || d->dtype == MDIE_BF16, "mdie_cdan_forward: bad dtype %d", d->dtype);
+  MDIE_REQUIRE(dtype_valid(d->dtype), "mdie_cdan_forward: bad dtype %d", d->dtype);
   MDIE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "mdie_cdan_forward: empty batch %dx%dx%d", d->B, d->H, d->W);
   MDIE_REQUIRE(d->H % 8 == 0 && d->W % 8 == 0,
                "mdie_cdan_forward: H, W must be multiples of 8 (three 2x2 pools + three x2 upsamples with skip adds), got %dx%d", d->H, d->W);

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_nchw3_kernel(int B,
     auto tap = [](const T* q, float (&t)[4]) {
       if constexpr (sizeof(T) == 2) {
         const uint2 u = *reinterpret_cast<const uint2*>(q);
-        t[0] = bf_lo(u.x); t[1] = bf_hi(u.x); t[2] = bf_lo(u.y); t[3] = bf_hi(u.y);
+        t[0] = Half<T>::lo(u.x); t[1] = Half<T>::hi(u.x); t[2] = Half<T>::lo(u.y); t[3] = Half<T>::hi(u.y);
       } else {
         const float4 u = *reinterpret_cast<const float4*>(q);
         t[0] = u.x; t[1] = u.y; t[2] = u.z; t[3] = u.w;
@@ -244,7 +244,7 @@ static int to_nchw(int B, int Creal, int Cst, int H, int W, const void* in, floa
 }
 
 static int check_layout(const char* who, int dtype, int B, int C, int H, int W, const void* a, const void* b) {
-  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "%s: bad dtype %d", who, dtype);
+  MDIE_REQUIRE(dtype_valid(dtype), "%s: bad dtype %d", who, dtype);
   MDIE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "%s: empty extent", who);
   MDIE_REQUIRE(a && b, "%s: null pointer", who);
   return MDIE_OK;
@@ -262,14 +262,10 @@ extern "C" int mdie_upsample2x_add(int dtype, int B, int H, int W, int C, const 
                "mdie_upsample2x_add: channels/strides must be multiples of 16");
   MDIE_REQUIRE((((uintptr_t)lo | (uintptr_t)skip | (uintptr_t)out) & 15) == 0, "mdie_upsample2x_add: alignment");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const size_t total = (size_t)B * 4 * H * W * (C / (dtype == MDIE_F32 ? 4 : 8));
+  const size_t total = (size_t)B * 4 * H * W * (C / dtype_vec(dtype));
   TimedLaunch tl(MDIE_K_UPSAMPLE);
-  if (dtype == MDIE_F32)
-    hipLaunchKernelGGL((upsample2x_add_kernel<float>), dim3(grid_for(total)), dim3(RS_THREADS), 0, s, B, H, W, C, (const char*)lo, lo_stride,
-                       (const char*)skip, skip_stride, (char*)out, out_stride);
-  else
-    hipLaunchKernelGGL((upsample2x_add_kernel<mdie::bf16>), dim3(grid_for(total)), dim3(RS_THREADS), 0, s, B, H, W, C, (const char*)lo,
-                       lo_stride, (const char*)skip, skip_stride, (char*)out, out_stride);
+  MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((upsample2x_add_kernel<T>), dim3(grid_for(total)), dim3(RS_THREADS), 0, s, B, H, W, C, (const char*)lo, lo_stride,
+                       (const char*)skip, skip_stride, (char*)out, out_stride));
   MDIE_LAUNCH_CHECK("mdie_upsample2x_add");
   return MDIE_OK;
 }
@@ -285,17 +281,13 @@ extern "C" int mdie_upsample2x_add_pool(int dtype, int B, int H, int W, int C, c
                "mdie_upsample2x_add_pool: C must be a power of two <= 512, strides multiples of 16");
   MDIE_REQUIRE((((uintptr_t)lo | (uintptr_t)skip | (uintptr_t)out) & 15) == 0, "mdie_upsample2x_add_pool: alignment");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int vec = dtype == MDIE_F32 ? 4 : 8;
+  const int vec = dtype_vec(dtype);
   const int rows = RS_THREADS / (C / vec);
   const size_t lds = (size_t)2 * rows * C * sizeof(float);
   TimedLaunch tl(MDIE_K_UPSAMPLE);
   const dim3 grid(pool_slabs, B);
-  if (dtype == MDIE_F32)
-    hipLaunchKernelGGL((upsample2x_add_pool_kernel<float>), grid, dim3(RS_THREADS), lds, s, H, W, C, (const char*)lo, lo_stride, (const char*)skip,
-                       skip_stride, (char*)out, out_stride, pool_partial);
-  else
-    hipLaunchKernelGGL((upsample2x_add_pool_kernel<mdie::bf16>), grid, dim3(RS_THREADS), lds, s, H, W, C, (const char*)lo, lo_stride,
-                       (const char*)skip, skip_stride, (char*)out, out_stride, pool_partial);
+  MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((upsample2x_add_pool_kernel<T>), grid, dim3(RS_THREADS), lds, s, H, W, C, (const char*)lo, lo_stride, (const char*)skip,
+                       skip_stride, (char*)out, out_stride, pool_partial));
   MDIE_LAUNCH_CHECK("mdie_upsample2x_add_pool");
   return MDIE_OK;
 }
@@ -306,20 +298,14 @@ extern "C" int mdie_upsample2x_add_nchw3(int dtype, int B, int H, int W, const v
   MDIE_REQUIRE(x_nchw != nullptr && lo_stride >= 4 && lo_stride % 4 == 0 && ((uintptr_t)lo & 15) == 0,
                "mdie_upsample2x_add_nchw3: null x, or lo not 16-byte aligned with a pixel stride that is a multiple of 4 channels (%d)", lo_stride);
   MDIE_REQUIRE(((uintptr_t)out & 15) == 0, "mdie_upsample2x_add_nchw3: alignment");
-  const int vec = dtype == MDIE_F32 ? 4 : 8;
+  const int vec = dtype_vec(dtype);
   MDIE_REQUIRE(out_channels == 16 || out_channels == vec, "mdie_upsample2x_add_nchw3: out_channels %d (16 or %d)", out_channels, vec);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int grid = grid_for((size_t)B * 4 * H * W);
   TimedLaunch tl(MDIE_K_UPSAMPLE);
-  if (dtype == MDIE_F32) {
-    if (out_channels == 16) hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<float, 16>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const float*)lo, lo_stride, x_nchw, (float*)out);
-    else hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<float, 4>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const float*)lo, lo_stride, x_nchw, (float*)out);
-  } else {
-    if (out_channels == 16)
-      hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<mdie::bf16, 16>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const mdie::bf16*)lo, lo_stride, x_nchw, (mdie::bf16*)out);
-    else
-      hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<mdie::bf16, 8>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const mdie::bf16*)lo, lo_stride, x_nchw, (mdie::bf16*)out);
-  }
+  MDIE_SWITCH_T(dtype,
+    if (out_channels == 16) hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<T, 16>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const T*)lo, lo_stride, x_nchw, (T*)out);
+    else hipLaunchKernelGGL((upsample2x_add_nchw3_kernel<T, Traits<T>::VEC>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, (const T*)lo, lo_stride, x_nchw, (T*)out));
   MDIE_LAUNCH_CHECK("mdie_upsample2x_add_nchw3");
   return MDIE_OK;
 }
@@ -327,25 +313,24 @@ extern "C" int mdie_upsample2x_add_nchw3(int dtype, int B, int H, int W, const v
 extern "C" int mdie_nchw_to_nhwc(int dtype, int B, int C, int H, int W, const float* x, void* out, void* stream) {
   if (int e = check_layout("mdie_nchw_to_nhwc", dtype, B, C, H, W, x, out)) return e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return dtype == MDIE_F32 ? to_nhwc<float>(B, C, C, H, W, x, out, s) : to_nhwc<mdie::bf16>(B, C, C, H, W, x, out, s);
+  MDIE_SWITCH_T(dtype, return to_nhwc<T>(B, C, C, H, W, x, out, s));
 }
 extern "C" int mdie_nhwc_to_nchw(int dtype, int B, int C, int H, int W, const void* in, float* y, void* stream) {
   if (int e = check_layout("mdie_nhwc_to_nchw", dtype, B, C, H, W, in, y)) return e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return dtype == MDIE_F32 ? to_nchw<float>(B, C, C, H, W, in, y, s) : to_nchw<mdie::bf16>(B, C, C, H, W, in, y, s);
+  MDIE_SWITCH_T(dtype, return to_nchw<T>(B, C, C, H, W, in, y, s));
 }
 extern "C" int mdie_nchw3_to_nhwc16(int dtype, int B, int H, int W, const float* x, void* out, void* stream) {
   if (int e = check_layout("mdie_nchw3_to_nhwc16", dtype, B, 3, H, W, x, out)) return e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   TimedLaunch tl(MDIE_K_LAYOUT);
   const int grid = grid_for((size_t)B * H * W);
-  if (dtype == MDIE_F32) hipLaunchKernelGGL((nchw3_to_nhwc16_kernel<float>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, x, reinterpret_cast<float*>(out));
-  else hipLaunchKernelGGL((nchw3_to_nhwc16_kernel<mdie::bf16>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, x, reinterpret_cast<mdie::bf16*>(out));
+  MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((nchw3_to_nhwc16_kernel<T>), dim3(grid), dim3(RS_THREADS), 0, s, B, H, W, x, reinterpret_cast<T*>(out)));
   MDIE_LAUNCH_CHECK("mdie_nchw3_to_nhwc16");
   return MDIE_OK;
 }
 extern "C" int mdie_nhwc16_to_nchw3(int dtype, int B, int H, int W, const void* in, float* y, void* stream) {
   if (int e = check_layout("mdie_nhwc16_to_nchw3", dtype, B, 3, H, W, in, y)) return e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return dtype == MDIE_F32 ? to_nchw<float>(B, 3, 16, H, W, in, y, s) : to_nchw<mdie::bf16>(B, 3, 16, H, W, in, y, s);
+  MDIE_SWITCH_T(dtype, return to_nchw<T>(B, 3, 16, H, W, in, y, s));
 }

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(RT_THREADS) void avgpool_heads_kernel(int HW, int C
 using namespace mdie;
 
 static int rt_check(const char* what, int dtype, int B, int H, int W, int C, const void* in, const void* out, int in_stride, int out_stride) {
-  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "%s: bad dtype %d", what, dtype);
+  MDIE_REQUIRE(dtype_valid(dtype), "%s: bad dtype %d", what, dtype);
   MDIE_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0, "%s: bad extent %dx%dx%dx%d", what, B, H, W, C);
   MDIE_REQUIRE(in && out && in_stride >= C && out_stride >= C && in_stride % 4 == 0 && out_stride % 4 == 0, "%s: null pointer / stride", what);
   MDIE_REQUIRE((((uintptr_t)in | (uintptr_t)out) & 15) == 0, "%s: alignment", what);
@@ -127,20 +127,18 @@ static int rt_check(const char* what, int dtype, int B, int H, int W, int C, con
 extern "C" int mdie_maxpool3x3s2(int dtype, int B, int H, int W, int C, const void* in, int in_stride, void* out, int out_stride, void* stream) {
   if (int e = rt_check("mdie_maxpool3x3s2", dtype, B, H, W, C, in, out, in_stride, out_stride)) return e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / (dtype == MDIE_F32 ? 4 : 8));
-  if (dtype == MDIE_F32) hipLaunchKernelGGL((maxpool3x3s2_kernel<float>), dim3(rt_grid(total)), dim3(RT_THREADS), 0, s, B, H, W, C, (const char*)in, in_stride, (char*)out, out_stride);
-  else hipLaunchKernelGGL((maxpool3x3s2_kernel<mdie::bf16>), dim3(rt_grid(total)), dim3(RT_THREADS), 0, s, B, H, W, C, (const char*)in, in_stride, (char*)out, out_stride);
+  const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / dtype_vec(dtype));
+  MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((maxpool3x3s2_kernel<T>), dim3(rt_grid(total)), dim3(RT_THREADS), 0, s, B, H, W, C, (const char*)in, in_stride, (char*)out, out_stride));
   MDIE_LAUNCH_CHECK("mdie_maxpool3x3s2");
   return MDIE_OK;
 }
 
 extern "C" int mdie_relu_inplace(int dtype, long npix, int C, void* x, int stride, void* stream) {
-  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_relu_inplace: bad dtype %d", dtype);
+  MDIE_REQUIRE(dtype_valid(dtype), "mdie_relu_inplace: bad dtype %d", dtype);
   MDIE_REQUIRE(npix > 0 && C > 0 && C % 16 == 0 && x && stride >= C && ((uintptr_t)x & 15) == 0 && stride % 4 == 0, "mdie_relu_inplace: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const size_t total = (size_t)npix * (C / (dtype == MDIE_F32 ? 4 : 8));
-  if (dtype == MDIE_F32) hipLaunchKernelGGL((relu_inplace_kernel<float>), dim3(rt_grid(total)), dim3(RT_THREADS), 0, s, (size_t)npix, C, (char*)x, stride);
-  else hipLaunchKernelGGL((relu_inplace_kernel<mdie::bf16>), dim3(rt_grid(total)), dim3(RT_THREADS), 0, s, (size_t)npix, C, (char*)x, stride);
+  const size_t total = (size_t)npix * (C / dtype_vec(dtype));
+  MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((relu_inplace_kernel<T>), dim3(rt_grid(total)), dim3(RT_THREADS), 0, s, (size_t)npix, C, (char*)x, stride));
   MDIE_LAUNCH_CHECK("mdie_relu_inplace");
   return MDIE_OK;
 }
@@ -159,16 +157,12 @@ extern "C" int mdie_subsample2(int dtype, int B, int H, int W, int C, const void
 
 extern "C" int mdie_avgpool_heads(int dtype, int B, int H, int W, int C, const void* x, int stride, const float* w_cls, const float* b_cls,
                                   const float* w_sev, const float* b_sev, int ncls, float* feat, float* prob_cls, float* sev, void* stream) {
-  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_avgpool_heads: bad dtype %d", dtype);
+  MDIE_REQUIRE(dtype_valid(dtype), "mdie_avgpool_heads: bad dtype %d", dtype);
   MDIE_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C <= 8192 && stride >= C, "mdie_avgpool_heads: bad extent");
   MDIE_REQUIRE(x && w_cls && b_cls && w_sev && b_sev && prob_cls && sev && ncls > 0, "mdie_avgpool_heads: null pointer");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == MDIE_F32)
-    hipLaunchKernelGGL((avgpool_heads_kernel<float>), dim3(B), dim3(RT_THREADS), (size_t)C * 4, s, H * W, C, (const float*)x, stride, w_cls, b_cls, w_sev, b_sev, ncls,
-                       feat, prob_cls, sev);
-  else
-    hipLaunchKernelGGL((avgpool_heads_kernel<mdie::bf16>), dim3(B), dim3(RT_THREADS), (size_t)C * 4, s, H * W, C, (const mdie::bf16*)x, stride, w_cls, b_cls, w_sev,
-                       b_sev, ncls, feat, prob_cls, sev);
+  MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((avgpool_heads_kernel<T>), dim3(B), dim3(RT_THREADS), (size_t)C * 4, s, H * W, C, (const T*)x, stride, w_cls, b_cls, w_sev, b_sev, ncls,
+                       feat, prob_cls, sev));
   MDIE_LAUNCH_CHECK("mdie_avgpool_heads");
   return MDIE_OK;
 }

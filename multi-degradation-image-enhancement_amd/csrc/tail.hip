@@ -83,6 +83,9 @@ template <typename T> __device__ __forceinline__ f32x4 tl_mma(const uint4& w, co
 template <> __device__ __forceinline__ f32x4 tl_mma<bf16>(const uint4& w, const uint4& x, f32x4 acc) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
 }
+template <> __device__ __forceinline__ f32x4 tl_mma<f16>(const uint4& w, const uint4& x, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+}
 template <> __device__ __forceinline__ f32x4 tl_mma<float>(const uint4& w, const uint4& x, f32x4 acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
@@ -277,7 +280,7 @@ __device__ __forceinline__ void tail_layer(const TailArgs& a, char* smem, int im
         if (valid[u]) {
           T* dst = reinterpret_cast<T*>(smem + LD::raw(L)) + pcv[u] * 16 + lq * 4;
           if constexpr (E == 4) *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
-          else *reinterpret_cast<uint2*>(dst) = make_uint2(bf_pack(v0, v1), bf_pack(v2, v3));
+          else *reinterpret_cast<uint2*>(dst) = make_uint2(Half<T>::pack(v0, v1), Half<T>::pack(v2, v3));
         }
       } else {
         const int gy = ty0 + oyv[u], gx = tx0 + oxv[u];
@@ -347,7 +350,7 @@ struct TailBlobLayout {
   size_t pre_scale[5], pre_shift[5], bias[5], w[5], total;
 };
 static TailBlobLayout tail_layout(int dtype) {
-  const int esz = dtype == MDIE_F32 ? 4 : 2;
+  const int esz = (int)dtype_size(dtype);
   TailBlobLayout L{};
   size_t off = 0;
   for (int l = 1; l <= 5; ++l) {
@@ -360,23 +363,15 @@ static TailBlobLayout tail_layout(int dtype) {
   return L;
 }
 
-static uint16_t tl_bf16(float f) {
-  uint32_t u;
-  memcpy(&u, &f, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-
 // w: [cout][cin][ks][ks] fp32 (nn.Conv2d), cin = 3 + 16*ng
 static void tail_pack_layer(int dtype, int l, const float* w, int cout, char* dst) {
-  const int esz = dtype == MDIE_F32 ? 4 : 2;
+  const int esz = (int)dtype_size(dtype);
   const int ng = tl_ng(l), ks = tl_ks(l), cin = tl_cin(l), nh = tl_nh(l);
   const int bs = tl_base_steps(esz);
   memset(dst, 0, (size_t)tl_steps(l, esz) * 1024);
   auto put = [&](int step, int o, int k, float v) {  // element k of row o in a 1 KiB step
     if (esz == 4) reinterpret_cast<float*>(dst + (size_t)step * 1024)[o * 16 + k] = v;
-    else reinterpret_cast<uint16_t*>(dst + (size_t)step * 1024)[o * 32 + k] = tl_bf16(v);
+    else reinterpret_cast<uint16_t*>(dst + (size_t)step * 1024)[o * 32 + k] = f32_to_half_bits(dtype, v);
   };
   const int kper = esz == 4 ? 16 : 32;
   for (int o = 0; o < cout; ++o) {
@@ -401,12 +396,12 @@ static void tail_pack_layer(int dtype, int l, const float* w, int cout, char* ds
 using namespace mdie;
 
 extern "C" size_t mdie_tail_param_bytes(int dtype) {
-  if (dtype != MDIE_F32 && dtype != MDIE_BF16) return 0;
+  if (!dtype_valid(dtype)) return 0;
   return tail_layout(dtype).total;
 }
 
 extern "C" int mdie_tail_pack_params(int dtype, const mdie_tensor* tensors, int n, const char* prefix, void* dst, size_t dst_bytes) {
-  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_tail_pack_params: bad dtype %d", dtype);
+  MDIE_REQUIRE(dtype_valid(dtype), "mdie_tail_pack_params: bad dtype %d", dtype);
   MDIE_REQUIRE(tensors && n > 0 && dst && prefix, "mdie_tail_pack_params: null argument");
   const TailBlobLayout L = tail_layout(dtype);
   if (dst_bytes < L.total) { set_error("mdie_tail_pack_params: %zu < %zu bytes", dst_bytes, L.total); return MDIE_ENOSPC; }
@@ -446,7 +441,7 @@ extern "C" int mdie_tail_pack_params(int dtype, const mdie_tensor* tensors, int 
 
 extern "C" int mdie_tail_fwd(const mdie_tail_desc* d, void* stream) {
   MDIE_REQUIRE(d != nullptr, "mdie_tail_fwd: null descriptor");
-  MDIE_REQUIRE(d->dtype == MDIE_F32 || d->dtype == MDIE_BF16, "mdie_tail_fwd: bad dtype %d", d->dtype);
+  MDIE_REQUIRE(dtype_valid(d->dtype), "mdie_tail_fwd: bad dtype %d", d->dtype);
   MDIE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "mdie_tail_fwd: empty extent");
   MDIE_REQUIRE(d->x && d->y && d->params, "mdie_tail_fwd: null pointer");
   MDIE_REQUIRE(!d->lo || (d->H % 2 == 0 && d->W % 2 == 0 && d->lo_stride >= 3), "mdie_tail_fwd: lo needs even H, W and >= 3 channels");
@@ -466,15 +461,10 @@ extern "C" int mdie_tail_fwd(const mdie_tail_desc* d, void* stream) {
   const int grid = cdiv(d->W, TL_TW) * cdiv(d->H, TL_TH) * d->B;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   TimedLaunch tl(MDIE_K_TAIL);
-  if (d->dtype == MDIE_F32) {
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, TailLds<float>::TOTAL); once = true; }
-    hipLaunchKernelGGL((tail_kernel<float>), dim3(grid), dim3(TL_THREADS), TailLds<float>::TOTAL, s, a);
-  } else {
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<mdie::bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, TailLds<mdie::bf16>::TOTAL); once = true; }
-    hipLaunchKernelGGL((tail_kernel<mdie::bf16>), dim3(grid), dim3(TL_THREADS), TailLds<mdie::bf16>::TOTAL, s, a);
-  }
+  MDIE_SWITCH_T(d->dtype,
+    static LdsOptIn opt;
+    if (!opt.ensure(reinterpret_cast<const void*>(&tail_kernel<T>), TailLds<T>::TOTAL)) return MDIE_ELAUNCH;
+    hipLaunchKernelGGL((tail_kernel<T>), dim3(grid), dim3(TL_THREADS), TailLds<T>::TOTAL, s, a));
   MDIE_LAUNCH_CHECK("mdie_tail_fwd");
   return MDIE_OK;
 }

@@ -143,8 +143,16 @@ __device__ __forceinline__ v4s lds_tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p));
 }
 
-// waves are arranged WC x WO; each owns CSW x OSW 16x16 subtiles of every tap
-template <int NTAP, int CSW, int OSW, int WC, int WO, bool PRE>
+template <typename T> __device__ __forceinline__ f32x4 mma_tr(const v8s& a, const v8s& b, f32x4 c);
+template <> __device__ __forceinline__ f32x4 mma_tr<bf16>(const v8s& a, const v8s& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mma_tr<f16>(const v8s& a, const v8s& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// waves are arranged WC x WO; each owns CSW x OSW 16x16 subtiles of every tap; T = bf16 or f16 (same layouts, other MFMA)
+template <typename T, int NTAP, int CSW, int OSW, int WC, int WO, bool PRE>
 __global__ __launch_bounds__(TR_THREADS, 2) void wgrad_tile_kernel(const WgradTileArgs a) {
   using G = WgGeom<NTAP>;
   constexpr int KS = NTAP == 9 ? 3 : 1;
@@ -241,10 +249,10 @@ __global__ __launch_bounds__(TR_THREADS, 2) void wgrad_tile_kernel(const WgradTi
         for (int j = 0; j < X_BATCH; ++j) {
           if (has_pre && oks[j]) {   // pre-activation BN + ReLU of the dense layers; the zero padding stays zero
             float f[8];
-            Vec16<bf16>::unpack(v[j], f);
+            Vec16<T>::unpack(v[j], f);
 #pragma unroll
             for (int i = 0; i < 8; ++i) f[i] = fmaxf(fmaf(f[i], psc[i], psh[i]), 0.f);
-            v[j] = Vec16<bf16>::pack(f);
+            v[j] = Vec16<T>::pack(f);
           }
           if (dsts[j] >= 0) *reinterpret_cast<uint4*>(lds_x + dsts[j]) = v[j];
         }
@@ -292,8 +300,7 @@ __global__ __launch_bounds__(TR_THREADS, 2) void wgrad_tile_kernel(const WgradTi
             const v8s af = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int os = 0; os < OSW; ++os)
-              acc[t][cs][os] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf[os]),
-                                                                       acc[t][cs][os], 0, 0, 0);
+              acc[t][cs][os] = mma_tr<T>(af, bf[os], acc[t][cs][os]);
           }
         }
       }
@@ -509,13 +516,13 @@ static WgTilePlan wgrad_tile_plan(int B, int H, int W, int cin_st, int cout_st) 
   return p;
 }
 
-template <int NTAP, int CSW, int OSW, int WC, int WO, bool PRE>
+template <typename T, int NTAP, int CSW, int OSW, int WC, int WO, bool PRE>
 static void launch_wgrad_tile_t(const WgradTileArgs& a, const WgTilePlan& p, hipStream_t s) {
   using G = WgGeom<NTAP>;
   const size_t lds = (size_t)CSW * WC * G::XPLANE + (size_t)OSW * WO * G::YPLANE;
-  auto kern = wgrad_tile_kernel<NTAP, CSW, OSW, WC, WO, PRE>;
-  static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-  if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  auto kern = wgrad_tile_kernel<T, NTAP, CSW, OSW, WC, WO, PRE>;
+  static LdsOptIn opt;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
+  if (!opt.ensure(reinterpret_cast<const void*>(kern), (int)lds)) return;   // (the caller's MDIE_LAUNCH_CHECK reports it)
   hipLaunchKernelGGL(kern, dim3(p.c_tiles * p.o_tiles, p.splits), dim3(TR_THREADS), lds, s, a);
 }
 
@@ -526,24 +533,28 @@ static void launch_wgrad_tile_f32(const WgradTileArgs& a, const WgTilePlan& p, h
   const dim3 grid(p.c_tiles * p.o_tiles, p.splits);
   if (a.pre_scale) {
     auto kern = wgrad_tile_f32_kernel<NTAP, CSW, OSW, WC, WO, true>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    static LdsOptIn opt;
+    if (!opt.ensure(reinterpret_cast<const void*>(kern), (int)lds)) return;
     hipLaunchKernelGGL(kern, grid, dim3(TR_THREADS), lds, s, a);
   } else {
     auto kern = wgrad_tile_f32_kernel<NTAP, CSW, OSW, WC, WO, false>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    static LdsOptIn opt;
+    if (!opt.ensure(reinterpret_cast<const void*>(kern), (int)lds)) return;
     hipLaunchKernelGGL(kern, grid, dim3(TR_THREADS), lds, s, a);
   }
 }
 
 // the pre-activation prologue is a separate instantiation: its 16 extra live registers would push the
 // 9-tap 64x64 configuration (never used with a prologue by this network: dense 3x3 layers have 16 outputs) into spills
-template <int NTAP, int CSW, int OSW, int WC, int WO>
-static void launch_wgrad_tile(const WgradTileArgs& a, const WgTilePlan& p, hipStream_t s) {
-  if (a.pre_scale) launch_wgrad_tile_t<NTAP, CSW, OSW, WC, WO, true>(a, p, s);
-  else launch_wgrad_tile_t<NTAP, CSW, OSW, WC, WO, false>(a, p, s);
+template <typename T, int NTAP, int CSW, int OSW, int WC, int WO>
+static void launch_wgrad_tile_h(const WgradTileArgs& a, const WgTilePlan& p, hipStream_t s) {
+  if (a.pre_scale) launch_wgrad_tile_t<T, NTAP, CSW, OSW, WC, WO, true>(a, p, s);
+  else launch_wgrad_tile_t<T, NTAP, CSW, OSW, WC, WO, false>(a, p, s);
 }
+template <int NTAP, int CSW, int OSW, int WC, int WO>
+static void launch_wgrad_tile(const WgradTileArgs& a, const WgTilePlan& p, hipStream_t s) { launch_wgrad_tile_h<bf16, NTAP, CSW, OSW, WC, WO>(a, p, s); }
+template <int NTAP, int CSW, int OSW, int WC, int WO>
+static void launch_wgrad_tile_f16(const WgradTileArgs& a, const WgTilePlan& p, hipStream_t s) { launch_wgrad_tile_h<f16, NTAP, CSW, OSW, WC, WO>(a, p, s); }
 
 }  // namespace mdie
 
@@ -551,21 +562,17 @@ using namespace mdie;
 
 extern "C" int mdie_pack_conv_weight_dev(int dtype, int ksize, int transposed, const float* w, int cout, int cin, int cout_stored,
                                          int cin_stored, int split, int gap, void* dst, void* stream) {
-  MDIE_REQUIRE(dtype == MDIE_F32 || dtype == MDIE_BF16, "mdie_pack_conv_weight_dev: bad dtype %d", dtype);
+  MDIE_REQUIRE(dtype_valid(dtype), "mdie_pack_conv_weight_dev: bad dtype %d", dtype);
   MDIE_REQUIRE(ksize == 1 || ksize == 3, "mdie_pack_conv_weight_dev: ksize %d", ksize);
   MDIE_REQUIRE(w && dst && cout > 0 && cin > 0, "mdie_pack_conv_weight_dev: null/empty");
   MDIE_REQUIRE(cout_stored >= cout && cout_stored % 16 == 0, "mdie_pack_conv_weight_dev: cout_stored %d", cout_stored);
   MDIE_REQUIRE(cin_stored % 16 == 0 && cin_stored >= cin + (split < cin ? gap : 0) && gap >= 0 && split >= 0,
                "mdie_pack_conv_weight_dev: cin_stored %d too small for cin %d split %d gap %d", cin_stored, cin, split, gap);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int kc = dtype == MDIE_F32 ? 16 : 32;
+  const int kc = dtype_kc(dtype);
   const size_t total = (size_t)cdiv(cin_stored, kc) * 4 * ksize * ksize * cout_stored * (kc / 4);
-  if (dtype == MDIE_F32)
-    hipLaunchKernelGGL((pack_weight_kernel<float>), dim3(tr_grid(total)), dim3(TR_THREADS), 0, s, ksize, transposed, w, cout, cin, cout_stored, cin_stored,
-                       split, gap, reinterpret_cast<float*>(dst));
-  else
-    hipLaunchKernelGGL((pack_weight_kernel<mdie::bf16>), dim3(tr_grid(total)), dim3(TR_THREADS), 0, s, ksize, transposed, w, cout, cin, cout_stored,
-                       cin_stored, split, gap, reinterpret_cast<mdie::bf16*>(dst));
+  MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(tr_grid(total)), dim3(TR_THREADS), 0, s, ksize, transposed, w, cout, cin, cout_stored, cin_stored,
+                       split, gap, reinterpret_cast<T*>(dst)));
   MDIE_LAUNCH_CHECK("mdie_pack_conv_weight_dev");
   return MDIE_OK;
 }
@@ -577,7 +584,7 @@ extern "C" size_t mdie_conv_wgrad_workspace_bytes(int B, int H, int W, int ksize
 
 extern "C" int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream) {
   MDIE_REQUIRE(d != nullptr, "mdie_conv_wgrad: null descriptor");
-  MDIE_REQUIRE(d->dtype == MDIE_F32 || d->dtype == MDIE_BF16, "mdie_conv_wgrad: bad dtype %d", d->dtype);
+  MDIE_REQUIRE(dtype_valid(d->dtype), "mdie_conv_wgrad: bad dtype %d", d->dtype);
   MDIE_REQUIRE(d->ksize == 3 || d->ksize == 1, "mdie_conv_wgrad: ksize %d", d->ksize);
   MDIE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "mdie_conv_wgrad: empty extent");
   MDIE_REQUIRE(d->nseg >= 1 && d->nseg <= MDIE_MAX_SEG, "mdie_conv_wgrad: nseg %d", d->nseg);
@@ -617,6 +624,7 @@ extern "C" int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream) {
     }                                                                  \
   } while (0)
   if (d->dtype == MDIE_F32) MDIE_WG(launch_wgrad_tile_f32);
+  else if (d->dtype == MDIE_F16) MDIE_WG(launch_wgrad_tile_f16);
   else MDIE_WG(launch_wgrad_tile);
 #undef MDIE_WG
   MDIE_LAUNCH_CHECK("mdie_conv_wgrad");

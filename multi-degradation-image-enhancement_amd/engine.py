@@ -11,15 +11,16 @@ import torch
 
 from . import lib as L
 
-DTYPES = {"fp32": L.F32, "f32": L.F32, "float32": L.F32, "bf16": L.BF16, "bfloat16": L.BF16}
-TORCH_DTYPE = {L.F32: torch.float32, L.BF16: torch.bfloat16}
+DTYPES = {"fp32": L.F32, "f32": L.F32, "float32": L.F32, "bf16": L.BF16, "bfloat16": L.BF16,
+          "fp16": L.F16, "f16": L.F16, "float16": L.F16, "half": L.F16}
+TORCH_DTYPE = {L.F32: torch.float32, L.BF16: torch.bfloat16, L.F16: torch.float16}
 
 
 def dtype_id(name):
     try:
         return DTYPES[str(name).lower()]
     except KeyError:
-        raise ValueError(f"unknown precision {name!r}; use 'fp32' or 'bf16'") from None
+        raise ValueError(f"unknown precision {name!r}; use 'fp32', 'bf16' or 'fp16'") from None
 
 
 def _stream_ptr(device):

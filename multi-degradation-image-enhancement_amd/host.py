@@ -334,8 +334,9 @@ class Model:
         print(f"Training completed in {t // 60:.0f}m {t % 60:.0f}s")
 
     def train_step(self):
-        """models/model.py:138-227: Adam(lr), loss pipeline, best-on-train-loss checkpoint.  No GradScaler: the
-        HIP convolutions accumulate in fp32 and activations are fp32 or bf16 (no fp16 overflow to guard)."""
+        """models/model.py:138-227: Adam(lr), loss pipeline, best-on-train-loss checkpoint.  Under fp16 storage
+        (MDIE_PRECISION=fp16, the reference's own autocast dtype) the loss goes through torch's GradScaler exactly as at
+        models/model.py:31,164-166 -- activation GRADIENTS are stored in fp16 and would underflow unscaled; fp32 / bf16 need none."""
         import torch.distributed as dist
         from . import train as T
         tr = self.config["train"]
@@ -344,6 +345,7 @@ class Model:
         if len(losses) == 0:
             raise ValueError("training needs at least one usable loss term")
         opt = torch.optim.Adam(self.network.parameters(), lr=lr)
+        scaler = torch.amp.GradScaler("cuda", enabled=str(getattr(self.network, "precision", "fp32")).lower() in ("fp16", "f16", "float16", "half"))
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if distributed:
             # identical replicas: rank 0's parameters and buffers (the seed already makes them equal; this makes it certain)
@@ -363,10 +365,11 @@ class Model:
                 opt.zero_grad(set_to_none=True)
                 out = self.network(x)
                 total, values = losses(out, y)
-                total.backward()
+                scaler.scale(total).backward()
                 if buckets is not None:
                     buckets.finish()     # averaged gradients (RCCL all-reduce launched from the grad hooks during backward)
-                opt.step()
+                scaler.step(opt)         # (unscales, skips the step on inf/nan; plain opt.step() when disabled)
+                scaler.update()
                 vals = values.cpu().tolist()  # one sync per step
                 for k, v in zip(losses.names + ["total"], vals):
                     sums[k] = sums.get(k, 0.0) + v

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Timing of the BASELINE.json configurations that are not the bench line (bench.py measures configs[1]):
   routed   configs[3]: 9 task weight sets, B=32 x 256x256 per GPU, images pre-labelled by a stub router
-  large    configs[4]: 1024x1024, batch 1 and 4, bf16
-  python tools/bench_configs.py [routed|large] [bf16|fp32]"""
+  large    configs[4]: config/pixelation_hard.json 1024x1024 fp16 (its stated dtype), batch 1 and 4
+  python tools/bench_configs.py [routed|large] [bf16|fp16|fp32]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,7 @@ from mdie_amd import engine as E
 from mdie_amd import synthetic as P
 
 what = sys.argv[1] if len(sys.argv) > 1 else "routed"
-prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+prec = sys.argv[2] if len(sys.argv) > 2 else ("fp16" if what == "large" else "bf16")
 
 
 def timed(fn, n=20, warm=3):
@@ -49,5 +49,5 @@ else:
         x, _ = P.lowlight_batch(2, B, 1024, 1024)
         x = x.cuda()
         dt = timed(lambda: eng.forward(x), n=10)
-        gb = B * 16 * (104.8e6 if prec == "bf16" else 209.6e6) / 1e9
+        gb = B * 16 * (209.6e6 if prec == "fp32" else 104.8e6) / 1e9
         print(f"large[{prec}] B={B} 1024x1024: {dt*1e3:.2f} ms = {B/dt:.1f} img/s, algorithmic {gb/dt/1e3:.2f} TB/s")
