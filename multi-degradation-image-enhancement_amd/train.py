@@ -587,6 +587,9 @@ class GradBuckets:
         target = max(1, -(-total // n_buckets))
         self.buckets, cur, size = [], [], 0
         for p in params:
+            if cur and size + p.numel() > 1.25 * target:   # a large tensor (decoder.conv1, encoder.conv4: 1.18 M each) starts its own
+                self.buckets.append(cur)                   # bucket: the small ones before it are exchanged as soon as they are ready
+                cur, size = [], 0
             cur.append(p)
             size += p.numel()
             if size >= target:

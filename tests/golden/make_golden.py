@@ -19,6 +19,14 @@ Files written
                           bilinear x2 + add, maxpool)
   train_step_32.npz       batch-stat BN forward, charbonnier loss, selected gradients,
                           updated running statistics (dropout disabled)
+  e2e_dec_taps.npz        decoder stage outputs (dec1..dec4) of two of the e2e_eval inputs, taken from the reference's
+                          own forward with hooks            [python make_golden.py dectaps]
+  ddp_2shard_32.npz       data-parallel semantics: one batch of 4 split into two shards,
+                          per-shard gradients of the reference's training step (models/model.py:159-164) for 12
+                          parameters -- their mean is what an N=2 gradient all-reduce + /world must reproduce
+                                                                                 [python make_golden.py ddp]
+
+`python make_golden.py` regenerates everything; a section name regenerates only that file.
 """
 import json
 import os
@@ -66,6 +74,76 @@ def load_seeded(m, seed):
 
 def pack_params(sd):
     return {"p:" + k: v.numpy() for k, v in sd.items()}
+
+
+GRAD_KEYS = ("encoder.conv1.conv.weight", "encoder.conv1.bn.weight", "encoder.dense1.layers.1.2.weight",
+             "encoder.dense2.transition_layer.2.weight", "bottleneck.ChannelGate.mlp.1.weight",
+             "bottleneck.SpatialGate.spatial.conv.weight", "decoder.conv1.bias", "decoder.conv3.weight",
+             "decoder.bn4.bias", "decoder.cbam2.ChannelGate.mlp.3.bias",
+             "decoder.final_dense.layers.3.2.weight", "decoder.final_dense.transition_layer.2.weight")
+
+
+def train_mode_reference(sd):
+    """the reference network as Model.train_step runs it (models/model.py:144), Dropout modules left in eval (their
+    RNG cannot be matched bit for bit)"""
+    ref = CDAN()
+    ref.load_state_dict(sd, strict=True)
+    ref.train()
+    for mod in ref.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.eval()
+    return ref
+
+
+def dec_taps():
+    """decoder taps through the reference's OWN forward: `out *= denses[k]` (models/cdan.py:133,141,149) multiplies the
+    CBAM module's output tensor in place, so a forward hook that keeps that tensor (no clone) holds the stage output
+    once the forward has finished; the input of final_dense (:154-155) is taken by a pre-hook."""
+    sd = P.make_state_dict(42)
+    ref = CDAN()
+    ref.load_state_dict(sd, strict=True)
+    ref.eval()
+    arrays = {}
+    for tag in ("1x32x32", "1x40x56"):
+        z = np.load(os.path.join(HERE, f"e2e_eval_{tag}.npz"))
+        x = torch.from_numpy(z["x"])
+        kept, hooks = {}, []
+        for i, name in enumerate(("cbam1", "cbam2", "cbam3")):
+            hooks.append(getattr(ref.decoder, name).register_forward_hook(lambda m, inp, out, k=f"dec{i + 1}": kept.__setitem__(k, out)))
+        hooks.append(ref.decoder.final_dense.register_forward_pre_hook(lambda m, inp: kept.__setitem__("dec4", inp[0])))
+        with torch.no_grad():
+            y = ref(x)
+        for h in hooks:
+            h.remove()
+        assert np.array_equal(np32(y), z["y"]), "the tapped forward must reproduce the committed output bit for bit"
+        for k, v in kept.items():
+            arrays[f"{tag}:{k}"] = np32(v)
+        arrays[f"{tag}:x"] = z["x"]
+    save("e2e_dec_taps.npz", **arrays)
+
+
+def ddp_fixture():
+    """N = 2 data parallel: each rank runs the reference's step (forward, charbonnier loss = mean over ITS shard, backward;
+    models/model.py:159-164) on its half of one batch; the exchanged gradient is the mean over ranks."""
+    sd = P.make_state_dict(42)
+    x, t = P.lowlight_batch(33, 4, 32, 32)
+    shards = [(x[:2], t[:2]), (x[2:], t[2:])]
+    out = {"x": np32(x), "t": np32(t)}
+    per = []
+    for r, (xs, ts) in enumerate(shards):
+        ref = train_mode_reference(sd)            # identical replicas at the start of the step
+        y = ref(xs)
+        loss = torch.sqrt((y - ts) ** 2 + 1e-6).mean()
+        loss.backward()
+        named = dict(ref.named_parameters())
+        per.append({k: named[k].grad.detach().clone() for k in GRAD_KEYS})
+        out[f"loss{r}"] = np.float64(loss.item())
+        out[f"y{r}"] = np32(y)
+        for k in GRAD_KEYS:
+            out[f"g{r}:" + k] = np32(per[r][k])
+        if r == 0:
+            out["norms0"] = np.array(json.dumps({k: float(v.grad.double().norm()) for k, v in named.items()}))
+    save("ddp_2shard_32.npz", **out)      # (the exchanged gradient, (g0 + g1) / 2, is derived by the tests)
 
 
 def main():
@@ -176,11 +254,7 @@ def main():
     loss.backward()
     named = dict(ref.named_parameters())
     grads = {}
-    for k in ("encoder.conv1.conv.weight", "encoder.conv1.bn.weight", "encoder.dense1.layers.1.2.weight",
-              "encoder.dense2.transition_layer.2.weight", "bottleneck.ChannelGate.mlp.1.weight",
-              "bottleneck.SpatialGate.spatial.conv.weight", "decoder.conv1.bias", "decoder.conv3.weight",
-              "decoder.bn4.bias", "decoder.cbam2.ChannelGate.mlp.3.bias",
-              "decoder.final_dense.layers.3.2.weight", "decoder.final_dense.transition_layer.2.weight"):
+    for k in GRAD_KEYS:
         grads["g:" + k] = np32(named[k].grad)
     norms = {k: float(v.grad.double().norm()) for k, v in named.items()}
     stats = {}
@@ -195,4 +269,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "all":
+        main()
+    if what in ("all", "dectaps"):
+        dec_taps()
+    if what in ("all", "ddp"):
+        ddp_fixture()

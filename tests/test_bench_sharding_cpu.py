@@ -112,3 +112,46 @@ def test_driver_shards_the_dataset_under_torchrun_env():
         p.join(60)
         assert p.exitcode == 0
     assert len(res[0]) == len(res[1]) == 5 and sorted(res[0] + res[1]) == list(range(10))
+
+
+def _ddp_fixture_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from mdie_amd.train import GradBuckets
+    from models.cdan import CDAN
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ddp_2shard_32.npz"))
+    net = CDAN()                                  # the 140 parameters of the real network (CPU tensors: only the exchange runs here)
+    named = dict(net.named_parameters())
+    buckets = GradBuckets(net.parameters())       # the production bucketing
+    mine = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"g{rank}:")}
+    # deliver this rank's per-shard reference gradients through autograd, so the post-accumulate hooks fire as in a real backward
+    sum((named[k] * g).sum() for k, g in mine.items()).backward()
+    assert all(torch.equal(named[k].grad, g) for k, g in mine.items())
+    buckets.finish()
+    ok = True
+    for k in mine:
+        mean = (torch.from_numpy(z["g0:" + k]).double() + torch.from_numpy(z["g1:" + k]).double()) / 2
+        ok = ok and torch.allclose(named[k].grad.double(), mean, rtol=0, atol=1e-7 * float(mean.abs().max()) + 1e-12)
+    untouched = [k for k, p in named.items() if k not in mine and p.grad is not None and float(p.grad.abs().max()) != 0.0]
+    q.put((rank, ok, len(buckets.buckets), untouched))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradbuckets_deliver_the_reference_two_shard_mean():
+    """fixture c-4 (tests/golden/ddp_2shard_32.npz, produced by the reference): two ranks hold the reference's per-shard
+    gradients of the real parameter set; after GradBuckets' bucketed all-reduce every rank holds their mean."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_fixture_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, nb, untouched in res:
+        assert ok and nb == 5 and not untouched     # tail..decoder.conv2 | decoder.conv1 | CBAMs, encoder dense blocks | encoder.conv4 | encoder.conv3..1

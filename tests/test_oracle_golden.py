@@ -112,3 +112,22 @@ def test_train_step(golden_dir):
     norms = json.loads(str(z["grad_norms"]))
     for k, n in norms.items():
         assert float(sd[k].grad.double().norm()) == pytest.approx(n, rel=2e-3, abs=1e-6), k  # biases feeding a batch-stat BN have ~0 gradient
+
+
+def test_ddp_two_shard_gradients(golden_dir):
+    """the per-shard training steps of an N=2 data-parallel run (each rank: forward, charbonnier
+    mean over ITS shard, backward -- models/model.py:159-164).  The oracle must reproduce each shard's gradients; their
+    mean is what the gradient exchange delivers (tests/test_bench_sharding_cpu.py, tests/test_gpu_parity.py)."""
+    z = np.load(os.path.join(golden_dir, "ddp_2shard_32.npz"))
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    for r, sl in enumerate((slice(0, 2), slice(2, 4))):
+        sd = {k: v.clone().requires_grad_(v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var")))
+              for k, v in P.make_state_dict(42).items()}
+        y = O.cdan_forward(sd, x[sl], bn_mode="batch", stats_out={})
+        loss = O.charbonnier(y, t[sl])
+        loss.backward()
+        _close(y.detach(), torch.from_numpy(z[f"y{r}"]), 1e-5)
+        assert loss.item() == pytest.approx(float(z[f"loss{r}"]), rel=1e-6)
+        for k in z.files:
+            if k.startswith(f"g{r}:"):
+                _close(sd[k[3:]].grad, torch.from_numpy(z[k]), 2e-4)
