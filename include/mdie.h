@@ -284,11 +284,20 @@ enum { MDIE_TAP_SKIP0 = 0, MDIE_TAP_SKIP1, MDIE_TAP_SKIP2, MDIE_TAP_DENSE0, MDIE
        MDIE_TAP_DENSE2, MDIE_TAP_ENC, MDIE_TAP_BOTT, MDIE_TAP_DEC1, MDIE_TAP_DEC2, MDIE_TAP_DEC3,
        MDIE_TAP_DEC4, MDIE_TAP_COUNT };
 
-/* Side streams for the three encoder DenseBlocks.  dense_k depends only on the pooled block output
+/* Concurrency of the three encoder DenseBlocks.  dense_k depends only on the pooled block output
  * o_k and is first consumed by the decoder (`out *= denses[k]`, models/cdan.py:133,141,149), so the
- * plan forks it onto its own stream right after conv_k and joins before the matching decoder CBAM:
- * the thin cout=16 launches then overlap the MFMA-heavy main chain.  Create/destroy OUTSIDE graph
- * capture; the fork/join events are captured like any other dependency. */
+ * plan runs it beside the main chain from right after conv_k until the matching decoder CBAM:
+ * the thin cout=16 launches then overlap the MFMA-heavy main chain.
+ *   - `stream` NOT capturing: the block goes to a side stream of `aux` (event fork / event join); without `aux`
+ *     everything stays on `stream`.
+ *   - `stream` capturing (hipStreamBeginCapture on it, or on a stream it was forked from -- any depth): the block
+ *     becomes a parallel BRANCH OF THE GRAPH through the stream's capture dependency set
+ *     (hipStreamUpdateCaptureDependencies); `aux` is not used and no stream of the library ever joins the caller's
+ *     capture, so any legal capture pattern of the caller stays legal (two engines on two forked streams, several
+ *     captures in a row, engines destroyed in between: tests/test_gpu_parity.py::test_capture_*).
+ * An mdie_aux belongs to ONE in-flight forward at a time: two forwards that may overlap (different streams) need two
+ * handles and two workspaces.  Create/destroy outside graph capture.  Every fork is joined before
+ * mdie_cdan_forward returns, also on an error return. */
 int mdie_aux_create(void** aux);
 void mdie_aux_destroy(void* aux);
 
@@ -306,11 +315,12 @@ typedef struct {
   void* workspace;  size_t workspace_bytes;
   mdie_tap* taps;
   int flags;                /* MDIE_FWD_* bits */
-  void* aux;                /* mdie_aux_create handle or NULL (everything on `stream`) */
+  void* aux;                /* mdie_aux_create handle or NULL; used only when `stream` is not capturing (see above) */
   float* launch_ms; int* launch_kind; int max_launches; int* n_launches;
 } mdie_cdan_fwd_desc;
 
-enum { MDIE_FWD_FUSED_TAIL = 1 /* run upsample + final_dense + sigmoid as ONE launch (mdie_tail_fwd) instead of 7 */ };
+enum { MDIE_FWD_FUSED_TAIL = 1 /* run upsample + final_dense + sigmoid as ONE launch (mdie_tail_fwd) instead of 7 */,
+       MDIE_FWD_SERIAL = 2     /* keep the encoder DenseBlocks in line with the main chain (no side streams, no graph branches) */ };
 
 enum { MDIE_K_LAYOUT = 0, MDIE_K_CONV3 = 1, MDIE_K_CONV1 = 2, MDIE_K_CBAM_POOL = 3, MDIE_K_CBAM_GATE = 4,
        MDIE_K_CBAM_CHANPOOL = 5, MDIE_K_CBAM_SPATIAL = 6, MDIE_K_UPSAMPLE = 7, MDIE_K_TAIL = 8, MDIE_K_COUNT = 9 };

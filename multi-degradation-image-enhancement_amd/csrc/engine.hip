@@ -460,6 +460,92 @@ static int run_up(const Ctx& c, const Plan& P, int H, int W, const Buf& lo, cons
                                   reinterpret_cast<float*>(c.ws + P.pool_ws), mdie_pool_slabs(2 * H, 2 * W), c.stream);
 }
 
+// Concurrency of the encoder DenseBlocks with the main path, in the two forms a caller's stream can be in:
+//   STREAMS  eager launches: the block is enqueued on a side stream of the caller's mdie_aux (event fork / event join);
+//   GRAPH    `stream` is being captured: NO other stream joins the capture.  The block's launches are captured on `stream`
+//            itself, then the stream's capture dependency set is put back to the fork point
+//            (hipStreamUpdateCaptureDependencies, SET), so what follows is a parallel branch of the graph; join() adds the
+//            block's last node to the dependency set again (ADD).  This is legal on any capturing stream, origin or forked,
+//            and leaves no foreign stream in capture state: round 1 forked its own non-blocking side streams into the
+//            caller's capture, and a capture that reached them through a stream which was itself a fork took the process
+//            down in hipStreamEndCapture once engines (and their side streams) of an earlier capture had been destroyed
+//            (tools/capture_probe.hip reproduces the shapes; profiles/r02b_capture_probe.txt).
+// Every fork is joined exactly once, also when a launch in between fails (the destructor joins what is still open), so an
+// error return never leaves a side stream running ahead of -- or a graph branch dangling from -- the caller's stream.
+struct Branches {
+  enum Mode { SERIAL, STREAMS, GRAPH } mode = SERIAL;
+  hipStream_t stream = nullptr;
+  Aux* aux = nullptr;
+  bool open[3] = {false, false, false};
+  std::vector<hipGraphNode_t> at_fork[3], tail[3];
+
+  static int deps_of(hipStream_t s, std::vector<hipGraphNode_t>& out) {
+    hipStreamCaptureStatus st; unsigned long long id; hipGraph_t g; const hipGraphNode_t* deps = nullptr; size_t n = 0;
+    if (hipStreamGetCaptureInfo_v2(s, &st, &id, &g, &deps, &n) != hipSuccess || st != hipStreamCaptureStatusActive) {
+      (void)hipGetLastError();
+      set_error("mdie_cdan_forward: hipStreamGetCaptureInfo_v2 failed on a capturing stream");
+      return MDIE_ELAUNCH;
+    }
+    out.assign(deps, deps + n);
+    return MDIE_OK;
+  }
+  // start branch k; *bs = the stream its launches go to
+  int fork(int k, hipStream_t* bs) {
+    *bs = stream;
+    if (mode == STREAMS) {
+      if (hipEventRecord(aux->fork[k], stream) != hipSuccess || hipStreamWaitEvent(aux->side[k], aux->fork[k], 0) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("mdie_cdan_forward: fork to side stream %d failed", k);
+        return MDIE_ELAUNCH;
+      }
+      *bs = aux->side[k];
+      open[k] = true;
+    } else if (mode == GRAPH) {
+      if (int rc = deps_of(stream, at_fork[k])) return rc;
+      if (at_fork[k].empty()) return MDIE_OK;   // nothing captured before the block: it IS the head of the stream, stay serial
+      open[k] = true;
+    }
+    return MDIE_OK;
+  }
+  // the branch's launches are enqueued: remember its end, give the main path its fork point back
+  int end_branch(int k) {
+    if (!open[k]) return MDIE_OK;
+    if (mode == STREAMS) {
+      if (hipEventRecord(aux->join[k], aux->side[k]) != hipSuccess) { (void)hipGetLastError(); set_error("mdie_cdan_forward: join record %d failed", k); return MDIE_ELAUNCH; }
+    } else if (mode == GRAPH) {
+      if (int rc = deps_of(stream, tail[k])) return rc;
+      if (hipStreamUpdateCaptureDependencies(stream, at_fork[k].data(), at_fork[k].size(), hipStreamSetCaptureDependencies) != hipSuccess) {
+        (void)hipGetLastError();
+        open[k] = false;                         // the block stays in line with the main path: correct, merely serial
+        set_error("mdie_cdan_forward: hipStreamUpdateCaptureDependencies(SET) failed");
+        return MDIE_ELAUNCH;
+      }
+    }
+    return MDIE_OK;
+  }
+  int join(int k) {
+    if (!open[k]) return MDIE_OK;
+    open[k] = false;
+    if (mode == STREAMS) {
+      if (hipStreamWaitEvent(stream, aux->join[k], 0) != hipSuccess) { (void)hipGetLastError(); set_error("mdie_cdan_forward: join wait %d failed", k); return MDIE_ELAUNCH; }
+    } else if (mode == GRAPH && !tail[k].empty()) {
+      if (hipStreamUpdateCaptureDependencies(stream, tail[k].data(), tail[k].size(), hipStreamAddCaptureDependencies) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("mdie_cdan_forward: hipStreamUpdateCaptureDependencies(ADD) failed");
+        return MDIE_ELAUNCH;
+      }
+    }
+    return MDIE_OK;
+  }
+  ~Branches() {
+    for (int k = 0; k < 3; ++k)
+      if (open[k]) {
+        if (mode == STREAMS) (void)hipEventRecord(aux->join[k], aux->side[k]);   // (idempotent when end_branch already did)
+        (void)join(k);
+      }
+  }
+};
+
 static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   const int B = d->B, H = d->H, W = d->W;
   const Plan P = make_plan(d->dtype, B, H, W);
@@ -469,26 +555,27 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   const int h1 = H / 2, w1 = W / 2, h2 = H / 4, w2 = W / 4, h3 = H / 8, w3 = W / 8;
   int e;
 #define RUN(call) do { if ((e = (call))) return e; } while (0)
-  // encoder DenseBlock k: forked onto a side stream when the caller provided aux streams
-  Aux* aux = (d->launch_ms == nullptr) ? reinterpret_cast<Aux*>(d->aux) : nullptr;  // instrumented mode stays serial
+  // The three encoder DenseBlocks only meet the main path again in the decoder (models/cdan.py:133,141,149), so each runs
+  // beside it (Branches, above): side streams when launching eagerly, explicit graph branches when `stream` is capturing.
+  Branches br;
+  br.stream = stream;
+  if (d->launch_ms == nullptr && !(d->flags & MDIE_FWD_SERIAL)) {   // instrumented mode stays serial
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); st = hipStreamCaptureStatusNone; }
+    if (st == hipStreamCaptureStatusActive) br.mode = Branches::GRAPH;
+    else if (st == hipStreamCaptureStatusNone && d->aux) { br.mode = Branches::STREAMS; br.aux = reinterpret_cast<Aux*>(d->aux); }
+    else if (st != hipStreamCaptureStatusNone) { set_error("mdie_cdan_forward: the stream's capture has been invalidated"); return MDIE_EINVAL; }
+  }
   auto side_dense = [&](int k, int hh, int ww) -> int {
-    if (!aux) return run_dense(c, k, hh, ww, P.o[k], P.g[k], P.d[k], MDIE_ACT_NONE);
-    if (hipEventRecord(aux->fork[k], stream) != hipSuccess || hipStreamWaitEvent(aux->side[k], aux->fork[k], 0) != hipSuccess) {
-      set_error("mdie_cdan_forward: fork to side stream %d failed", k);
-      return MDIE_ELAUNCH;
-    }
+    hipStream_t bs = stream;
+    if (int rc = br.fork(k, &bs)) return rc;
     Ctx cs = c;
-    cs.stream = aux->side[k];
+    cs.stream = bs;
     const int rc = run_dense(cs, k, hh, ww, P.o[k], P.g[k], P.d[k], MDIE_ACT_NONE);
-    if (rc) return rc;
-    if (hipEventRecord(aux->join[k], aux->side[k]) != hipSuccess) { set_error("mdie_cdan_forward: join record %d failed", k); return MDIE_ELAUNCH; }
-    return MDIE_OK;
+    const int rc2 = br.end_branch(k);     // also after a failed launch: the branch must stay joinable
+    return rc ? rc : rc2;
   };
-  auto join_dense = [&](int k) -> int {
-    if (!aux) return MDIE_OK;
-    if (hipStreamWaitEvent(stream, aux->join[k], 0) != hipSuccess) { set_error("mdie_cdan_forward: join wait %d failed", k); return MDIE_ELAUNCH; }
-    return MDIE_OK;
-  };
+  auto join_dense = [&](int k) -> int { return br.join(k); };
   // Encoder.forward, models/cdan.py:70-98 (dropout = identity in eval)
   {
     mdie_conv_first_desc f{};  // encoder.conv1 + BN + ReLU + maxpool straight from the fp32 NCHW input

@@ -76,17 +76,41 @@ def instantiate(spec, *args, default_module=None, kind="Network", **extra):
 
 # ---- datasets ----------------------------------------------------------------------------------------------------------
 def _images(root):
-    return sorted(f for f in os.listdir(root) if f.lower().endswith(IMAGE_EXT))
+    return sorted(f for f in os.listdir(root) if f.lower().endswith(IMAGE_EXT) and not f.startswith("."))   # data/dataset.py:19
+
+
+def _resize_bilinear(x, h, w):
+    """uint8 HWC -> uint8 HWC, bilinear with half-pixel centres and NO antialiasing: what albumentations' Resize does
+    (cv2.INTER_LINEAR).  PIL's BILINEAR widens its filter when shrinking, which changes test-phase PSNR/SSIM."""
+    if x.shape[0] == h and x.shape[1] == w:
+        return x
+    t = torch.from_numpy(np.array(x, copy=True)).permute(2, 0, 1)[None].float()
+    t = torch.nn.functional.interpolate(t, size=(h, w), mode="bilinear", align_corners=False, antialias=False)
+    return t[0].permute(1, 2, 0).add_(0.5).clamp_(0, 255).to(torch.uint8).numpy()
+
+
+def _lut(x, table):
+    return np.clip(table, 0, 255).astype(np.uint8)[x]
 
 
 class _Transform:
-    """Deterministic subset of the configs' albumentations/torchvision op lists.  If the list ends with
-    Normalize(mean 0, std 1) + ToTensorV2 (every shipped config does), that tail is left to the GPU and
-    samples stay uint8 HWC."""
+    """The op lists of the reference's configs (utils/transforms_factory.py:19-86) on numpy uint8 images.  Geometric ops
+    and the photometric ones the shipped configs use (RandomBrightnessContrast, RandomGamma; config/low_light.json:102-103,
+    config/low_contrast.json:101) plus GaussNoise follow albumentations' published formulas and, like its
+    `additional_targets={"target": "image"}` (:85), draw ONE set of parameters per sample for input and target
+    (albumentations itself is not installed here: these are restatements, not pinned against it).  Op names are checked
+    at construction.  If the list ends with Normalize(mean 0, std 1) + ToTensorV2 (every shipped config does), that tail
+    is left to the GPU and samples stay uint8 HWC."""
+
+    SUPPORTED = ("Resize", "HorizontalFlip", "RandomHorizontalFlip", "VerticalFlip", "RandomVerticalFlip", "RandomRotate90",
+                 "RandomBrightnessContrast", "RandomGamma", "GaussNoise", "Normalize", "ToTensorV2", "ToTensor")
 
     def __init__(self, cfg, device_tail=True):
         self.ops = list((cfg or {}).get("ops", []))
         names = [o["name"] for o in self.ops]
+        bad = [n for n in names if n not in self.SUPPORTED]
+        if bad:
+            raise ValueError(f"transform not supported by the MI355X host path: {', '.join(bad)} (supported: {', '.join(self.SUPPORTED)})")
         self.on_device = False
         if device_tail and len(names) >= 2 and names[-2:] == ["Normalize", "ToTensorV2"]:
             a = self.ops[-2].get("args") or {}
@@ -98,33 +122,59 @@ class _Transform:
         as_float = False
         for op in self.ops:
             name, a = op["name"], (op.get("args") or {})
+            fires = rng is not None and rng.random() < a.get("p", 0.5)
             if name == "Resize":
                 h, w = (a["size"] if "size" in a else (a["height"], a["width"]))
-                arrs = [np.asarray(Image.fromarray(x).resize((w, h), Image.BILINEAR)) for x in arrs]
-            elif name in ("HorizontalFlip", "RandomHorizontalFlip", "VerticalFlip", "RandomVerticalFlip", "RandomRotate90"):
-                if rng is not None and rng.random() < a.get("p", 0.5):
-                    if "Horizontal" in name:
-                        arrs = [x[:, ::-1] for x in arrs]
-                    elif "Vertical" in name:
-                        arrs = [x[::-1] for x in arrs]
-                    else:
-                        k = int(rng.integers(1, 4))
-                        arrs = [np.rot90(x, k) for x in arrs]
+                arrs = [_resize_bilinear(x, h, w) for x in arrs]
+            elif name in ("HorizontalFlip", "RandomHorizontalFlip"):
+                if fires:
+                    arrs = [x[:, ::-1] for x in arrs]
+            elif name in ("VerticalFlip", "RandomVerticalFlip"):
+                if fires:
+                    arrs = [x[::-1] for x in arrs]
+            elif name == "RandomRotate90":
+                if fires:
+                    k = int(rng.integers(0, 4))
+                    arrs = [np.rot90(x, k) for x in arrs]
+            elif name == "RandomBrightnessContrast":       # alpha = 1 + U(-c, c), beta = U(-b, b); uint8: x * alpha + beta * 255
+                if fires:
+                    b_lim, c_lim = a.get("brightness_limit", 0.2), a.get("contrast_limit", 0.2)
+                    alpha, beta = 1.0 + rng.uniform(-c_lim, c_lim), rng.uniform(-b_lim, b_lim)
+                    table = np.arange(256, dtype=np.float32) * alpha + beta * 255.0
+                    arrs = [_lut(x, table) for x in arrs]
+            elif name == "RandomGamma":                    # gamma = U(lo, hi) / 100; uint8: (x / 255) ** gamma * 255
+                if fires:
+                    lo, hi = a.get("gamma_limit", (80, 120))
+                    table = np.power(np.arange(256, dtype=np.float32) / 255.0, rng.uniform(lo, hi) / 100.0) * 255.0
+                    arrs = [_lut(x, table) for x in arrs]
+            elif name == "GaussNoise":                     # additive N(mean, var) with var = U(var_limit), same noise field for the pair
+                if fires:
+                    lo, hi = a.get("var_limit", (10.0, 50.0))
+                    noise = rng.normal(a.get("mean", 0.0), np.sqrt(rng.uniform(lo, hi)), arrs[0].shape)
+                    arrs = [np.clip(x.astype(np.float32) + noise, 0, 255).astype(np.uint8) for x in arrs]
             elif name == "Normalize":
                 mean, std = np.asarray(a["mean"], np.float32), np.asarray(a["std"], np.float32)
                 arrs = [(x.astype(np.float32) / 255.0 - mean) / std for x in arrs]
                 as_float = True
-            elif name in ("ToTensorV2", "ToTensor"):
-                if not as_float and name == "ToTensor":
-                    arrs = [x.astype(np.float32) / 255.0 for x in arrs]
-                    as_float = True
-            else:
-                raise ValueError(f"transform not supported by the MI355X host path: {name}")
+            elif name == "ToTensor" and not as_float:
+                arrs = [x.astype(np.float32) / 255.0 for x in arrs]
+                as_float = True
         out = []
         for x in arrs:
-            x = np.ascontiguousarray(x)
+            x = np.array(x, copy=True)       # (flips / rot90 leave negative-stride views)
             out.append(torch.from_numpy(x) if self.on_device else torch.from_numpy(x.astype(np.float32)).permute(2, 0, 1).contiguous())
         return out
+
+
+def _sample_rng(holder):
+    """Augmentation generator of the calling process: DataLoader workers are re-forked every epoch with a fresh
+    torch.initial_seed() (base seed + worker id), the main process keeps its own; the torchrun rank is mixed in so that
+    ranks, workers and epochs all draw different flips."""
+    key = (os.getpid(), torch.initial_seed())
+    if holder.get("key") != key:
+        holder["key"] = key
+        holder["rng"] = np.random.default_rng([torch.initial_seed() % (2 ** 63), int(os.environ.get("RANK", 0))])
+    return holder["rng"]
 
 
 class ImageFolderPairs(Dataset):
@@ -145,13 +195,13 @@ class ImageFolderPairs(Dataset):
         else:
             raise ValueError(f"Unknown pairing_mode: {pairing_mode}")
         self.tf = _Transform(transform)
-        self.rng = np.random.default_rng(42)
+        self._rng = {}
 
     def __len__(self):
         return len(self.pairs)
 
     def __getitem__(self, i):
-        x, t = self.tf(Image.open(self.pairs[i][0]), Image.open(self.pairs[i][1]), rng=self.rng)
+        x, t = self.tf(Image.open(self.pairs[i][0]), Image.open(self.pairs[i][1]), rng=_sample_rng(self._rng))
         return x, t
 
 
@@ -247,10 +297,31 @@ class RunLogger:
                 json.dump(data, f, indent=2)
 
     def generate_plots(self):
-        pass
+        """loss curves of train.csv next to it (utils/logger.py:168-185 does the same, also best effort)"""
+        if not self.enabled or "train" not in self._csv:
+            return
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+            with open(os.path.join(self._dir, "train.csv")) as f:
+                rows = [r for r in csv.DictReader(f) if r.get("type") == "epoch"]
+            keys = [k for k in (rows[0] if rows else {}) if k.startswith("loss_")]
+            if not keys:
+                return
+            fig, ax = plt.subplots(figsize=(7, 4))
+            for k in keys:
+                ax.plot([int(r["epoch"]) for r in rows], [float(r[k]) for r in rows], label=k[5:])
+            ax.set_xlabel("epoch")
+            ax.set_ylabel("training loss")
+            ax.legend()
+            fig.savefig(os.path.join(self._dir, "loss_curves.png"), dpi=120, bbox_inches="tight")
+            plt.close(fig)
+        except Exception as e:  # noqa: BLE001  (plots never fail a run)
+            warnings.warn(f"loss curves not written: {e}")
 
     def close(self):
-        pass
+        self._csv.clear()
 
 
 # ---- losses (utils/loss_factory.py:106-235; terms that need downloaded networks are skipped) -----------------------------------
@@ -415,8 +486,12 @@ class Model:
         os.makedirs(out_dir, exist_ok=True)
         fmt = str(self.save_cfg.get("format", "png")).lower()
         arr = u8_hwc.cpu().numpy()
+        hw = self.save_cfg.get("resize_hw")                       # [h, w] or None (models/model.py:77,86-87)
         for i in range(arr.shape[0]):
-            Image.fromarray(arr[i]).save(os.path.join(out_dir, f"{prefix}{start + i:05d}.{fmt}"))
+            img = Image.fromarray(arr[i])
+            if hw is not None:
+                img = img.resize((int(hw[1]), int(hw[0])), Image.BILINEAR)
+            img.save(os.path.join(out_dir, f"{prefix}{start + i + 1}.{fmt}"))   # 1-based, no padding: the reference's names (:90)
 
     def _metrics(self, out, tgt):
         from . import pipeline as PL
@@ -431,10 +506,13 @@ class Model:
         path = os.path.join(self.model_path, self.model_name)
         if os.path.exists(path):
             self.network.load_state_dict(torch.load(path, map_location="cpu"))
+        elif os.environ.get("MDIE_ALLOW_UNTRAINED") == "1":          # explicit opt-in only (benchmarks on synthetic weights)
+            warnings.warn(f"checkpoint {path} not found: evaluating the network's current weights (MDIE_ALLOW_UNTRAINED=1)")
         else:
-            warnings.warn(f"checkpoint {path} not found: evaluating the network's current weights")
+            raise FileNotFoundError(f"checkpoint {path} not found (the reference's test phase loads it unconditionally, models/model.py:230-231)")
         self.network.eval()
         sums = {"raw": {}, "post": {}}
+        losses = build_losses(self.config.get("loss")) if self.is_dataset_paired else None     # models/model.py:257,264
         n_batches = n_images = 0
         max_save = self.save_cfg.get("max_images")
         t0 = time.time()
@@ -448,12 +526,15 @@ class Model:
                 saving = self.save_cfg.get("enabled", True) and (max_save is None or n_images < max_save)
                 pp, pp_u8 = PL.apply_postprocessing(raw, self.postproc_cfg, want_uint8=True) if want_post else (raw, None)
                 if t is not None:
-                    if self.eval_on_raw:
-                        for k, v in self._metrics(raw, t).items():
-                            sums["raw"][k] = sums["raw"].get(k, 0.0) + v
-                    if self.eval_on_post and want_post:
-                        for k, v in self._metrics(pp, t).items():
-                            sums["post"][k] = sums["post"].get(k, 0.0) + v
+                    for stage, on, img in (("raw", self.eval_on_raw, raw), ("post", self.eval_on_post and want_post, pp)):
+                        if not on:
+                            continue
+                        vals = dict(self._metrics(img, t))
+                        if losses is not None and len(losses):      # the loss pipeline is evaluated in the test phase too
+                            lv = losses(img, t)[1].cpu().tolist()
+                            vals.update({f"loss_{k}": v for k, v in zip(losses.names + ["total"], lv)})
+                        for k, v in vals.items():
+                            sums[stage][k] = sums[stage].get(k, 0.0) + v
                 if saving:
                     if self.save_cfg["save_raw"]:
                         self._save(PL.to_uint8_hwc(raw), n_images, self.save_cfg["raw_prefix"])
@@ -475,3 +556,50 @@ class Model:
             self.logger.log("test", row)
             self.logger.summary(self.results)
         return self.results
+
+
+# ---- the driver ---------------------------------------------------------------------------------------------------------
+def seed_everything(seed=42):
+    """python / numpy / torch generators (the reference seeds 42 before every run, utils/reproducibility.py:6-20; the HIP
+    kernels themselves are deterministic by construction: ordered reductions, counter-based dropout)"""
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def run(config):
+    """One run of the phase a parsed config names (`load_config(path, phase)`): the objects the config describes are built
+    by the ["module", "Class"] factory in dependency order -- data, loader, network, harness -- and the harness method of
+    the same name as the phase is called.  Returns the harness (its `.results` / `.history` hold what was measured)."""
+    phase = config["phase"]
+    if phase not in ("train", "test"):
+        raise ValueError(f"phase must be 'train' or 'test', got {phase!r}")
+    seed_everything(int(config.get("seed") or 42))
+    section, model_cfg = config[phase], config["model"]
+    log = RunLogger(config)
+    if log.run_dir():
+        print(f"run directory: {log.run_dir()}")
+    loader = make_dataloader(instantiate(section["dataset"], default_module="data", kind="Dataset"), section["dataloader"]["args"])
+    network = instantiate(model_cfg["networks"][0], default_module="models.network", kind="Network")
+    harness_spec = {"name": model_cfg["which_model"]["name"], "args": dict(model_cfg["which_model"].get("args") or {})}
+    harness = instantiate(harness_spec, network, default_module="models.model", kind="Model", config=config, dataloader=loader, logger=log)
+    try:
+        getattr(harness, phase)()
+        if phase == "train":
+            log.generate_plots()
+    finally:
+        log.close()
+    return harness
+
+
+def cli(argv=None):
+    """`run.py -c config/<task>.json -p train|test`: the command line of the reference's run.py:37-53"""
+    import argparse
+    ap = argparse.ArgumentParser(description="CDAN restoration on the MI355X engine, driven by the reference's config files")
+    ap.add_argument("-c", "--config", required=True, help="JSON config (// comments allowed), e.g. config/low_light.json")
+    ap.add_argument("-p", "--phase", choices=("train", "test"), default="train")
+    a = ap.parse_args(argv)
+    return run(load_config(a.config, a.phase))

@@ -75,7 +75,9 @@ class CDAN(nn.Module):
         self._packed = {}
 
     def _engine(self, device):
-        key = (str(device), self.precision)
+        # one engine (workspace + side streams) per (device, precision, STREAM): forwards issued on different streams may
+        # overlap on the GPU and must not share a workspace; forwards on one stream are ordered by the stream
+        key = (str(device), self.precision, torch.cuda.current_stream(device).cuda_stream)
         eng = self._engines.get(key)
         fp = (_fingerprint(self), id(next(self.parameters())))
         if eng is None:

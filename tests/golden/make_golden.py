@@ -26,6 +26,9 @@ Files written
                           parameters -- their mean is what an N=2 gradient all-reduce + /world must reproduce
                                                                                  [python make_golden.py ddp]
 
+  reference_config_digest.json   transform / loss / metric / post-processing sections of the reference's 11 configs
+                                                                                 [python make_golden.py configs]
+
 `python make_golden.py` regenerates everything; a section name regenerates only that file.
 """
 import json
@@ -144,6 +147,24 @@ def ddp_fixture():
         if r == 0:
             out["norms0"] = np.array(json.dumps({k: float(v.grad.double().norm()) for k, v in named.items()}))
     save("ddp_2shard_32.npz", **out)      # (the exchanged gradient, (g0 + g1) / 2, is derived by the tests)
+
+
+def config_digest():
+    """the parts of the reference's 11 task configs the boundary caller consumes, as data: per config and phase the
+    transform op list, the loss terms, metric names, post-processing ops and the ["module", "Class"] names"""
+    import glob
+    out = {}
+    for path in sorted(glob.glob("/root/reference/config/*.json")):
+        with open(path) as f:
+            cfg = json.loads("\n".join(line.split("//")[0] for line in f.read().splitlines()))
+        entry = {"model": cfg["model"], "loss": cfg.get("loss"), "metrics": cfg.get("metrics"), "post_processing": cfg.get("post_processing")}
+        for phase in ("train", "test"):
+            ds = cfg[phase]["dataset"]
+            entry[phase] = {"dataset_name": ds["name"], "transform": ds["args"].get("transform"), "dataloader": cfg[phase]["dataloader"]}
+        out[os.path.basename(path)] = entry
+    with open(os.path.join(HERE, "reference_config_digest.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print(f"reference_config_digest.json: {len(out)} configs")
 
 
 def main():
@@ -276,3 +297,5 @@ if __name__ == "__main__":
         dec_taps()
     if what in ("all", "ddp"):
         ddp_fixture()
+    if what in ("all", "configs"):
+        config_digest()

@@ -78,3 +78,82 @@ def test_package_synthetic_workload_equals_the_oracle_generators():
     assert torch.equal(d1, d2) and torch.equal(c1, c2)
     r1, r2 = S.make_state_dict(7, R.router_param_spec()), P.fill_spec(R.router_param_spec(), 7, randomize_bn=True)
     assert all(torch.equal(r1[k], r2[k]) for k in r1)
+
+
+def _reference_configs():
+    """every task config of the reference: read from /root/reference where it exists (the build container), else from
+    the digest tests/golden/make_golden.py wrote from it"""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    paths = sorted(glob.glob("/root/reference/config/*.json"))
+    if paths:
+        return {os.path.basename(p): {ph: H.load_config(p, ph) for ph in ("train", "test")} for p in paths}
+    with open(os.path.join(here, "golden", "reference_config_digest.json")) as f:
+        digest = json.load(f)
+    out = {}
+    for name, e in digest.items():
+        out[name] = {}
+        for ph in ("train", "test"):
+            out[name][ph] = H._wrap({"phase": ph, "model": e["model"], "loss": e["loss"], "metrics": e["metrics"],
+                                     "post_processing": e["post_processing"],
+                                     ph: {"dataset": {"name": e[ph]["dataset_name"], "args": {"transform": e[ph]["transform"]}},
+                                          "dataloader": e[ph]["dataloader"]}})
+    return out
+
+
+def test_every_reference_config_drives_both_phases(tmp_path):
+    """`run.py -c config/<task>.json -p train|test` for all 11 task configs: the transform list of each phase is accepted
+    and runs on a sample pair (RandomGamma / RandomBrightnessContrast included, config/low_light.json:102-103), the loss
+    section builds (network-bound terms skipped with a warning), the factory names resolve to this repository's classes."""
+    import warnings
+    _write_pairs(str(tmp_path), n=2)
+    cfgs = _reference_configs()
+    assert len(cfgs) == 11
+    seen_ops = set()
+    for name, phases in cfgs.items():
+        for ph, cfg in phases.items():
+            ds = cfg[ph]["dataset"]
+            tf = ds["args"]["transform"]
+            seen_ops |= {o["name"] for o in tf["ops"]}
+            pairs = H.instantiate({"name": ds["name"], "args": {"input_root": str(tmp_path / "degraded"), "target_root": str(tmp_path / "clean"),
+                                                                "pairing_mode": "filename", "transform": tf}}, default_module="data", kind="Dataset")
+            for rep in range(8):                      # the random ops all get to fire
+                x, t = pairs[rep % 2]
+                assert x.dtype == torch.uint8 and tuple(x.shape) == (256, 384, 3) and tuple(t.shape) == (256, 384, 3), (name, ph)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                assert len(H.build_losses(cfg.get("loss"))) >= 1, name
+            net_name = cfg["model"]["networks"][0]["name"]
+            assert net_name == ["models.cdan", "CDAN"] and cfg["model"]["which_model"]["name"] == ["models.model", "Model"]
+    assert {"RandomGamma", "RandomBrightnessContrast", "RandomRotate90", "VerticalFlip", "HorizontalFlip", "Resize"} <= seen_ops
+
+
+def test_photometric_ops_share_parameters_between_input_and_target():
+    """albumentations' additional_targets={"target": "image"} (utils/transforms_factory.py:85): one draw per sample"""
+    tf = H._Transform({"ops": [{"name": "RandomGamma", "args": {"gamma_limit": [70, 130], "p": 1.0}},
+                               {"name": "RandomBrightnessContrast", "args": {"brightness_limit": 0.1, "contrast_limit": 0.1, "p": 1.0}}]}, device_tail=False)
+    img = Image.fromarray(np.tile(np.arange(256, dtype=np.uint8)[None, :, None], (4, 1, 3)))
+    a, b = tf(img, img, rng=np.random.default_rng(3))
+    assert torch.equal(a, b) and not torch.equal(a, torch.from_numpy(np.asarray(img)).permute(2, 0, 1).float())
+    assert (a[0, 0, 1:] >= a[0, 0, :-1]).all()                 # both ops are monotonic look-up tables
+
+
+def test_resize_is_plain_bilinear_without_antialiasing():
+    """albumentations Resize = cv2.INTER_LINEAR: half-pixel centres, two taps per axis also when shrinking"""
+    x = np.zeros((8, 8, 3), np.uint8)
+    x[:, 4:] = 200
+    y = H._resize_bilinear(x, 4, 4)               # 2x shrink: output column j samples between input columns 2j and 2j+1
+    assert y.shape == (4, 4, 3) and (y[:, :2] == 0).all() and (y[:, 2:] == 200).all()
+    z = H._resize_bilinear(x, 8, 16)
+    assert z.shape == (8, 16, 3) and z[0, 0, 0] == 0 and z[0, -1, 0] == 200
+
+
+def test_workers_and_epochs_draw_different_augmentations(tmp_path):
+    _write_pairs(str(tmp_path), n=4)
+    tf = {"ops": [{"name": "HorizontalFlip", "args": {"p": 0.5}}, {"name": "VerticalFlip", "args": {"p": 0.5}},
+                  {"name": "Normalize", "args": {"mean": [0, 0, 0], "std": [1, 1, 1]}}, {"name": "ToTensorV2", "args": {}}]}
+    ds = H.ImageFolderPairs(str(tmp_path / "degraded"), str(tmp_path / "clean"), "filename", tf)
+    torch.manual_seed(1)
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, num_workers=2)
+    epochs = [torch.cat([x for x, _ in loader]) for _ in range(3)]
+    assert not (torch.equal(epochs[0], epochs[1]) and torch.equal(epochs[1], epochs[2]))   # (was: every epoch identical)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """PCIe-inclusive serving rate: pinned uint8 HWC batches on the host -> async H2D -> normalise
 on the GPU -> CDAN forward -> uint8 HWC on the GPU -> async D2H into pinned memory, three batches in flight on three
-stream pairs.  bench.py's `value` keeps inputs resident in HBM; this is the number with the host transfers in.
+streams (one engine -- workspace, side streams -- per stream; the slots' outputs are compared with a single-stream run before
+anything is timed).  bench.py's `value` keeps inputs resident in HBM; this is the number with the host transfers in.
   python tools/bench_e2e.py [bf16|fp32] [B] [S] [batches]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,6 +27,20 @@ streams = [torch.cuda.Stream(dev) for _ in range(DEPTH)]
 done = [None] * DEPTH
 
 
+def check_slots():
+    """every in-flight slot (its own stream, hence its own engine and workspace: modules.CDAN._engine) must reproduce
+    the single-stream result bit for bit, also when the three overlap on the GPU"""
+    with torch.no_grad():
+        ref = PL.to_uint8_hwc(net(PL.feed_uint8(host_in[0].to(dev)))).cpu()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i in range(DEPTH):
+            submit(i)
+        torch.cuda.synchronize()
+        for k in range(DEPTH):
+            assert torch.equal(host_out[k], ref), f"slot {k} differs from the single-stream output (round {rep})"
+
+
 def submit(i):
     k = i % DEPTH
     if done[k] is not None:
@@ -39,6 +54,7 @@ def submit(i):
         done[k] = ev
 
 
+check_slots()
 for i in range(2 * DEPTH):
     submit(i)
 torch.cuda.synchronize()
