@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -562,7 +563,10 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   if (d->launch_ms == nullptr && !(d->flags & MDIE_FWD_SERIAL)) {   // instrumented mode stays serial
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); st = hipStreamCaptureStatusNone; }
-    if (st == hipStreamCaptureStatusActive) br.mode = Branches::GRAPH;
+    // (experiments only: MDIE_CAPTURE_SIDE_STREAMS=1 restores round 1's shape -- the library's side streams join the caller's capture)
+    static const bool legacy_capture = getenv("MDIE_CAPTURE_SIDE_STREAMS") && atoi(getenv("MDIE_CAPTURE_SIDE_STREAMS")) != 0;
+    if (st == hipStreamCaptureStatusActive && legacy_capture && d->aux) { br.mode = Branches::STREAMS; br.aux = reinterpret_cast<Aux*>(d->aux); }
+    else if (st == hipStreamCaptureStatusActive) br.mode = Branches::GRAPH;
     else if (st == hipStreamCaptureStatusNone && d->aux) { br.mode = Branches::STREAMS; br.aux = reinterpret_cast<Aux*>(d->aux); }
     else if (st != hipStreamCaptureStatusNone) { set_error("mdie_cdan_forward: the stream's capture has been invalidated"); return MDIE_EINVAL; }
   }

@@ -585,6 +585,71 @@ def test_thin_single_chunk_conv(E, L, prec, cin_segs, shape, pre):
     assert (out[..., :16] == -7.0).all() and (out[..., 32:] == -7.0).all()     # nothing written outside the slice
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", ["plain", "pool", "residual", "stats", "convT_ragged_batch"])
+def test_wide_conv_lds_dma_kernel(E, L, prec, case):
+    """conv_wide_kernel (csrc/conv_wide.hip: 32x16-pixel tiles, LDS-DMA double buffering, persistent workgroups) -- the
+    kernel behind encoder.conv2-4 and decoder.conv1-3 at BASELINE sizes -- against torch's CPU convolution on the same
+    rounded operands, and bit for bit against conv_kernel (which a single image, too few work items for the persistent
+    grid, still runs on): border tiles, several items per workgroup, 2 and 4 K chunks, every epilogue it has."""
+    import ctypes as C
+    import torch.nn.functional as F
+    dt, td = E.dtype_id(prec), TORCH_DT[prec]
+    rnd = lambda t: t.to(td).float()
+    B, H, W, cin, cout = {"plain": (12, 32, 64, 64, 128), "pool": (12, 32, 64, 128, 128), "residual": (12, 32, 32, 128, 256),
+                          "stats": (16, 32, 32, 64, 512), "convT_ragged_batch": (13, 16, 32, 64, 512)}[case]
+    assert B * (H // 16) * (W // 32) * (cout // 64) >= 96 > (H // 16) * (W // 32) * (cout // 64)    # the batch runs conv_wide, one image conv_kernel
+    g = torch.Generator().manual_seed(len(case) * 13 + cin)
+    x = rnd(torch.randn(B, H, W, cin, generator=g))
+    transposed = case.startswith("convT")
+    w = rnd(torch.randn((cin, cout, 3, 3) if transposed else (cout, cin, 3, 3), generator=g) * 0.05)
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    res = rnd(torch.randn(B, H, W, cout, generator=g)) if case == "residual" else None
+    xin = x.permute(0, 3, 1, 2)
+    ref = F.conv_transpose2d(xin, w, padding=1) if transposed else F.conv2d(xin, w, padding=1)
+    ref = torch.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    if case == "pool":
+        ref = F.max_pool2d(ref, 2, 2)
+    if res is not None:
+        ref = ref + res.permute(0, 3, 1, 2)
+    ref = ref.permute(0, 2, 3, 1)
+
+    wp = E.pack_conv_weight(w, dt, transposed=transposed).cuda()
+    dx, dsc, dsh = x.cuda().to(td), sc.cuda(), sh.cuda()
+    dres = res.cuda().to(td) if res is not None else None
+
+    def run(nb):
+        Ho, Wo = (H // 2, W // 2) if case == "pool" else (H, W)
+        out = torch.full((nb, Ho, Wo, cout), -7.0, device="cuda", dtype=td)
+        d = L.ConvDesc()
+        d.dtype, d.B, d.H, d.W, d.ksize, d.nseg = dt, nb, H, W, 3, 1
+        d.inp[0] = L.Seg(dx.data_ptr(), cin, cin)
+        d.cin, d.cout = cin, cout
+        d.weight, d.post_scale, d.post_shift = wp.data_ptr(), dsc.data_ptr(), dsh.data_ptr()
+        d.act, d.pool = L.ACT_RELU, int(case == "pool")
+        if dres is not None:
+            d.residual, d.res_stride = dres.data_ptr(), cout
+        d.out, d.out_stride = out.data_ptr(), cout
+        part = None
+        if case == "stats":
+            assert L.lib.mdie_conv_tile(nb, H, W, cout) == 16
+            part = torch.full((nb, (H // 16) * (W // 16), 2, cout), 3.0, device="cuda")
+            d.pool_partial = part.data_ptr()
+        L.check(L.lib.mdie_conv_fwd(C.byref(d), None), "mdie_conv_fwd")
+        torch.cuda.synchronize()
+        return out, part
+
+    out, part = run(B)                     # >= 96 work items: conv_wide_kernel
+    assert rel_to_max(out, ref) <= {"bf16": 8e-3, "fp16": 1e-3}[prec]
+    if case != "stats":
+        one, _ = run(1)                    # 1 image: conv_kernel
+        assert torch.equal(one[0], out[0]), "the two convolution kernels must agree bit for bit"
+    else:
+        o = out.float().reshape(B, H // 16, 16, W // 16, 16, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, -1, 256, cout)
+        assert torch.allclose(part[:, :, 0], o.sum(2), rtol=1e-5, atol=1e-3)
+        assert torch.equal(part[:, :, 1], o.amax(2))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # training mode (SURVEY.md 8a rows a5, a13, a14): HIP convolutions (forward / dgrad / wgrad) under autograd
 # ---------------------------------------------------------------------------------------------------------------------
