@@ -65,27 +65,60 @@ def kind_model(B, H, W, esz):
     return {k: (v[0] * B, v[1] * B) for k, v in by.items()}
 
 
-def cpu_baseline(sd, x_cpu, seconds_budget=20.0):
-    """The oracle (a port of the reference's PyTorch CPU path) on this host's cores."""
+def cpu_baseline(sd, x_cpu, seconds_budget=16.0):
+    """The oracle (a port of the reference's PyTorch CPU path) on this host's cores: the whole batch of the GPU run
+    (B = 32 at 256x256, 1 warm-up + timed forwards, median) on every core this process may use, plus a
+    one-thread figure on a 2-image sample (a one-thread pass over 32 images alone would take most of a minute)."""
     from oracle import cdan_oracle as O
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # a one-GPU box owns a 16-core share of its host; more threads than that only oversubscribe
     cores = int(os.environ.get("MDIE_CPU_THREADS", min(avail, 16)))
-    torch.set_num_threads(cores)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        ref = O.cdan_forward(sd, x_cpu)          # warm-up (also the parity reference)
-        warm = time.perf_counter() - t0
-        reps = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
-        times = []
-        for _ in range(reps):
+
+    def timed(x, threads, budget, max_reps):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
             t0 = time.perf_counter()
-            O.cdan_forward(sd, x_cpu)
-            times.append(time.perf_counter() - t0)
-    med = sorted(times)[len(times) // 2]
+            ref = O.cdan_forward(sd, x)          # warm-up (also the parity reference)
+            warm = time.perf_counter() - t0
+            reps = max(1, min(max_reps, int(budget / max(warm, 1e-3)) - 1))
+            times = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                O.cdan_forward(sd, x)
+                times.append(time.perf_counter() - t0)
+        return ref, sorted(times)[len(times) // 2], reps
+
+    ref, med, reps = timed(x_cpu, cores, seconds_budget, 3)
+    _, med1, reps1 = timed(x_cpu[:2], 1, 6.0, 2)
+    torch.set_num_threads(cores)
     return ref, {"value": round(x_cpu.shape[0] / med, 3), "unit": "images/sec", "cores": cores, "kind": "port",
                  "sample": f"{reps} timed fp32 forwards of {x_cpu.shape[0]}x3x{x_cpu.shape[2]}x{x_cpu.shape[3]} "
-                           f"(same synthetic low-light images, first {x_cpu.shape[0]} of the GPU batch), median"}
+                           f"(the GPU batch itself: same synthetic low-light images), median, after 1 warm-up",
+                 "one_thread": {"value": round(2 / med1, 3), "unit": "images/sec", "cores": 1,
+                                "sample": f"{reps1} timed fp32 forwards of 2x3x{x_cpu.shape[2]}x{x_cpu.shape[3]}, median, after 1 warm-up"}}
+
+
+def source_sha16():
+    """hash of the kernel sources + C header: ties a committed rocprofv3 traffic file to the build it was measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pk = os.path.join(ROOT, "multi-degradation-image-enhancement_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(pk, "*.hip")) + glob.glob(os.path.join(pk, "*.hpp")) + [os.path.join(ROOT, "include", "mdie.h")]):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def timed_loop(fn, dev, n, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / n
 
 
 def max_over_ranks(elapsed, dist, device):
@@ -115,7 +148,8 @@ def main():
                     help="how a step is enqueued: one hipGraph replay, 41 eager launches from one host call, or (auto) whichever "
                          "of the two ran the untimed warmup steps faster on this box")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=32, help="images of the GPU batch the CPU baseline runs (SURVEY.md 8d: the whole batch)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed side measurements (fp32 / fp16 paths, nn.Module boundary)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -236,13 +270,18 @@ def main():
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
     # HBM bytes per step from the committed rocprofv3 PMC passes of this exact workload (tools/traffic_from_pmc.py;
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- bench.py cannot run the profiler itself
-    traffic = None
+    traffic, traffic_note = None, "no profiles/traffic_*.json for this workload"
     tfile = os.path.join(ROOT, "profiles", f"traffic_{args.precision}_b{B}_{S}.json")
     if os.path.exists(tfile):
         with open(tfile) as f:
-            traffic = json.load(f).get("hbm_bytes_per_step")
+            tj = json.load(f)
+        if tj.get("kernel_source_sha16") == source_sha16():
+            traffic, traffic_note = tj.get("hbm_bytes_per_step"), f"{os.path.basename(tfile)} (rocprofv3 PMC passes on this source, sha16 {tj.get('kernel_source_sha16')})"
+        else:   # never echo counters measured on other kernels
+            traffic_note = (f"{os.path.basename(tfile)} was measured on kernel source {tj.get('kernel_source_sha16')}, this tree is {source_sha16()}: "
+                            f"stale, not reported (was {tj.get('hbm_bytes_per_step')})")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic, "traffic_source": traffic_note,
                 "kernel": "cdan_forward (all launches of one step)", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_step": alg_bytes, "flops_per_step": flops,
                 "mfma_frac": round(flops / (kernel_ms * 1e-3) / 1e12 / MFMA_PEAK_TF[args.precision], 4) if kernel_ms else None,
@@ -257,6 +296,26 @@ def main():
                       "launch": ("eager (one host call, 41 launches)" if graph is None else "hipGraph replay") + (", chosen in warmup" if args.launch == "auto" else "")},
            "roofline": roofline}
 
+    if not args.no_extra and world == 1:
+        # side measurements, outside the timed region: the other storage types of the same workload and the cost of going
+        # through nn.Module.forward (state_dict fingerprint walk + output allocation per call) instead of the C ABI call above
+        extra = {}
+        with torch.no_grad():
+            t_mod = timed_loop(lambda: net(x), dev, 20)
+            extra["module_forward_bf16" if args.precision == "bf16" else f"module_forward_{args.precision}"] = {
+                "images_per_sec": round(B / t_mod, 1), "ms_per_step": round(t_mod * 1e3, 4),
+                "what": "net(x) through models.cdan.CDAN.forward (eager launches), same batch"}
+            for prec in ("fp16", "fp32", "bf16"):
+                if prec == args.precision:
+                    continue
+                net.precision = prec
+                e2 = net._engine(dev)
+                y2 = torch.empty_like(x)
+                t2 = timed_loop(lambda: e2.forward(x, out=y2), dev, 10 if prec == "fp32" else 20)
+                extra[prec] = {"images_per_sec": round(B / t2, 1), "ms_per_step": round(t2 * 1e3, 4), "_y": y2}
+            net.precision = args.precision
+        out["extra"] = extra
+
     if not args.no_cpu and world == 1:   # the CPU leg is a single-GPU-run feature (rank 0 at N=1 only)
         nb = min(args.cpu_batch, B)
         ref, cb = cpu_baseline(sd, x_cpu[:nb])
@@ -267,11 +326,17 @@ def main():
         from mdie_amd import pipeline as PL
         clean_d, ref_d = clean_cpu[:nb].to(dev), ref.to(dev)
         m_gc, m_gt, m_ct = (PL.psnr_ssim(a, b).cpu().tolist() for a, b in ((y[:nb], ref_d), (y[:nb], clean_d), (ref_d, clean_d)))
+        for prec, e in out.get("extra", {}).items():      # the other storage types against the same CPU output
+            if "_y" in e:
+                ye = e.pop("_y")[:nb].float().cpu()
+                e["max_abs_err_over_max_vs_cpu"] = round(((ye - ref).abs().max() / ref.abs().max()).item(), 7)
         cb["parity"] = {"max_abs_err_over_max": round(err, 6),
                         "gpu_vs_cpu": {"psnr_db": round(m_gc[0], 2), "ssim": round(m_gc[1], 5)},
                         "gpu_vs_clean": {"psnr_db": round(m_gt[0], 2), "ssim": round(m_gt[1], 5)},
                         "cpu_vs_clean": {"psnr_db": round(m_ct[0], 2), "ssim": round(m_ct[1], 5)}}
         out["cpu_baseline"] = cb
+    for e in out.get("extra", {}).values():
+        e.pop("_y", None)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -32,7 +32,7 @@ for f in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursi
             split = collections.defaultdict(float)
             for d in disp[a:b]:
                 n = d["name"]
-                key = "conv3x3" if ("conv_kernel" in n and "Li3E" in n) or "conv_first" in n else "conv1x1" if ("conv_kernel" in n or "conv1x1" in n) else \
+                key = "conv3x3" if ("conv_kernel" in n and "Li3E" in n) or "conv_first" in n or "conv_wide" in n else "conv1x1" if ("conv_kernel" in n or "conv1x1" in n) else \
                       "cbam" if "cbam" in n else "upsample_add" if "upsample" in n else "tail" if "tail" in n else "layout"
                 if "conv_kernel<" in n:  # demangled template form
                     key = "conv"
@@ -40,7 +40,10 @@ for f in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursi
             per_counter[cname]["kib_by_kind"] = dict(split)
 fetch = per_counter.get("FETCH_SIZE", {}).get("kib_per_step_median")
 write = per_counter.get("WRITE_SIZE", {}).get("kib_per_step_median")
-res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --no-graph",
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (source_sha16: bench.py reports this file only for the kernel sources it was measured on)
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --launch eager",
+       "kernel_source_sha16": bench.source_sha16(),
        "fetch_size_kib": fetch, "write_size_kib": write,
        "hbm_bytes_per_step": (2.0 * fetch + write) * 1024 if fetch is not None and write is not None else None,
        "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 64 B per 128 B request)",
