@@ -385,7 +385,7 @@ int mdie_bn_fold(int C_stored, int C_real, int split, int gap, const float* mean
  * the backward); either output may be NULL */
 int mdie_bn_act_pool_fwd(int dtype, int B, int H, int W, int C, const void* y, int y_stride, const float* scale,
                          const float* shift, int pool, void* out, int out_stride, void* out_drop, int drop_stride,
-                         float p, unsigned seed, void* stream);
+                         float p, unsigned seed, const unsigned* seed_dev, void* stream);
 typedef struct {
   int dtype, B, H, W, C, c_real;          /* H, W: resolution of y */
   const void* y; int y_stride;
@@ -394,6 +394,7 @@ typedef struct {
   const void* d_out; int d_out_stride;    /* gradient w.r.t. `out` (or NULL) */
   const void* d_drop; int d_drop_stride;  /* gradient w.r.t. `out_drop` (or NULL) */
   float p; unsigned seed;
+  const unsigned* seed_dev;               /* as in mdie_bn_act_pool_fwd: the SAME counter value must be in place for forward and backward */
   void* dz; int dz_stride;                /* out: masked, pool-routed gradient at y's resolution */
   float* dgamma; float* dbeta;            /* out: [c_real] */
   float* coef;                            /* out: [2][C], consumed by mdie_bn_bwd_apply */

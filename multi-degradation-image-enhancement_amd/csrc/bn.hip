@@ -125,6 +125,12 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+// seed of a launch: the caller's host value, mixed with a counter in DEVICE memory when one is given -- a captured training
+// step (hipGraph replay) freezes every host argument, the counter is bumped by a captured kernel, so each replay drops
+// other elements while forward and backward of one step still see the same mask
+__device__ __forceinline__ uint32_t launch_seed(uint32_t seed, const uint32_t* seed_dev) {
+  return seed_dev ? seed ^ mix32(*seed_dev + 0x9e3779b9U) : seed;
+}
 // multiplier applied to element idx: 0 (dropped) or 1 / (1 - p)
 __device__ __forceinline__ float drop_factor(uint32_t seed, size_t idx, float p, float keep_scale) {
   const uint32_t h = mix32((uint32_t)idx ^ mix32(seed ^ (uint32_t)(idx >> 32) * 0x9e3779b9U));
@@ -136,8 +142,9 @@ __device__ __forceinline__ float drop_factor(uint32_t seed, size_t idx, float p,
 template <typename T, bool POOL>
 __global__ __launch_bounds__(BN_THREADS) void bn_act_pool_fwd_kernel(int B, int H, int W, int C, const char* y, int y_stride, const float* scale,
                                                                      const float* shift, char* out_o, int o_stride, char* out_t, int t_stride, float p,
-                                                                     uint32_t seed) {
+                                                                     uint32_t seed_host, const uint32_t* seed_dev) {
   constexpr int VEC = Traits<T>::VEC;
+  const uint32_t seed = launch_seed(seed_host, seed_dev);
   const int CV = C / VEC;
   const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
   const size_t total = (size_t)B * Ho * Wo * CV;
@@ -188,7 +195,7 @@ struct BnBwdPoolArgs {
   const float *scale, *shift, *mean, *invstd;
   const char* d_o; int do_stride;
   const char* d_t; int dt_stride;
-  float p; uint32_t seed;
+  float p; uint32_t seed; const uint32_t* seed_dev;
   char* dz; int dz_stride;
   float* partial;
   long chunk;    // output pixels per block
@@ -203,6 +210,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_pool_bwd_kernel(const BnBwd
   const int Ho = POOL ? a.H / 2 : a.H, Wo = POOL ? a.W / 2 : a.W;
   const long NO = (long)a.B * Ho * Wo;
   const float ks = 1.0f / (1.0f - a.p);
+  const uint32_t seed = launch_seed(a.seed, a.seed_dev);
   float s[2][VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) s[0][i] = s[1][i] = 0.f;
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_pool_bwd_kernel(const BnBwd
         float f[VEC];
         Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.d_t + (size_t)op * a.dt_stride * sizeof(T) + (size_t)v * 16), f);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) g[i] += a.p > 0.f ? f[i] * drop_factor(a.seed, (size_t)op * a.C + v * VEC + i, a.p, ks) : f[i];
+        for (int i = 0; i < VEC; ++i) g[i] += a.p > 0.f ? f[i] * drop_factor(seed, (size_t)op * a.C + v * VEC + i, a.p, ks) : f[i];
       }
       if (POOL) {
         const int ox = (int)(op % Wo);
@@ -611,7 +619,8 @@ extern "C" int mdie_bn_fold(int C_stored, int C_real, int split, int gap, const 
 }
 
 extern "C" int mdie_bn_act_pool_fwd(int dtype, int B, int H, int W, int C, const void* y, int y_stride, const float* scale, const float* shift, int pool,
-                                    void* out, int out_stride, void* out_drop, int drop_stride, float p, unsigned seed, void* stream) {
+                                    void* out, int out_stride, void* out_drop, int drop_stride, float p, unsigned seed, const unsigned* seed_dev,
+                                    void* stream) {
   if (int e = bn_check("mdie_bn_act_pool_fwd", dtype, (long)B * H * W, C)) return e;
   MDIE_REQUIRE(y && scale && shift && (out || out_drop), "mdie_bn_act_pool_fwd: null pointer");
   MDIE_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), "mdie_bn_act_pool_fwd: pooling needs even H, W (got %dx%d)", H, W);
@@ -621,7 +630,7 @@ extern "C" int mdie_bn_act_pool_fwd(int dtype, int B, int H, int W, int C, const
   const size_t total = (size_t)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C / vec);
   const dim3 grid(bn_grid(total)), blk(BN_THREADS);
 #define MDIE_BN_FWD(T, P) hipLaunchKernelGGL((bn_act_pool_fwd_kernel<T, P>), grid, blk, 0, s, B, H, W, C, (const char*)y, y_stride, scale, shift, (char*)out, \
-                                             out_stride, (char*)out_drop, drop_stride, p, (uint32_t)seed)
+                                             out_stride, (char*)out_drop, drop_stride, p, (uint32_t)seed, (const uint32_t*)seed_dev)
   MDIE_SWITCH_T(dtype, if (pool) MDIE_BN_FWD(T, true); else MDIE_BN_FWD(T, false));
 #undef MDIE_BN_FWD
   MDIE_LAUNCH_CHECK("mdie_bn_act_pool_fwd");
@@ -653,7 +662,7 @@ extern "C" int mdie_bn_act_pool_bwd(const mdie_bn_pool_bwd_desc* d, void* stream
   a.scale = d->scale; a.shift = d->shift; a.mean = d->mean; a.invstd = d->invstd;
   a.d_o = (const char*)d->d_out; a.do_stride = d->d_out_stride;
   a.d_t = (const char*)d->d_drop; a.dt_stride = d->d_drop_stride;
-  a.p = d->p; a.seed = d->seed;
+  a.p = d->p; a.seed = d->seed; a.seed_dev = (const uint32_t*)d->seed_dev;
   a.dz = (char*)d->dz; a.dz_stride = d->dz_stride;
   a.partial = reinterpret_cast<float*>(d->workspace);
   a.chunk = p.chunk;

@@ -305,7 +305,7 @@ bool conv_wide_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw
   if (off || dtype == MDIE_F32 || ksize != 3 || has_nchw3 || a.pre_scale || a.nseg != 1) return false;
   if (a.cin % 32 != 0 || a.cin < 64 || a.cout % WD_BN != 0 || a.cout > WD_MAX_COUT) return false;
   if (a.W % WD_TW != 0 || a.H % WD_TH != 0) return false;
-  if (a.e.act != MDIE_ACT_RELU) return false;
+  if (a.e.act != MDIE_ACT_RELU && !(a.e.act == MDIE_ACT_NONE && !a.e.pool && !a.pool_partial)) return false;   // (NONE: training forward / dgrad)
   if (a.pool_partial && (a.e.pool || mdie_conv_tile(a.B, a.H, a.W, a.cout) != 16)) return false;   // slabs are 16x16 tiles
   if ((size_t)a.B * a.H * a.W * a.seg[0].stride * 2 >= ((size_t)1 << 32)) return false;            // 32-bit source offsets
   const long items = (long)a.B * (a.H / WD_TH) * (a.W / WD_TW) * (a.cout / WD_BN);
@@ -325,6 +325,7 @@ static int launch_wide_t(WideArgs& w, hipStream_t stream) {
   } while (0)
   if (a.pool_partial) MDIE_WIDE(MDIE_ACT_RELU, false, true);
   else if (a.e.pool) MDIE_WIDE(MDIE_ACT_RELU, true, false);
+  else if (a.e.act == MDIE_ACT_NONE) MDIE_WIDE(MDIE_ACT_NONE, false, false);
   else MDIE_WIDE(MDIE_ACT_RELU, false, false);
 #undef MDIE_WIDE
   MDIE_LAUNCH_CHECK("mdie_conv_fwd");

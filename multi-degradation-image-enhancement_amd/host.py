@@ -415,14 +415,23 @@ class Model:
         losses = build_losses(self.config.get("loss"))
         if len(losses) == 0:
             raise ValueError("training needs at least one usable loss term")
-        opt = torch.optim.Adam(self.network.parameters(), lr=lr)
         scaler = torch.amp.GradScaler("cuda", enabled=str(getattr(self.network, "precision", "fp32")).lower() in ("fp16", "f16", "float16", "half"))
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # One hipGraph per batch shape (train.CapturedStep; MDIE_TRAIN_GRAPH=0 turns it off): forward + loss + backward, and the
+        # Adam step too when nothing has to happen between backward and step (no gradient exchange, no GradScaler check).
+        # (auto: only while a step is launch-bound -- measured on MI355X, bf16, B = 8: 256x256 7.5 -> 5.3 ms per step as a graph,
+        #  512x512 10.9 -> 11.5 ms: ~520 graph nodes cost ~1 us each that eager launching hides behind a GPU-bound step)
+        mode = os.environ.get("MDIE_TRAIN_GRAPH", "auto") if self.device.type == "cuda" else "0"
+        want_graph = (lambda x: mode == "1" or (mode == "auto" and x.shape[0] * x.shape[2] * x.shape[3] <= 8 * 384 * 384))
+        whole = mode != "0" and not distributed and not scaler.is_enabled()      # the Adam step rides in the graph too
+        opt = torch.optim.Adam(self.network.parameters(), lr=lr, capturable=whole)
+        captured = {}
         if distributed:
             # identical replicas: rank 0's parameters and buffers (the seed already makes them equal; this makes it certain)
             for t in list(self.network.parameters()) + list(self.network.buffers()):
                 dist.broadcast(t.data, src=0)
         buckets = T.GradBuckets(self.network.parameters()) if distributed else None
+        hooks_on = buckets is not None
         best = float("inf")
         self.history = []
         for epoch in range(n_epoch):
@@ -433,14 +442,29 @@ class Model:
             sums, n = {}, 0
             for inputs, targets in self.dataloader:
                 x, y = self._to_device(inputs), self._to_device(targets)
-                opt.zero_grad(set_to_none=True)
-                out = self.network(x)
-                total, values = losses(out, y)
-                scaler.scale(total).backward()
-                if buckets is not None:
-                    buckets.finish()     # averaged gradients (RCCL all-reduce launched from the grad hooks during backward)
-                scaler.step(opt)         # (unscales, skips the step on inf/nan; plain opt.step() when disabled)
-                scaler.update()
+                if want_graph(x):
+                    if hooks_on:
+                        buckets.remove()     # a replayed backward fires no hooks: the exchange runs after the replay (GradBuckets.exchange)
+                        hooks_on = False
+                    key = (tuple(x.shape), tuple(y.shape))
+                    if key not in captured:
+                        captured[key] = T.CapturedStep(self.network, losses, opt if whole else None, x, y,
+                                                       scale_fn=scaler.scale if scaler.is_enabled() else None)
+                    values = captured[key](x, y)
+                    if not whole:
+                        if buckets is not None:
+                            buckets.exchange()
+                        scaler.step(opt)
+                        scaler.update()
+                else:
+                    opt.zero_grad(set_to_none=True)
+                    out = self.network(x)
+                    total, values = losses(out, y)
+                    scaler.scale(total).backward()
+                    if buckets is not None:      # averaged gradients: RCCL all-reduce launched from the grad hooks during backward
+                        buckets.finish() if hooks_on else buckets.exchange()
+                    scaler.step(opt)         # (unscales, skips the step on inf/nan; plain opt.step() when disabled)
+                    scaler.update()
                 vals = values.cpu().tolist()  # one sync per step
                 for k, v in zip(losses.names + ["total"], vals):
                     sums[k] = sums.get(k, 0.0) + v
@@ -464,7 +488,7 @@ class Model:
                 row = {"type": "epoch", "epoch": epoch + 1, "epoch_time_sec": time.time() - t0, "lr": lr, "best_loss_so_far": best}
                 row.update({f"loss_{k}": v for k, v in avg.items()})
                 self.logger.log("train", row)
-        if buckets is not None:
+        if hooks_on:
             buckets.remove()
         return self.history
 

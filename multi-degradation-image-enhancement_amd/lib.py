@@ -51,7 +51,7 @@ class BnPoolBwdDesc(C.Structure):
                 ("y", C.c_void_p), ("y_stride", C.c_int),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("pool", C.c_int),
                 ("d_out", C.c_void_p), ("d_out_stride", C.c_int), ("d_drop", C.c_void_p), ("d_drop_stride", C.c_int),
-                ("p", C.c_float), ("seed", C.c_uint), ("dz", C.c_void_p), ("dz_stride", C.c_int),
+                ("p", C.c_float), ("seed", C.c_uint), ("seed_dev", C.c_void_p), ("dz", C.c_void_p), ("dz_stride", C.c_int),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("coef", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
@@ -186,7 +186,7 @@ SIGNATURES = {
     "mdie_bn_fold": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_long,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdie_bn_act_pool_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
-                                       C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_uint, C.c_void_p]),
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_uint, C.c_void_p, C.c_void_p]),
     "mdie_bn_act_pool_bwd": (C.c_int, [C.POINTER(BnPoolBwdDesc), C.c_void_p]),
     "mdie_bn_act_up_add_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

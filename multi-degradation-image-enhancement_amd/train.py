@@ -178,7 +178,7 @@ class _ConvBnFn(torch.autograd.Function):
     """(o, t) = (pool?(relu(bn(conv3x3(x) + b))), dropout(o)); o or t is None when not requested."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, bn, dt, pool, p, seed, need_o, need_t):
+    def forward(ctx, x, weight, bias, gamma, beta, bn, dt, pool, p, seed, need_o, need_t, seed_dev=None):
         B, cin_st, H, W = x.shape
         dev = x.device
         cout, cin = weight.shape[0], weight.shape[1]
@@ -192,11 +192,13 @@ class _ConvBnFn(torch.autograd.Function):
         o = _empty(dt, B, cout, Ho, Wo, dev) if need_o else None
         t = _empty(dt, B, cout, Ho, Wo, dev) if need_t else None
         L.check(L.lib.mdie_bn_act_pool_fwd(dt, B, H, W, cout, y.data_ptr(), cout, k[0].data_ptr(), k[1].data_ptr(), int(pool),
-                                           o.data_ptr() if need_o else None, cout, t.data_ptr() if need_t else None, cout, p, seed, _sp(dev)),
+                                           o.data_ptr() if need_o else None, cout, t.data_ptr() if need_t else None, cout, p, seed,
+                                           seed_dev.data_ptr() if seed_dev is not None else None, _sp(dev)),
                 "mdie_bn_act_pool_fwd")
         ctx.save_for_backward(x, w32, y, k, mv)
         ctx.set_materialize_grads(False)
         ctx.meta = (dt, pool, p, seed, cin, cout, need_o, need_t)
+        ctx.seed_dev = seed_dev
         outs = tuple(v for v in (o, t) if v is not None)
         return outs if len(outs) > 1 else outs[0]
 
@@ -224,6 +226,7 @@ class _ConvBnFn(torch.autograd.Function):
         d.d_out, d.d_out_stride = (d_o.data_ptr(), cout) if d_o is not None else (None, 0)
         d.d_drop, d.d_drop_stride = (d_t.data_ptr(), cout) if d_t is not None else (None, 0)
         d.p, d.seed = p, seed
+        d.seed_dev = ctx.seed_dev.data_ptr() if ctx.seed_dev is not None else None
         d.dz, d.dz_stride = dz.data_ptr(), cout
         d.dgamma, d.dbeta, d.coef = dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), nws
@@ -234,7 +237,7 @@ class _ConvBnFn(torch.autograd.Function):
             dx = _empty(dt, B, cin_st, H, W, dev)
             _conv_raw(dt, [dz], _pack(dt, w32, 3, True, cin, cout, cin_st, cout), _zeros(cin_st, dev), 3, cin_st, dx)
         dw = _wgrad(dt, [x], dz, w32.shape, 3, False, cin, cout, cout)
-        return dx, dw, torch.zeros(cout, dtype=torch.float32, device=dev), dgb[0], dgb[1], None, None, None, None, None, None, None
+        return dx, dw, torch.zeros(cout, dtype=torch.float32, device=dev), dgb[0], dgb[1], None, None, None, None, None, None, None, None
 
 
 class _DenseFn(torch.autograd.Function):
@@ -440,9 +443,21 @@ def conv(dtype, weight, bias, segs, transposed=False):
 
 
 def _tick(net):
-    for name, buf in net.named_buffers():
-        if name.endswith("num_batches_tracked"):
-            buf += 1
+    bufs = [buf for name, buf in net.named_buffers() if name.endswith("num_batches_tracked")]
+    if bufs:
+        torch._foreach_add_(bufs, 1)        # (one or two launches instead of 32)
+
+
+def _dropout_state(net, dev):
+    """(salt, step counter on the device).  The masks of a step are hash(salt + layer, counter, element): the counter
+    lives in device memory and is bumped by a (capturable) kernel once per forward, so a step replayed from a hipGraph
+    draws new masks although every host-side argument of its launches is frozen; the salt comes from torch's CPU
+    generator once per network (torch.manual_seed reproduces a run)."""
+    st = getattr(net, "_mdie_dropout", None)
+    if st is None or st[1].device != dev:
+        st = (int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), torch.zeros(1, dtype=torch.int32, device=dev))
+        net._mdie_dropout = st
+    return st
 
 
 def _dense_params(blk):
@@ -458,9 +473,10 @@ def dense_block(dt, blk, x, real_c, sigmoid=False):
     return _DenseFn.apply(x, blk, dt, real_c, sigmoid, *_dense_params(blk))
 
 
-def conv_block(dt, blk, x, pool, p, need_o=True, need_t=True):
-    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0       # CPU generator: no device sync
-    return _ConvBnFn.apply(x, blk.conv.weight, blk.conv.bias, blk.bn.weight, blk.bn.bias, blk.bn, dt, pool, float(p), seed, need_o, need_t)
+def conv_block(dt, blk, x, pool, p, need_o=True, need_t=True, seed=None, seed_dev=None):
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0       # CPU generator: no device sync
+    return _ConvBnFn.apply(x, blk.conv.weight, blk.conv.bias, blk.bn.weight, blk.bn.bias, blk.bn, dt, pool, float(p), seed, need_o, need_t, seed_dev)
 
 
 def deconv_stage(dt, cv, bn, x, skip, up):
@@ -546,16 +562,20 @@ def forward_train(net, x, precision="fp32", dropout_p=0.2):
         raise L.MdieError(f"forward_train: input must be [B,3,H,W] with H, W multiples of 8, got {tuple(x.shape)}")
     xin = _empty(dt, B, 16, H, W, x.device)
     L.check(L.lib.mdie_nchw3_to_nhwc16(dt, B, H, W, _f32(x).data_ptr(), xin.data_ptr(), _sp(x.device)), "mdie_nchw3_to_nhwc16")
+    salt, counter = (0, None)
+    if dropout_p > 0:
+        salt, counter = _dropout_state(net, x.device)
+        counter += 1                                  # on the device: a new set of masks per step, also under graph replay
     t = xin
     skips, denses = [], []
     for i in (1, 2, 3):
         if dropout_p > 0:
-            o, t = conv_block(dt, getattr(enc, f"conv{i}"), t, True, dropout_p)
+            o, t = conv_block(dt, getattr(enc, f"conv{i}"), t, True, dropout_p, seed=(salt + 7919 * i) & 0x7fffffff, seed_dev=counter)
         else:
             o = t = conv_block(dt, getattr(enc, f"conv{i}"), t, True, 0.0, need_t=False)
         denses.append(dense_block(dt, getattr(enc, f"dense{i}"), o, o.shape[1]))
         skips.append(t)
-    e = conv_block(dt, enc.conv4, t, False, dropout_p, need_o=False)
+    e = conv_block(dt, enc.conv4, t, False, dropout_p, need_o=False, seed=(salt + 7919 * 4) & 0x7fffffff, seed_dev=counter)
     t = cbam(dt, net.bottleneck, e)
     t = deconv_stage(dt, dec.conv1, dec.bn1, t, skips[2], False)
     t = cbam(dt, dec.cbam1, t, denses[2])
@@ -565,6 +585,70 @@ def forward_train(net, x, precision="fp32", dropout_p=0.2):
     t = cbam(dt, dec.cbam3, t, denses[0])
     t = deconv_stage(dt, dec.conv4, dec.bn4, t, xin, True)
     return dense_block(dt, dec.final_dense, t, 3, sigmoid=True)
+
+
+# ---- one training step as a hipGraph (models/model.py:154-172: zero_grad, forward, loss, backward, optimizer step) -------------------
+class CapturedStep:
+    """forward + loss + backward (+ the optimizer step) of ONE batch shape, captured once and replayed.
+
+    An eager step is ~520 kernel launches issued from Python through autograd: below 512x512 the GPU waits for the host.
+    Everything on the step is capturable -- the HIP entry points neither allocate nor synchronise, tensors come from
+    torch's graph-private pool, the dropout counter and BatchNorm's num_batches_tracked are bumped on the device -- so the
+    whole step becomes one graph launch.  `optimizer` must have been built with capturable=True (Adam keeps its step
+    count on the device then); pass optimizer=None to capture forward + loss + backward only (gradient all-reduce and a
+    GradScaler-guarded step then follow the replay in the usual way).
+
+        step = CapturedStep(net, losses, opt, x0, t0)          # eager warm-up on a side stream, then capture
+        values = step(x, t)                                     # device tensor [terms..., total]; ONE graph launch
+
+    Building it leaves the training state untouched: the warm-up passes run forward + backward only and the BatchNorm /
+    dropout buffers they advanced are put back; the optimizer's state is created by one step on all-zero gradients (no
+    parameter moves) whose step count is reset.  `scale_fn` (e.g. GradScaler.scale) is applied to the total loss before
+    backward inside the graph -- the scaler's factor is a device tensor, so replays follow its updates."""
+
+    def __init__(self, net, losses, optimizer, x, t, warmup=2, scale_fn=None):
+        dev = x.device
+        self.net, self.losses, self.opt = net, losses, optimizer
+        self.x, self.t = x.clone(), t.clone()
+
+        def fwd_bwd():
+            total, values = losses(net(self.x), self.t)
+            (scale_fn(total) if scale_fn is not None else total).backward()
+            return values
+
+        targets = list(net.buffers())           # what a training-mode forward advances besides the parameters
+        if getattr(net, "dropout_p", 0.0) > 0:
+            targets.append(_dropout_state(net, dev)[1])
+        saved = [b.detach().clone() for b in targets]
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                net.zero_grad(set_to_none=True)
+                fwd_bwd()
+            if optimizer is not None:           # create the optimizer state outside the capture without moving a parameter
+                for p in net.parameters():
+                    if p.grad is not None:
+                        p.grad.zero_()
+                optimizer.step()
+                for st in optimizer.state.values():
+                    if torch.is_tensor(st.get("step")):
+                        st["step"].zero_()
+            for dst, src in zip(targets, saved):
+                dst.copy_(src)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        net.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.values = fwd_bwd()
+            if optimizer is not None:
+                optimizer.step()
+
+    def __call__(self, x, t):
+        self.x.copy_(x, non_blocking=True)
+        self.t.copy_(t, non_blocking=True)
+        self.graph.replay()
+        return self.values
 
 
 # ---- data-parallel gradient exchange (SURVEY.md 8e) ---------------------------------------------------------------------
@@ -635,6 +719,17 @@ class GradBuckets:
                 off += p.numel()
             self._pending[bi] = len(b)
             self._work[bi] = None
+
+    def exchange(self):
+        """gradients that did not come through the hooks (a captured step replays kernels, not Python): pack every
+        bucket now, all-reduce, average, unpack"""
+        self._pending = [len(b) for b in self.buckets]
+        self._work = [None] * len(self.buckets)
+        for b in self.buckets:
+            for p in b:
+                if p.grad is not None:
+                    self._on_grad(p)
+        self.finish()
 
     def remove(self):
         for h in self._hooks:

@@ -1324,6 +1324,48 @@ def test_whole_network_training_step_vs_oracle(E, precision, shape, min_cos, med
     assert worst[0] >= min_cos and median >= med_cos, (worst, median)
 
 
+def test_captured_training_step_equals_eager_steps(E):
+    """train.CapturedStep: forward + loss + backward + Adam as ONE hipGraph.  Two nets from the same checkpoint and the same
+    dropout salt take 3 steps on changing batches, one eagerly, one by graph replay: parameters, BatchNorm buffers and
+    losses must agree bit for bit (the dropout counter lives on the device, so every replay draws the masks the eager step
+    of the same index draws), and building the graph must not have moved the training state."""
+    from models.cdan import CDAN
+    from mdie_amd import host as H
+    from mdie_amd import train as T
+    from oracle import params as P
+    sd = P.make_state_dict(42)
+    losses = H.build_losses({"enabled": True, "terms": [{"name": "charbonnier", "weight": 1.0}, {"name": "ssim", "weight": 0.5}]})
+    batches = [tuple(v.cuda() for v in P.lowlight_batch(60 + i, 2, 32, 32)) for i in range(3)]
+    runs = []
+    for mode in ("eager", "graph"):
+        torch.manual_seed(5)
+        net = CDAN(precision="bf16")
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+        vals = []
+        if mode == "graph":
+            before = [b.clone() for b in net.buffers()] + [p.detach().clone() for p in net.parameters()]
+            step = T.CapturedStep(net, losses, opt, *batches[0])
+            after = [b for b in net.buffers()] + [p.detach() for p in net.parameters()]
+            assert all(torch.equal(a, b) for a, b in zip(before, after)), "building the graph moved the training state"
+            for x, t in batches:
+                vals.append(step(x, t).clone())
+        else:
+            for x, t in batches:
+                opt.zero_grad(set_to_none=True)
+                total, v = losses(net(x), t)
+                total.backward()
+                opt.step()
+                vals.append(v.clone())
+        torch.cuda.synchronize()
+        runs.append((vals, [p.detach().clone() for p in net.parameters()], [b.clone() for b in net.buffers()]))
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][0], runs[1][0])), "loss values differ"
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1])), "parameters differ after 3 steps"
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2])), "BatchNorm buffers differ"
+    assert not torch.equal(runs[1][0][0], runs[1][0][1])
+
+
 def test_training_step_is_bitwise_reproducible(E):
     """same seed, same batch -> bit-identical loss and gradients (ordered reductions everywhere, counter-based dropout)"""
     from models.cdan import CDAN

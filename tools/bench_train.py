@@ -1,17 +1,27 @@
 #!/usr/bin/env python3
-"""Training-step timing (BASELINE configs[2] shape: blur-style loss, 512x512, batch 8 per GPU).
-  python tools/bench_train.py [bf16|fp32] [B] [S] [loss terms, e.g. charbonnier:1,ssim:0.5]      (under torchrun: one rank per GPU, bucketed RCCL all-reduce)"""
+"""Training-step timing (BASELINE configs[2] shape: blur-style loss, 512x512, batch 8 per GPU), eager and as one hipGraph.
+  python tools/bench_train.py [bf16|fp16|fp32] [B] [S] [loss terms, e.g. charbonnier:1,ssim:0.5] [eager|graph|both]
+  (under torchrun: one rank per GPU, bucketed RCCL all-reduce; the graph then holds forward + loss + backward and the
+   exchange + Adam step follow the replay)
+
+Roofline model of the step (stated, not measured): FLOPs = 3 x the forward's (forward, input-gradient and weight-gradient
+GEMMs of every convolution; `mdie_cdan_flops`); HBM bytes = 3 x the forward's fused-schedule activation bytes
+(`mdie_cdan_algorithmic_bytes`: each of the three GEMM families reads its operands and writes its result once) + 16 bytes
+per parameter per step (fp32 weight read, gradient write + read, Adam's two moments read + written, weight written)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from models.cdan import CDAN
 from mdie_amd import host as H
+from mdie_amd import lib as L
 from mdie_amd import train as T
 from mdie_amd import synthetic as P
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+spec = sys.argv[4] if len(sys.argv) > 4 else "charbonnier:1,ssim:0.5"
+modes = {"both": ["eager", "graph"]}.get(sys.argv[5] if len(sys.argv) > 5 else "both", [sys.argv[5]] if len(sys.argv) > 5 else [])
 rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 torch.cuda.set_device(local)
 dist = None
@@ -19,33 +29,55 @@ if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("nccl")
-torch.manual_seed(42)
-net = CDAN(precision=prec).cuda().train()
 x, t = P.lowlight_batch(100 + rank, B, S, S)
 x, t = x.cuda(), t.cuda()
-spec = sys.argv[4] if len(sys.argv) > 4 else "charbonnier:1,ssim:0.5"
 losses = H.build_losses({"enabled": True, "terms": [{"name": s.split(":")[0], "weight": float(s.split(":")[1])} for s in spec.split(",")]})
-opt = torch.optim.Adam(net.parameters(), lr=1e-3)
-buckets = T.GradBuckets(net.parameters()) if dist is not None else None
+esz = 4 if prec == "fp32" else 2
+flops = 3.0 * L.lib.mdie_cdan_flops(B, S, S)
+byts = 3.0 * L.lib.mdie_cdan_algorithmic_bytes(B, S, S, esz) + 16.0 * 3585663
+peak_tf = 157.3 if prec == "fp32" else 2500.0
 
-def step():
-    opt.zero_grad(set_to_none=True)
-    out = net(x)
-    total, _ = losses(out, t)
-    total.backward()
-    if buckets is not None:
-        buckets.finish()
-    opt.step()
-    return total
+for mode in modes:
+    torch.manual_seed(42)
+    net = CDAN(precision=prec).cuda().train()
+    scaler = torch.amp.GradScaler("cuda", enabled=prec == "fp16")
+    whole = mode == "graph" and dist is None and not scaler.is_enabled()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=whole)
+    buckets = T.GradBuckets(net.parameters()) if dist is not None else None
+    if mode == "graph":
+        if buckets is not None:
+            buckets.remove()
+        cap = T.CapturedStep(net, losses, opt if whole else None, x, t, scale_fn=scaler.scale if scaler.is_enabled() else None)
 
-for _ in range(3):
-    l = step()
-torch.cuda.synchronize()
-n = 10
-t0 = time.perf_counter()
-for _ in range(n):
-    l = step()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / n
-if rank == 0:
-    print(f"train[{prec}] B={B}x{world} {S}x{S} loss={spec}: {dt*1e3:.1f} ms/step, {B*world/dt:.1f} img/s, loss {l.item():.4f}")
+        def step():
+            v = cap(x, t)
+            if not whole:
+                if buckets is not None:
+                    buckets.exchange()
+                scaler.step(opt)
+                scaler.update()
+            return v[-1]
+    else:
+        def step():
+            opt.zero_grad(set_to_none=True)
+            total, _ = losses(net(x), t)
+            scaler.scale(total).backward()
+            if buckets is not None:
+                buckets.finish()
+            scaler.step(opt)
+            scaler.update()
+            return total
+
+    for _ in range(3):
+        l = step()
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        l = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    if rank == 0:
+        print(f"train[{prec},{mode}] B={B}x{world} {S}x{S} loss={spec}: {dt*1e3:.2f} ms/step, {B*world/dt:.1f} img/s, loss {l.item():.4f} | "
+              f"model: {flops/1e9:.0f} GFLOP, {byts/1e9:.2f} GB per rank-step -> {flops/dt/1e12:.0f} TFLOP/s = {flops/dt/1e12/peak_tf:.3f} of the {prec} MFMA peak, "
+              f"{byts/dt/1e9:.0f} GB/s = {byts/dt/8e12:.3f} of 8 TB/s")
