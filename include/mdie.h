@@ -284,6 +284,24 @@ enum { MDIE_TAP_SKIP0 = 0, MDIE_TAP_SKIP1, MDIE_TAP_SKIP2, MDIE_TAP_DENSE0, MDIE
        MDIE_TAP_DENSE2, MDIE_TAP_ENC, MDIE_TAP_BOTT, MDIE_TAP_DEC1, MDIE_TAP_DEC2, MDIE_TAP_DEC3,
        MDIE_TAP_DEC4, MDIE_TAP_COUNT };
 
+/* Last decoder stage + first layer of decoder.final_dense in one launch (models/cdan.py:153-155 and DenseBlock layer 0,
+ * :35-36,41-46):  base = bilinear_x2(lo)[:, :3] + x ;  g0 = conv3x3(relu(base * pre_scale + pre_shift)) + bias.
+ * K = 27 is one 32-deep MFMA step per 16 pixels (csrc/updense0.hip).  `weight` is the layer's [16,3,3,3] weight in
+ * mdie_pack_conv_first_weight's layout (cout_stored = 16); `base` gets base_channels (16, or one 16-byte group) stored
+ * channels per pixel, channels 3.. zero; g0 is written with 16 channels at pixel stride g0_stride. */
+typedef struct {
+  int dtype;
+  int B, H, W;                 /* output extent; lo is [B, H/2, W/2, >= 4 channels] */
+  const void* lo; int lo_stride;
+  const float* x;              /* fp32 NCHW [B,3,H,W] */
+  void* base; int base_channels;
+  const void* weight;
+  const float* pre_scale; const float* pre_shift;   /* >= 3 entries */
+  const float* bias;           /* [16] */
+  void* g0; int g0_stride;
+} mdie_up_dense0_desc;
+int mdie_up_add_dense0_fwd(const mdie_up_dense0_desc* d, void* stream);
+
 /* Concurrency of the three encoder DenseBlocks.  dense_k depends only on the pooled block output
  * o_k and is first consumed by the decoder (`out *= denses[k]`, models/cdan.py:133,141,149), so the
  * plan runs it beside the main chain from right after conv_k until the matching decoder CBAM:

@@ -95,6 +95,7 @@ struct CbamBlob { size_t w1, b1, w2, b2, w7, bn; };
 struct BlobLayout {
   ConvBlob conv[CV_COUNT];
   CbamBlob cbam[CB_COUNT];
+  size_t fl0_w;  // decoder.final_dense layer 0 once more, im2col-packed (k = tap*3 + c) for mdie_up_add_dense0_fwd
   size_t tail;   // mdie_tail_pack_params("decoder.final_dense")
   size_t total;
 };
@@ -128,6 +129,7 @@ static BlobLayout blob_layout(int dtype) {
     L.cbam[i].w7 = take(98 * sizeof(float));
     L.cbam[i].bn = take(2 * sizeof(float));
   }
+  L.fl0_w = take(first_weight_bytes(dtype, 16));
   L.tail = take(mdie_tail_param_bytes(dtype));
   L.total = off;
   return L;
@@ -303,6 +305,7 @@ extern "C" int mdie_cdan_pack_params(int dtype, const mdie_tensor* tensors, int 
     const float* b = T.get(s.b_key, s.cout);
     if (!w || !b) return MDIE_ENOENT;
     if (i == CV_E1) pack_first_weight(dtype, w, s.cout, s.cout_st, blob + L.conv[i].w);
+    else if (i == CV_DENSE0 + 3 * 5) { pack_first_weight(dtype, w, s.cout, s.cout_st, blob + L.fl0_w); pack_conv_weight(dtype, s.ks, s.transposed, w, s.cout, s.cin, s.cout_st, s.cin_st, s.split, s.gap, blob + L.conv[i].w); }
     else pack_conv_weight(dtype, s.ks, s.transposed, w, s.cout, s.cin, s.cout_st, s.cin_st, s.split, s.gap, blob + L.conv[i].w);
     float* ps = reinterpret_cast<float*>(blob + L.conv[i].post_scale);
     float* pt = reinterpret_cast<float*>(blob + L.conv[i].post_shift);
@@ -427,10 +430,10 @@ static int run_conv(const Ctx& c, int id, int H, int W, std::initializer_list<Bu
 }
 
 static int run_dense(const Ctx& c, int block, int H, int W, const Buf& base, const Buf* g, const Buf& out, int act,
-                     float* out_nchw3 = nullptr) {
+                     float* out_nchw3 = nullptr, bool have_g0 = false) {
   const int id0 = CV_DENSE0 + block * 5;
   int e;
-  if ((e = run_conv(c, id0 + 0, H, W, {base}, g[0], MDIE_ACT_NONE, 0, nullptr))) return e;
+  if (!have_g0 && (e = run_conv(c, id0 + 0, H, W, {base}, g[0], MDIE_ACT_NONE, 0, nullptr))) return e;
   if ((e = run_conv(c, id0 + 1, H, W, {base, g[0]}, g[1], MDIE_ACT_NONE, 0, nullptr))) return e;
   if ((e = run_conv(c, id0 + 2, H, W, {base, g[0], g[1]}, g[2], MDIE_ACT_NONE, 0, nullptr))) return e;
   if ((e = run_conv(c, id0 + 3, H, W, {base, g[0], g[1], g[2]}, g[3], MDIE_ACT_NONE, 0, nullptr))) return e;
@@ -621,8 +624,23 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   RUN(run_conv(c, CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
   if (!(d->flags & MDIE_FWD_FUSED_TAIL)) {
     // bilinear x2 + x (x read from its fp32 NCHW planes), final_dense, sigmoid written straight to NCHW
-    RUN(mdie_upsample2x_add_nchw3(d->dtype, B, h1, w1, c.ws + P.t4lo.off, P.t4lo.C, d->x, c.ws + P.t4.off, P.t4.C, stream));
-    RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID, d->y));
+    static const bool split_l0 = getenv("MDIE_FUSED_L0") && atoi(getenv("MDIE_FUSED_L0")) == 0;   // experiments: the two-launch form
+    if (split_l0) {
+      RUN(mdie_upsample2x_add_nchw3(d->dtype, B, h1, w1, c.ws + P.t4lo.off, P.t4lo.C, d->x, c.ws + P.t4.off, P.t4.C, stream));
+    } else {   // upsample + x and final_dense layer 0 in one launch (csrc/updense0.hip)
+      const int id0 = CV_DENSE0 + 3 * 5;
+      mdie_up_dense0_desc u{};
+      u.dtype = d->dtype; u.B = B; u.H = H; u.W = W;
+      u.lo = c.ws + P.t4lo.off; u.lo_stride = P.t4lo.C; u.x = d->x;
+      u.base = c.ws + P.t4.off; u.base_channels = P.t4.C;
+      u.weight = c.params + c.L.fl0_w;
+      u.pre_scale = reinterpret_cast<const float*>(c.params + c.L.conv[id0].pre_scale);
+      u.pre_shift = reinterpret_cast<const float*>(c.params + c.L.conv[id0].pre_shift);
+      u.bias = reinterpret_cast<const float*>(c.params + c.L.conv[id0].post_shift);
+      u.g0 = c.ws + P.fg[0].off; u.g0_stride = P.fg[0].C;
+      RUN(mdie_up_add_dense0_fwd(&u, stream));
+    }
+    RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID, d->y, !split_l0));
   } else {
     mdie_tail_desc t{};
     t.dtype = d->dtype; t.B = B; t.H = H; t.W = W;

@@ -1,0 +1,226 @@
+// Last decoder stage into the first layer of decoder.final_dense, one launch:
+//     base = bilinear_x2(t4)[:, :3] + x                      (models/cdan.py:153-154)
+//     g0   = conv3x3(relu(bn0(base)))                        (DenseBlock layer 0, models/cdan.py:35-36,41-46,155)
+// `base` is still written (layers 1-3 and the transition read it), as ONE 16-byte channel group per pixel; g0 is the
+// block's first 16-channel growth map.
+//
+// Why fused.  Both steps live on 3 real channels at full resolution.  As two launches (upsample2x_add_nchw3 + conv_kernel
+// with the base padded to one 16-byte K group) they cost 24 + 45 us at B = 32, 256x256, bf16 -- nine K = 32 MFMAs and nine
+// LDS fragment reads per 16 pixels on 3 channels, a second staging pass over a tensor the first launch had in registers.
+// Here the tile's 18x18 base patch is computed straight from t4 (4 taps, channels 0..3 in one load each) and the fp32 NCHW
+// input planes, activated and laid out [pixel][4] in LDS; K = 9 taps x 3 channels = 27 is im2col'ed into ONE 32-deep MFMA
+// step per 16 pixels (two 16-deep steps in fp32), exactly as conv_first_kernel does for encoder.conv1.  The halo ring of
+// the patch is recomputed by the neighbouring tiles (324 / 256 pixels): cheaper than a round trip through HBM.
+// Arithmetic is kept identical to the unfused pair: the base is rounded to the storage type before the pre-activation,
+// the pre-activation is one fused multiply-add rounded once, zero padding applies to the ACTIVATED tensor.
+#include "common.hpp"
+
+#pragma clang fp contract(off)   // (the interpolation must round like upsample2x_add_nchw3's, resample.hip)
+
+namespace mdie {
+
+constexpr int UD_THREADS = 256;
+constexpr int UD_TILE = 16, UD_PW = UD_TILE + 2;
+
+struct UpDense0Args {
+  int B, H, W;                    // OUTPUT extent (= network input extent); t4 is H/2 x W/2
+  const char* lo; int lo_stride;  // decoder.conv4 output, NHWC, >= 4 stored channels per pixel
+  const float* x;                 // network input, fp32 NCHW [B,3,H,W]
+  char* base; int base_ch;        // out: NHWC, base_ch stored channels per pixel (one 16-byte group, or 16)
+  const char* weight;             // mdie_pack_conv_first_weight layout: [step][16][64 B], k = tap*3 + c
+  const float *pre_scale, *pre_shift;   // folded BatchNorm of dense layer 0, >= 3 entries
+  const float* bias;              // [16]
+  char* g0; int g0_stride;        // out: NHWC, 16 channels
+};
+
+__device__ __forceinline__ void ud_src(int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {   // = resample.hip src_index
+  float src = ((float)dst + 0.5f) * 0.5f - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+template <typename T> __device__ __forceinline__ f32x4 ud_mma(const uint4& w, const uint4& x, f32x4 acc);
+template <> __device__ __forceinline__ f32x4 ud_mma<bf16>(const uint4& w, const uint4& x, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 ud_mma<f16>(const uint4& w, const uint4& x, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 ud_mma<float>(const uint4& w, const uint4& x, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
+  return acc;
+}
+
+template <typename T, int BASE_CH>
+__global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0Args a) {
+  constexpr int E = sizeof(T);
+  constexpr int VEC = Traits<T>::VEC;
+  constexpr int STEPS = E == 2 ? 1 : 2;
+  constexpr int NPS = 4;
+  constexpr int PW = UD_PW;
+  __shared__ __attribute__((aligned(16))) T patch[PW * PW * 4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lp = lane & 15;
+  int bid = blockIdx.x;
+  const int tiles_x = (a.W + UD_TILE - 1) / UD_TILE, tiles_y = (a.H + UD_TILE - 1) / UD_TILE;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; bid /= tiles_y;
+  const int img = bid;
+  const int y0 = ty * UD_TILE, x0 = tx * UD_TILE;
+
+  // weight fragments and constants first: they land while the patch is computed
+  uint4 wf[STEPS];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) wf[s] = *reinterpret_cast<const uint4*>(a.weight + ((size_t)s * 16 + lp) * 64 + lq * 16);
+  const float4 bias = *reinterpret_cast<const float4*>(a.bias + lq * 4);
+  const float ps0 = a.pre_scale[0], ps1 = a.pre_scale[1], ps2 = a.pre_scale[2];
+  const float pb0 = a.pre_shift[0], pb1 = a.pre_shift[1], pb2 = a.pre_shift[2];
+
+  // ---- the tile's base patch: every load of both iterations is issued before the first use ----
+  const int Hl = a.H >> 1, Wl = a.W >> 1;
+  const size_t plane = (size_t)a.H * a.W;
+  constexpr int PIT = (PW * PW + UD_THREADS - 1) / UD_THREADS;
+  float t[PIT][4][4], xin[PIT][3], hy[PIT][2], wx[PIT][2];
+  bool inside[PIT];
+#pragma unroll
+  for (int it = 0; it < PIT; ++it) {
+    const int p = tid + it * UD_THREADS;
+    const int py = p / PW, px = p - py * PW;
+    const int gy = y0 + py - 1, gx = x0 + px - 1;
+    inside[it] = p < PW * PW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t[it][k][c] = 0.f;
+    xin[it][0] = xin[it][1] = xin[it][2] = 0.f;
+    hy[it][0] = hy[it][1] = wx[it][0] = wx[it][1] = 0.f;
+    if (inside[it]) {
+      int ya, yb, xa, xb;
+      ud_src(gy, Hl, ya, yb, hy[it][0], hy[it][1]);
+      ud_src(gx, Wl, xa, xb, wx[it][0], wx[it][1]);
+      const char* lb = a.lo + (size_t)img * Hl * Wl * a.lo_stride * E;
+      const char* q[4] = {lb + ((size_t)ya * Wl + xa) * a.lo_stride * E, lb + ((size_t)ya * Wl + xb) * a.lo_stride * E,
+                          lb + ((size_t)yb * Wl + xa) * a.lo_stride * E, lb + ((size_t)yb * Wl + xb) * a.lo_stride * E};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if constexpr (E == 2) {
+          const uint2 u = *reinterpret_cast<const uint2*>(q[k]);
+          t[it][k][0] = Half<T>::lo(u.x); t[it][k][1] = Half<T>::hi(u.x); t[it][k][2] = Half<T>::lo(u.y);
+        } else {
+          const float4 u = *reinterpret_cast<const float4*>(q[k]);
+          t[it][k][0] = u.x; t[it][k][1] = u.y; t[it][k][2] = u.z;
+        }
+      }
+      const float* xp = a.x + (size_t)img * 3 * plane + (size_t)gy * a.W + gx;
+      xin[it][0] = xp[0]; xin[it][1] = xp[plane]; xin[it][2] = xp[2 * plane];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < PIT; ++it) {
+    const int p = tid + it * UD_THREADS;
+    if (p < PW * PW) {
+      const int py = p / PW, px = p - py * PW;
+      float f[3], act[3];
+      const float ps[3] = {ps0, ps1, ps2}, pb[3] = {pb0, pb1, pb2};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        f[c] = hy[it][0] * (wx[it][0] * t[it][0][c] + wx[it][1] * t[it][1][c]) + hy[it][1] * (wx[it][0] * t[it][2][c] + wx[it][1] * t[it][3][c]) + xin[it][c];
+        if constexpr (E == 2) f[c] = (float)(T)f[c];                 // the stored base: what the unfused layer 0 would read back
+        act[c] = inside[it] ? fmaxf(fmaf(f[c], ps[c], pb[c]), 0.f) : 0.f;   // zero padding of the ACTIVATED tensor
+      }
+      T* d = patch + p * 4;
+      if constexpr (E == 2) *reinterpret_cast<uint2*>(d) = make_uint2(Half<T>::pack(act[0], act[1]), Half<T>::pack(act[2], 0.f));
+      else *reinterpret_cast<float4*>(d) = make_float4(act[0], act[1], act[2], 0.f);
+      if (inside[it] && py >= 1 && py <= UD_TILE && px >= 1 && px <= UD_TILE) {   // this tile's own pixels: the base tensor
+        float o[BASE_CH];
+#pragma unroll
+        for (int c = 0; c < BASE_CH; ++c) o[c] = c < 3 ? f[c] : 0.f;
+        uint4* dst = reinterpret_cast<uint4*>(a.base + (((size_t)img * a.H + (y0 + py - 1)) * a.W + (x0 + px - 1)) * BASE_CH * E);
+#pragma unroll
+        for (int v = 0; v < BASE_CH / VEC; ++v) dst[v] = Vec16<T>::pack(o + v * VEC);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- im2col gather (k = tap*3 + c) and one MFMA step per 16 pixels ----
+  constexpr int KPL = 16 / E;
+  int goff[STEPS][KPL];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+      const int k = (E == 2 ? 8 * lq : 16 * s + 4 * lq) + i;
+      const int tap = k / 3, c = k - tap * 3;
+      goff[s][i] = tap < 9 ? ((tap / 3) * PW + (tap % 3)) * 4 + c : 3;   // k >= 27: the zero channel of the pixel
+    }
+#pragma unroll
+  for (int ps = 0; ps < NPS; ++ps) {
+    const int blk = (wave * NPS + ps) * 4 + (lp >> 2);
+    const int y = 2 * (blk / (UD_TILE / 2)) + ((lp >> 1) & 1), x = 2 * (blk % (UD_TILE / 2)) + (lp & 1);
+    const T* bp = patch + (y * PW + x) * 4;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      uint4 xf;
+      if constexpr (E == 2) {
+        uint32_t h[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = *reinterpret_cast<const unsigned short*>(bp + goff[s][i]);
+        xf = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+      } else {
+        uint32_t h[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = *reinterpret_cast<const uint32_t*>(bp + goff[s][i]);
+        xf = make_uint4(h[0], h[1], h[2], h[3]);
+      }
+      acc = ud_mma<T>(wf[s], xf, acc);
+    }
+    const int gy = y0 + y, gx = x0 + x;
+    if (gy < a.H && gx < a.W) {     // lane: output channels 4 lq .. 4 lq + 3 of this pixel
+      const float v0 = acc[0] + bias.x, v1 = acc[1] + bias.y, v2 = acc[2] + bias.z, v3 = acc[3] + bias.w;
+      char* dst = a.g0 + (((size_t)img * a.H + gy) * a.W + gx) * a.g0_stride * E + lq * 4 * E;
+      if constexpr (E == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(Half<T>::pack(v0, v1), Half<T>::pack(v2, v3));
+      else *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
+    }
+  }
+}
+
+}  // namespace mdie
+
+using namespace mdie;
+
+extern "C" int mdie_up_add_dense0_fwd(const mdie_up_dense0_desc* d, void* stream) {
+  MDIE_REQUIRE(d != nullptr, "mdie_up_add_dense0_fwd: null descriptor");
+  MDIE_REQUIRE(dtype_valid(d->dtype), "mdie_up_add_dense0_fwd: bad dtype %d", d->dtype);
+  MDIE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0, "mdie_up_add_dense0_fwd: extent %dx%dx%d (H, W even)", d->B, d->H, d->W);
+  MDIE_REQUIRE(d->lo && d->x && d->base && d->weight && d->pre_scale && d->pre_shift && d->bias && d->g0, "mdie_up_add_dense0_fwd: null pointer");
+  const int vec = dtype_vec(d->dtype);
+  MDIE_REQUIRE(d->lo_stride >= 4 && d->lo_stride % 4 == 0 && ((uintptr_t)d->lo & 15) == 0,
+               "mdie_up_add_dense0_fwd: lo must be 16-byte aligned with a pixel stride that is a multiple of 4 channels (%d)", d->lo_stride);
+  MDIE_REQUIRE(d->base_channels == 16 || d->base_channels == vec, "mdie_up_add_dense0_fwd: base_channels %d (16 or %d)", d->base_channels, vec);
+  MDIE_REQUIRE(d->g0_stride >= 16 && d->g0_stride % 4 == 0 && (((uintptr_t)d->g0 | (uintptr_t)d->base | (uintptr_t)d->weight) & 15) == 0,
+               "mdie_up_add_dense0_fwd: g0_stride %d / alignment", d->g0_stride);
+  UpDense0Args a{};
+  a.B = d->B; a.H = d->H; a.W = d->W;
+  a.lo = reinterpret_cast<const char*>(d->lo); a.lo_stride = d->lo_stride;
+  a.x = d->x;
+  a.base = reinterpret_cast<char*>(d->base); a.base_ch = d->base_channels;
+  a.weight = reinterpret_cast<const char*>(d->weight);
+  a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift; a.bias = d->bias;
+  a.g0 = reinterpret_cast<char*>(d->g0); a.g0_stride = d->g0_stride;
+  const int grid = cdiv(d->W, UD_TILE) * cdiv(d->H, UD_TILE) * d->B;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  TimedLaunch tl(MDIE_K_CONV3);
+  MDIE_SWITCH_T(d->dtype,
+    if (d->base_channels == 16) hipLaunchKernelGGL((up_dense0_kernel<T, 16>), dim3(grid), dim3(UD_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((up_dense0_kernel<T, Traits<T>::VEC>), dim3(grid), dim3(UD_THREADS), 0, s, a));
+  MDIE_LAUNCH_CHECK("mdie_up_add_dense0_fwd");
+  return MDIE_OK;
+}

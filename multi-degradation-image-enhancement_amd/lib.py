@@ -97,6 +97,12 @@ class ConvFirstDesc(C.Structure):
                 ("act", C.c_int), ("pool", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int)]
 
 
+class UpDense0Desc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("lo", C.c_void_p), ("lo_stride", C.c_int),
+                ("x", C.c_void_p), ("base", C.c_void_p), ("base_channels", C.c_int), ("weight", C.c_void_p),
+                ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("bias", C.c_void_p), ("g0", C.c_void_p), ("g0_stride", C.c_int)]
+
+
 class CbamDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
                 ("x", C.c_void_p), ("x_stride", C.c_int),
@@ -149,6 +155,7 @@ SIGNATURES = {
     "mdie_conv_first_fwd": (C.c_int, [C.POINTER(ConvFirstDesc), C.c_void_p]),
     "mdie_conv_first_weight_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mdie_pack_conv_first_weight": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "mdie_up_add_dense0_fwd": (C.c_int, [C.POINTER(UpDense0Desc), C.c_void_p]),
     "mdie_cbam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mdie_cbam_fwd": (C.c_int, [C.POINTER(CbamDesc), C.c_void_p]),
     "mdie_cbam_channel_only_fwd": (C.c_int, [C.POINTER(CbamDesc), C.c_void_p]),

@@ -395,6 +395,46 @@ def test_upsample_nchw3_last_stage(E, L):
         assert L.lib.mdie_upsample2x_add_nchw3(dt, 2, 9, 7, lo.data_ptr() + 8, 16, x.data_ptr(), out.data_ptr(), oc, None) != 0
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_upsample_into_first_dense_layer_fused(E, L, precision):
+    """mdie_up_add_dense0_fwd (csrc/updense0.hip): bilinear x2 + x and layer 0 of decoder.final_dense in one launch, K = 27
+    im2col'ed into one MFMA step.  The base tensor it writes must equal upsample2x_add_nchw3's bit for bit; g0 is checked
+    against torch's CPU convolution of the activated base (ragged extent, zero padding of the ACTIVATED tensor)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    dt, td = E.dtype_id(precision), TORCH_DT[precision]
+    vec = 4 if precision == "fp32" else 8
+    g = torch.Generator().manual_seed(21)
+    B, H, W = 3, 40, 56
+    lo = torch.randn(B, H // 2, W // 2, 16, generator=g).cuda().to(td)
+    x = torch.rand(B, 3, H, W, generator=g).cuda()
+    w = torch.randn(16, 3, 3, 3, generator=g) * 0.3
+    ps, pb, bias = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.3, torch.randn(16, generator=g)
+    wp = torch.zeros(L.lib.mdie_conv_first_weight_bytes(dt, 16), dtype=torch.uint8)
+    wn = np.ascontiguousarray(w.numpy())
+    L.check(L.lib.mdie_pack_conv_first_weight(dt, wn.ctypes.data, 16, 16, wp.data_ptr()), "pack")
+    wp, dps, dpb, dbias = wp.cuda(), ps.cuda(), pb.cuda(), bias.cuda()
+    base_ref = torch.full((B, H, W, vec), 5.0, device="cuda", dtype=td)
+    L.check(L.lib.mdie_upsample2x_add_nchw3(dt, B, H // 2, W // 2, lo.data_ptr(), 16, x.data_ptr(), base_ref.data_ptr(), vec, None), "nchw3")
+    base = torch.full((B, H, W, vec), 5.0, device="cuda", dtype=td)
+    g0 = torch.full((B, H, W, 32), -7.0, device="cuda", dtype=td)
+    d = L.UpDense0Desc()
+    d.dtype, d.B, d.H, d.W = dt, B, H, W
+    d.lo, d.lo_stride, d.x = lo.data_ptr(), 16, x.data_ptr()
+    d.base, d.base_channels, d.weight = base.data_ptr(), vec, wp.data_ptr()
+    d.pre_scale, d.pre_shift, d.bias = dps.data_ptr(), dpb.data_ptr(), dbias.data_ptr()
+    d.g0, d.g0_stride = g0[..., 8:].data_ptr(), 32        # a 16-channel slice of a wider buffer
+    L.check(L.lib.mdie_up_add_dense0_fwd(C.byref(d), None), "mdie_up_add_dense0_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(base, base_ref)
+    rnd = lambda t: t.to(td).float()
+    b3 = base_ref[..., :3].float().cpu().permute(0, 3, 1, 2)
+    act = rnd(torch.relu(b3 * ps[:3].view(1, 3, 1, 1) + pb[:3].view(1, 3, 1, 1)))
+    ref = F.conv2d(act, rnd(w), bias, padding=1).permute(0, 2, 3, 1)
+    assert rel_to_max(g0[..., 8:24], ref) <= {"fp32": 2e-5, "bf16": 8e-3, "fp16": 1e-3}[precision]
+    assert (g0[..., :8] == -7.0).all() and (g0[..., 24:] == -7.0).all()
+
+
 def test_conv_rejects_bad_arguments(E, L):
     x = torch.zeros(1, 4, 4, 16, device="cuda")
     w = torch.zeros(L.lib.mdie_conv_weight_bytes(L.F32, 3, 16, 16), dtype=torch.uint8, device="cuda")
