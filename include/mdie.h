@@ -441,6 +441,13 @@ typedef struct {
   int nseg; mdie_seg x[MDIE_MAX_SEG];     /* the normalised tensor (a concatenation of segments) */
   mdie_seg g[MDIE_MAX_SEG];               /* apply: destination, same partition */
   unsigned accumulate;
+  /* optional fp32 accumulators for 16-bit tensors (a DenseBlock segment collects the gradients of up to five consuming
+   * layers: summing them in bf16 would round five times).  acc32[s].ptr != NULL: running sums of segment s live in
+   * acc32[s] (fp32, same channel count); `accumulate` then says whether acc32[s] already holds earlier contributions.
+   * Channels >= final_from[s] of the segment receive their LAST contribution in this call and are written to g[s] in
+   * `dtype`; the channels below stay in acc32[s]. */
+  mdie_seg acc32[MDIE_MAX_SEG];
+  int final_from[MDIE_MAX_SEG];
   const void* da; int da_stride;
   const float *mean, *invstd, *scale, *shift;
   int relu;

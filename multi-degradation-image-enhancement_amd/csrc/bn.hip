@@ -420,6 +420,8 @@ struct BnBwdArgs {
   SegP x[MDIE_MAX_SEG];
   SegW g[MDIE_MAX_SEG];          // gradient destination, same channel partition as x (apply only)
   unsigned accumulate;            // bit s: g[s] += instead of =
+  SegW acc32[MDIE_MAX_SEG];      // optional fp32 running sums (ptr = nullptr: none); see mdie_bn_bwd_desc
+  int final_from[MDIE_MAX_SEG];
   const char* da; int da_stride;
   int C;
   const float *mean, *invstd, *scale, *shift;
@@ -491,12 +493,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnBwdArg
   const int v = m.cv, c0 = v * VEC;
   const char* xb = nullptr; int xs = 0;
   char* gb = nullptr; int gs = 0; bool acc = false;
+  float* sb = nullptr; int ss = 0; bool fin = true;     // fp32 running sums of this thread's channels; fin: write the final T value
 #pragma unroll
   for (int k = 0; k < MDIE_MAX_SEG; ++k)
     if (k < a.nseg && c0 >= a.x[k].ch_begin && c0 < a.x[k].ch_end) {
       xb = a.x[k].ptr + (size_t)(c0 - a.x[k].ch_begin) * sizeof(T); xs = a.x[k].stride;
       gb = a.g[k].ptr + (size_t)(c0 - a.g[k].ch_begin) * sizeof(T); gs = a.g[k].stride;
       acc = (a.accumulate >> k) & 1u;
+      if (a.acc32[k].ptr) {
+        sb = reinterpret_cast<float*>(a.acc32[k].ptr) + (c0 - a.x[k].ch_begin); ss = a.acc32[k].stride;
+        fin = (c0 - a.x[k].ch_begin) >= a.final_from[k];
+      }
     }
   float sc[VEC], sh[VEC], mu[VEC], is[VEC], k2[VEC], k3[VEC];
 #pragma unroll
@@ -507,13 +514,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnBwdArg
   const long b = (long)blockIdx.x * a.chunk, e = min(a.N, b + a.chunk);
   // Streaming loop, software-pipelined: the 2-3 loads of the NEXT pixel are requested before the current one is combined and
   // stored (past the end they re-read the thread's first pixel; the result is unused), so two pixels are in flight per thread.
-  struct It { uint4 x, d, g; };
+  struct It { uint4 x, d, g, g2; };
   const long p_first = b + m.row;
+  const bool acc_t = acc && !sb, acc_f = acc && sb;    // earlier contributions are in g (element type) / in the fp32 sums
   auto fetch = [&](long p, It& t) {
     const long pp = p < e ? p : p_first;
     t.x = *reinterpret_cast<const uint4*>(xb + (size_t)pp * xs * sizeof(T));
     t.d = *reinterpret_cast<const uint4*>(a.da + (size_t)pp * a.da_stride * sizeof(T) + (size_t)v * 16);
-    if (acc) t.g = *reinterpret_cast<const uint4*>(gb + (size_t)pp * gs * sizeof(T));
+    if (acc_t) t.g = *reinterpret_cast<const uint4*>(gb + (size_t)pp * gs * sizeof(T));
+    if (acc_f) {
+      t.g = *reinterpret_cast<const uint4*>(sb + (size_t)pp * ss);
+      if constexpr (VEC == 8) t.g2 = *reinterpret_cast<const uint4*>(sb + (size_t)pp * ss + 4);
+    }
   };
   It cur, nxt;
   if (p_first < e) fetch(p_first, cur);
@@ -522,8 +534,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnBwdArg
     float xv[VEC], d[VEC], r[VEC];
     Vec16<T>::unpack(cur.x, xv);
     Vec16<T>::unpack(cur.d, d);
-    if (acc) Vec16<T>::unpack(cur.g, r);
-    else {
+    if (acc_t) Vec16<T>::unpack(cur.g, r);
+    else if (acc_f) {
+      Vec16<float>::unpack(cur.g, r);
+      if constexpr (VEC == 8) Vec16<float>::unpack(cur.g2, r + 4);
+    } else {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) r[i] = 0.f;
     }
@@ -532,7 +547,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnBwdArg
       const float dd = (!a.relu || fmaf(xv[i], sc[i], sh[i]) > 0.f) ? d[i] : 0.f;
       r[i] += sc[i] * (dd - k2[i] - (xv[i] - mu[i]) * is[i] * k3[i]);
     }
-    *reinterpret_cast<uint4*>(gb + (size_t)p * gs * sizeof(T)) = Vec16<T>::pack(r);
+    if (fin) *reinterpret_cast<uint4*>(gb + (size_t)p * gs * sizeof(T)) = Vec16<T>::pack(r);
+    else {
+      *reinterpret_cast<uint4*>(sb + (size_t)p * ss) = Vec16<float>::pack(r);
+      if constexpr (VEC == 8) *reinterpret_cast<uint4*>(sb + (size_t)p * ss + 4) = Vec16<float>::pack(r + 4);
+    }
     cur = nxt;
   }
 }
@@ -722,6 +741,14 @@ static int fill_bwd_args(const char* what, const mdie_bn_bwd_desc* d, BnBwdArgs&
     if (need_g) {
       MDIE_REQUIRE(d->g[k].ptr && d->g[k].channels == d->x[k].channels && d->g[k].stride >= d->g[k].channels, "%s: gradient segment %d", what, k);
       a.g[k].ptr = (char*)d->g[k].ptr; a.g[k].ch_begin = c; a.g[k].ch_end = c + d->g[k].channels; a.g[k].stride = d->g[k].stride;
+      a.acc32[k].ptr = nullptr; a.final_from[k] = 0;
+      if (d->acc32[k].ptr) {
+        MDIE_REQUIRE(d->dtype != MDIE_F32 && d->acc32[k].channels == d->x[k].channels && d->acc32[k].stride >= d->acc32[k].channels &&
+                     d->acc32[k].stride % 4 == 0 && ((uintptr_t)d->acc32[k].ptr & 15) == 0 && d->final_from[k] >= 0 && d->final_from[k] % 8 == 0,
+                     "%s: fp32 accumulator of segment %d (16-bit element types only; same channels; final_from a multiple of 8)", what, k);
+        a.acc32[k].ptr = (char*)d->acc32[k].ptr; a.acc32[k].ch_begin = c; a.acc32[k].ch_end = c + d->acc32[k].channels; a.acc32[k].stride = d->acc32[k].stride;
+        a.final_from[k] = d->final_from[k];
+      }
     }
     c += d->x[k].channels;
   }

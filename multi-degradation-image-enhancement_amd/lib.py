@@ -67,6 +67,7 @@ class BnUpBwdDesc(C.Structure):
 
 class BnBwdDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_long), ("nseg", C.c_int), ("x", Seg * MAX_SEG), ("g", Seg * MAX_SEG), ("accumulate", C.c_uint),
+                ("acc32", Seg * MAX_SEG), ("final_from", C.c_int * MAX_SEG),
                 ("da", C.c_void_p), ("da_stride", C.c_int),
                 ("mean", C.c_void_p), ("invstd", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", C.c_int),
                 ("c_real", C.c_int), ("split", C.c_int), ("gap", C.c_int),

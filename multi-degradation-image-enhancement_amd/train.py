@@ -30,6 +30,12 @@ from . import engine as E
 from . import lib as L
 
 EPS = 1e-5
+# fp32 running sums for the DenseBlock segment gradients under 16-bit storage (MDIE_TRAIN_ACC32=1).  OFF by default: measured on
+# MI355X (whole network, 2x3x64x64, vs the fp64 oracle) the gradient direction does not move -- bf16 median cosine 0.98699 with,
+# 0.98708 without, worst 0.897 / 0.893 (the bottleneck gate's arg-max routing) -- because what separates bf16 from the oracle is
+# the rounding of the FORWARD activations (fp16, 8x finer, gives 0.9987 / 0.993 with the same five bf16-style roundings), while
+# the fp32 traffic costs 6 % of a 512x512 step (11.57 vs 10.88 ms, B = 8).
+ACC32 = __import__("os").environ.get("MDIE_TRAIN_ACC32", "0") == "1"
 
 
 def _cl(t):
@@ -296,6 +302,12 @@ class _DenseFn(torch.autograd.Function):
         else:
             dz = _cl(d_out.to(td))
         gx, gg = torch.empty_like(x), torch.empty_like(grow)
+        # 16-bit storage: a segment's gradient is the sum over its (up to five) consuming layers -- kept in fp32 until the
+        # last consumer has added its part, then rounded ONCE into gx / gg (csrc/bn.hip bn_bwd_apply_kernel, acc32)
+        acc32 = dt != L.F32 and ACC32
+        if acc32:
+            sx = torch.empty(x.shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+            sg = torch.empty(grow.shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
         grads = [None] * 20
         for l in (4, 3, 2, 1, 0):
             w, k = weights[l], consts[l]
@@ -329,6 +341,12 @@ class _DenseFn(torch.autograd.Function):
                 ptr, c, st = _nhwc(g)
                 d.g[i] = L.Seg(ptr, c, st)
             d.accumulate = 0 if l == 4 else 3
+            if acc32:
+                ptr, c, st = _nhwc(sx)
+                d.acc32[0], d.final_from[0] = L.Seg(ptr, c, st), (0 if l == 0 else c0)        # x: layer 0 is its last consumer
+                if l:
+                    ptr, c, st = _nhwc(sg[:, :16 * l])
+                    d.acc32[1], d.final_from[1] = L.Seg(ptr, c, st), 16 * (l - 1)             # growth map l-1: this layer is its last consumer
             d.da, d.da_stride = da.data_ptr(), cin_st
             d.mean, d.invstd, d.scale, d.shift, d.relu = mv[0].data_ptr(), k[2].data_ptr(), k[0].data_ptr(), k[1].data_ptr(), 1
             d.c_real, d.split, d.gap = cin_real, real_c, gap

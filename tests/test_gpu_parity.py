@@ -1318,7 +1318,7 @@ def test_router_checkpoint_format_thresholds_and_routing(E, tmp_path):
                                                                      # 1x1 maps at the deep end: BatchNorm over TWO samples normalises to exactly +-1, the true gradient
                                                                      # through it is ~0 and what is left is summation-order noise -> direction only loosely pinned there
                                                                      ("fp32", (2, 8, 8), 0.95, 0.9999, 2e-4),
-                                                                     ("bf16", (2, 64, 64), 0.85, 0.97, 3e-2),
+                                                                     ("bf16", (2, 64, 64), 0.87, 0.98, 3e-2),     # measured: worst 0.8934-0.8966, median 0.9870
                                                                      # fp16 = the reference's own autocast dtype: gradients need its GradScaler (models/model.py:31,164)
                                                                      ("fp16", (2, 64, 64), 0.986, 0.9975, 8e-3)])     # measured: worst 0.9931, median 0.99874, output 3.9e-3
 def test_whole_network_training_step_vs_oracle(E, precision, shape, min_cos, med_cos, out_tol):
