@@ -940,6 +940,37 @@ def _nhwc_cuda(t, pad_to=None):
     return t.cuda().contiguous(memory_format=torch.channels_last)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_dense_block_gradients_with_fp32_running_sums(E, L, precision, monkeypatch):
+    """MDIE_TRAIN_ACC32 path of bn_bwd_apply_kernel (segment gradients summed in fp32 over the consuming layers, rounded
+    once): same DenseBlock backward as the default path up to the roundings it removes, and closer to (never further
+    from) the fp32 engine's gradients."""
+    import mdie_amd.train as T
+    net, _ = _train_net()
+    blk = net.encoder.dense1
+    g = torch.Generator().manual_seed(4)
+    x32 = torch.randn(2, 64, 12, 20, generator=g)
+    dy32 = torch.randn(2, 64, 12, 20, generator=g)
+
+    def run(prec, acc32):
+        monkeypatch.setattr(T, "ACC32", acc32)
+        td = TORCH_DT[prec]
+        gx = x32.cuda().to(td).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        net.zero_grad(set_to_none=True)
+        y = T.dense_block(E.dtype_id(prec), blk, gx, 64)
+        y.backward(dy32.cuda().to(td).contiguous(memory_format=torch.channels_last))
+        return gx.grad.float(), [p.grad.clone() for p in blk.parameters()]
+
+    ref_dx, ref_dp = run("fp32", False)
+    dx0, dp0 = run(precision, False)
+    dx1, dp1 = run(precision, True)
+    tol = {"bf16": 3e-2, "fp16": 4e-3}[precision]
+    assert rel_to_max(dx1, dx0) <= tol and rel_to_max(dx1, ref_dx) <= tol
+    assert rel_to_max(dx1, ref_dx) <= 1.05 * rel_to_max(dx0, ref_dx) + 1e-6       # rounding once is not worse than rounding five times
+    for a, b in zip(dp1, dp0):
+        assert rel_to_max(a, b) <= tol
+
+
 @pytest.mark.parametrize("stage,hw", [(2, (12, 8)), (3, (6, 10)), (4, (5, 7))])
 def test_conv_block_train_matches_oracle(E, L, stage, hw):
     """conv -> batch-stat BN -> ReLU (-> maxpool): outputs, running statistics and every gradient."""

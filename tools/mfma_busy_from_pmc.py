@@ -30,7 +30,12 @@ for k in sorted(rows):
         continue
     short = d["name"].replace("_ZN4mdie", "").split("EvNS_")[0][:44]
     agg.setdefault((short, d["grid"]), []).append(d)
-print(f"{'kernel (mangled, shortened)':46s} {'grid':>9s} {'n':>4s} {'us':>8s} {'mfma_busy':>9s} {'sq_busy':>8s} {'clock GHz':>9s}", file=out)
+print("# mfma_busy   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): matrix-pipe busy fraction of the cycles the chip\n"
+      "#               counted while the dispatch ran (GRBM counts at its own reference rate: reads low when the shader clock is throttled)\n"
+      "# vs_2.4GHz   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz): busy fraction against the NOMINAL peak clock, i.e. the\n"
+      "#               fraction of the dense bf16 MFMA peak (2.5 PFLOP/s) the dispatch delivered as matrix work\n"
+      "# (in-kernel shader clock of the wide convolutions under this load: 1.4-1.66 GHz, profiles/r02g_wide_conv_stage_stamps.txt)", file=out)
+print(f"{'kernel (mangled, shortened)':46s} {'grid':>9s} {'n':>4s} {'us':>8s} {'mfma_busy':>9s} {'vs_2.4GHz':>9s} {'sq_busy':>8s}", file=out)
 for (name, grid), ds in agg.items():
     ds = sorted(ds, key=lambda d: d.get("us", 0.0))
     m = ds[len(ds) // 2]
@@ -38,4 +43,5 @@ for (name, grid), ds in agg.items():
     busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc) if cyc else 0.0
     sq = m.get("SQ_BUSY_CYCLES", 0.0) / (32.0 * cyc) if cyc else 0.0          # per shader engine (32 of them)
     us = m.get("us", 0.0)
-    print(f"{name:46s} {grid:9d} {len(ds):4d} {us:8.1f} {busy:9.3f} {sq:8.3f} {cyc / us / 1e3 if us else 0:9.2f}", file=out)
+    nominal = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * us * 2400.0) if us else 0.0
+    print(f"{name:46s} {grid:9d} {len(ds):4d} {us:8.1f} {busy:9.3f} {nominal:9.3f} {sq:8.3f}", file=out)

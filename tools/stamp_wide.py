@@ -24,7 +24,7 @@ for name in sys.argv[1:] or list(SHAPES):
     Ho = H // 2 if pool else H
     out = torch.empty(B, Ho, Ho, cout, device="cuda", dtype=td)
     items = B * (H // 16) * (H // 32) * (cout // 64)
-    grid = -(-items // -(-items // 256))
+    grid = 8 * min(-(-items // 8), 32)
     dbg = torch.zeros(grid * 100 + 16, dtype=torch.int64, device="cuda")
 
     def run(stamp):
@@ -53,7 +53,7 @@ for name in sys.argv[1:] or list(SHAPES):
     real = dbg[grid * 96:grid * 98].view(grid, 2).cpu().double()
     tend = dbg[grid * 98:grid * 99].cpu().double()
     nchunk = cin // 32
-    nst = min(24, -(-items // 256) * nchunk)
+    nst = min(24, -(-items // grid) * nchunk)
     live = st[:, 0, 0] > 0
     st, real, tend = st[live], real[live], tend[live]
     cyc = tend - st[:, 0, 0]
