@@ -148,8 +148,10 @@ int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream);
 
 /* First layer, straight from the network input: out = pool2x2?(act(conv3x3(x) * post_scale + post_shift))
  * with x fp32 NCHW [B,3,H,W] (encoder.conv1 + maxpool, models/cdan.py:58,74-75).  K = 27 is im2col'ed
- * into one 32-deep MFMA step; weights packed by mdie_pack_conv_first_weight:
- * [step][cout_stored][64 bytes], element k = tap*3 + c (k < 27), steps = 1 (bf16) / 2 (f32). */
+ * into two MFMA steps; weights packed by mdie_pack_conv_first_weight:
+ * [step][cout_stored][64 bytes], two steps.  fp32: element k = tap*3 + c (k < 27), 16 per step.  16-bit types: element
+ * k' = tap*4 + c (c < 3; a pixel of the kernel's [pixel][4] LDS patch is then 8 aligned bytes of the operand), 32 per step:
+ * taps 0..7 in step 0, tap 8 in step 1. */
 typedef struct {
   int dtype;
   int B, H, W;

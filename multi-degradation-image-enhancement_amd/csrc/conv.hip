@@ -544,7 +544,7 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_kernel(const First
   constexpr int TILE = 16, PW = TILE + 2;
   constexpr int E = sizeof(T);
   constexpr int NCS = BN / 16, NPS = 4;
-  constexpr int STEPS = E == 2 ? 1 : 2;
+  constexpr int STEPS = 2;   // fp32: 2 x 16 of k = tap*3 + c;  16-bit: k' = tap*4 + c, taps 0..7 | tap 8 (two aligned 8-byte pixel reads per lane)
   __shared__ __attribute__((aligned(16))) T patch[PW * PW * 4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lp = lane & 15;
@@ -554,7 +554,6 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_kernel(const First
   const int ty = bid % a.tiles_y; bid /= a.tiles_y;
   const int img = bid;
   const int y0 = ty * TILE, x0 = tx * TILE, n0 = nt * BN;
-
   // weight fragments -> registers (issued first; they land while the patch is staged)
   uint4 wf[STEPS][NCS];
 #pragma unroll
@@ -597,16 +596,22 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_kernel(const First
   __syncthreads();
 
   // this lane's im2col columns k = tap*3 + c -> element offsets in the [pixel][4] patch (lane-constant)
-  constexpr int KPL = 16 / E;  // K elements per lane per step
+  constexpr int KPL = E == 2 ? 3 : 4;  // gather offsets per lane: 16-bit = the three pixels (taps 2lq, 2lq+1, 8), fp32 = 4 elements per step
   int goff[STEPS][KPL];
+  if constexpr (E == 2) {
+    const int ta = 2 * lq, tb = 2 * lq + 1;
+    goff[0][0] = ((ta / 3) * PW + ta % 3) * 4; goff[0][1] = ((tb / 3) * PW + tb % 3) * 4; goff[0][2] = (2 * PW + 2) * 4;
+    goff[1][0] = goff[1][1] = goff[1][2] = 0;
+  } else {
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s)
+    for (int s = 0; s < STEPS; ++s)
 #pragma unroll
-    for (int i = 0; i < KPL; ++i) {
-      const int k = (E == 2 ? 8 * lq : 16 * s + 4 * lq) + i;
-      const int tap = k / 3, c = k - tap * 3;
-      goff[s][i] = tap < 9 ? ((tap / 3) * PW + (tap % 3)) * 4 + c : 0;
-    }
+      for (int i = 0; i < KPL; ++i) {
+        const int k = 16 * s + 4 * lq + i;
+        const int tap = k / 3, c = k - tap * 3;
+        goff[s][i] = tap < 9 ? ((tap / 3) * PW + (tap % 3)) * 4 + c : 0;
+      }
+  }
 
   // gather of one pixel subtile's im2col operands; the next subtile's gather is issued before this one's MFMAs and
   // epilogue (pinned by sched_barrier), so its LDS round trips ride under them
@@ -614,14 +619,14 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_kernel(const First
     int y, x;
     tile_pixel<TILE>(wave * NPS + ps, lp, y, x);
     const T* base = patch + (y * PW + x) * 4;
+    if constexpr (E == 2) {   // a pixel = 8 aligned bytes = half an operand: no sub-dword reads, no packing
+      const uint2 pa = *reinterpret_cast<const uint2*>(base + goff[0][0]), pb = *reinterpret_cast<const uint2*>(base + goff[0][1]);
+      const uint2 pc = *reinterpret_cast<const uint2*>(base + goff[0][2]);
+      xf[0] = make_uint4(pa.x, pa.y, pb.x, pb.y);
+      xf[1] = make_uint4(pc.x, pc.y, pc.x, pc.y);     // tap 8 in k' 0..3 of step 1 (lane group 0); every other weight of the step is zero
+    } else {
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      if constexpr (E == 2) {
-        uint32_t h[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) h[i] = *reinterpret_cast<const unsigned short*>(base + goff[s][i]);
-        xf[s] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-      } else {
+      for (int s = 0; s < STEPS; ++s) {
         uint32_t h[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) h[i] = *reinterpret_cast<const uint32_t*>(base + goff[s][i]);
@@ -653,6 +658,187 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_kernel(const First
     conv_epilogue<T, NCS, 1, TILE>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS + ps, lq, lp);
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// The same layer as the network runs it -- 16-bit storage, 64 outputs per workgroup, ReLU, 2x2 max-pool -- with the MFMA
+// operand roles exchanged: pixels are the A rows, output channels the B columns, so a lane's four accumulator registers are
+// the four pixels of ONE pooling window (tile_pixel puts a 2x2 block on 4 consecutive rows) for one output channel.  Pooling
+// is then two v_max3_f32 on the lane's own registers with the ReLU folded in, instead of DPP quad exchanges on all 64 lanes
+// for a result a quarter of them keep; and with column j of channel subtile cs standing for channel 4j + cs (chosen by the
+// weight fragment's ADDRESS: the packed layout is conv_first_kernel's) the lane ends up with 4 consecutive channels of one
+// pooled pixel = one 8-byte store, a wave's store instruction covering 4 pooled pixels x 128 B.
+// Why it matters: stamps (tools/stamp_first.py) show this layer bound by vector-instruction issue (4 cycles per instruction
+// per wave, 16 for 32-bit integer multiplies), not by HBM or the matrix pipe.  Per 16 pixels x 64 outputs the epilogue is 18
+// vector instructions instead of 56, and every address is a wave-uniform (scalar) base plus one 32-bit lane offset computed
+// once per workgroup -- no 64-bit vector arithmetic, no integer multiply after the prologue.
+#ifdef EXP_FSTAMPS   // diagnostic build only (tools/stamp_first.py): shader-clock stamps of wave 0 into g_exp_dbg
+#define FSTAMP(slot) do { if (dbg && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dbg[(size_t)blockIdx.x * 12 + (slot)] = t_; } } while (0)
+#else
+#define FSTAMP(slot) do {} while (0)
+#endif
+template <typename T, bool FULL>   // FULL: H and W are multiples of the tile, no store needs a bounds check (and so no branch: see the waits below)
+__global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_pool_kernel(const FirstArgs a, const int n_items) {
+  static_assert(sizeof(T) == 2, "16-bit storage types");
+  constexpr int TILE = 16, PW = TILE + 2, BN = 64, NCS = 4, NPS = 4;
+  __shared__ __attribute__((aligned(16))) T patch[2][PW * PW * 4];
+
+  const int tid = threadIdx.x, lane = tid & 63, lq = lane >> 4, lp = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef EXP_FSTAMPS
+  unsigned long long* const dbg = a.e.res_stride == -12345 ? (unsigned long long*)a.e.residual : nullptr;
+  if (dbg && tid == 0) { unsigned long long t_; unsigned hw; asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(hw) :: "memory"); dbg[(size_t)blockIdx.x * 12 + 10] = t_; dbg[(size_t)blockIdx.x * 12 + 11] = hw; }
+  FSTAMP(0);
+#endif
+  const size_t plane = (size_t)a.H * a.W;
+  const int Ho = a.e.H >> 1, Wo = a.e.W >> 1;
+
+  // ---- lane constants, once per workgroup ----
+  // patch staging: this thread's (up to) two patch pixels
+  constexpr int PIT = (PW * PW + CONV_THREADS - 1) / CONV_THREADS;
+  unsigned ppy[PIT], ppx[PIT], poff[PIT];
+#pragma unroll
+  for (int it = 0; it < PIT; ++it) {
+    const unsigned p = tid + it * CONV_THREADS;
+    ppy[it] = p / PW; ppx[it] = p - ppy[it] * PW;
+    poff[it] = (ppy[it] * (unsigned)a.W + ppx[it]) * 4u;                    // bytes from the patch's corner; < 18 image rows
+  }
+  // operand gather: A row lp of subtile ps = tile_pixel(wave*4 + ps, lp) = (4*wave + 2*(ps/2) + bit1(lp), 8*(ps%2) + 2*(lp/4) + bit0(lp));
+  // lane group lq reads taps 2lq, 2lq+1 (step 0) and tap 8 (step 1: k' 0..3 of group 0, the rest has zero weights)
+  const int ta = 2 * lq, tb = 2 * lq + 1;
+  const int g0 = ((4 * wave + ((lp >> 1) & 1)) * PW + 2 * (lp >> 2) + (lp & 1)) * 4;
+  const int ga = g0 + ((ta / 3) * PW + ta % 3) * 4, gb = g0 + ((tb / 3) * PW + tb % 3) * 4, gc = g0 + (2 * PW + 2) * 4;
+  const unsigned olane = ((unsigned)lq * a.e.out_stride + 4u * lp) * (unsigned)sizeof(T);
+
+  // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2: XCD x walks the x-th eighth of the
+  // tile list, its resident workgroups on consecutive tiles at any moment, so the halo rows and the 128-byte lines two
+  // neighbouring tiles share are fetched from HBM by one L2 instead of by several.  (blockIdx.y = the 64-channel tile.)
+  const int per_xcd = (n_items + 7) >> 3, stride = gridDim.x >> 3;          // (gridDim.x is a multiple of 8)
+  const int band_end = min(((int)blockIdx.x & 7) * per_xcd + per_xcd, n_items);
+  int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (item >= band_end) return;
+  const int n0 = blockIdx.y * BN;
+  auto decode = [&](int it_, int& img, int& y0, int& x0) {                  // wave-uniform
+    const int tx = it_ % a.tiles_x; it_ /= a.tiles_x;
+    const int ty = it_ % a.tiles_y; img = it_ / a.tiles_y;
+    y0 = ty * TILE; x0 = tx * TILE;
+  };
+  // Every load is unconditional (a border lane reads the tile's own first pixel instead and is zeroed when the patch is
+  // written) and so is every store of the FULL form: with no branch around a memory instruction the compiler's waits stay
+  // COUNTED -- the patch write waits for the loads only, not for the acknowledgement of the stores issued after them (which
+  // a conservative vmcnt(0) does: ~2 us under load, stamps), and the MFMAs never wait for the prefetch.
+  float xin[PIT][3];
+  unsigned okm = 0;
+  auto issue_patch = [&](int img, int y0, int x0) {   // scalar base (may point before the tensor at the borders: never read there) + lane offset
+    const float* const xb = a.x + (size_t)img * 3 * plane + ((ptrdiff_t)(y0 - 1) * a.W + (x0 - 1));
+    okm = 0;
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const bool ok = (unsigned)(y0 - 1 + (int)ppy[it]) < (unsigned)a.H && (unsigned)(x0 - 1 + (int)ppx[it]) < (unsigned)a.W;   // (ppy >= 18 past the patch: masked at the write)
+      okm |= ok ? 1u << it : 0u;
+      const unsigned off = ok ? poff[it] : ((unsigned)a.W + 1u) * 4u;
+#ifdef EXP_NO_GLOAD
+      if (a.B == 12345)
+#endif
+      {
+        xin[it][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xb) + off);
+        xin[it][1] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xb + plane) + off);
+        xin[it][2] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xb + 2 * plane) + off);
+      }
+    }
+  };
+
+  // weight fragments (column j of subtile cs = channel 4j + cs) and this lane's 4 channels' constants, once per workgroup
+  uint4 wf[2][NCS];
+  {
+    const char* const wbase = a.weight + (size_t)n0 * 64;                    // wave-uniform
+    const unsigned wlane = (unsigned)(4 * lp) * 64u + (unsigned)lq * 16u;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int cs = 0; cs < NCS; ++cs) wf[s][cs] = *reinterpret_cast<const uint4*>(wbase + (size_t)s * a.cout * 64 + cs * 64 + wlane);
+  }
+  const float4 psc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.e.post_scale + n0) + (unsigned)lp * 16u);
+  const float4 psh = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.e.post_shift + n0) + (unsigned)lp * 16u);
+  const float sc[4] = {psc.x, psc.y, psc.z, psc.w}, sh[4] = {psh.x, psh.y, psh.z, psh.w};
+  int img, y0, x0;
+  decode(item, img, y0, x0);
+  issue_patch(img, y0, x0);
+
+  // Persistent over tiles: the next tile's patch loads are issued right after the barrier and fly under this tile's
+  // MFMAs, epilogue and stores; two patch buffers, so ONE barrier per tile orders everything (a wave overwrites
+  // buffer b for tile i+2 only after passing tile i+1's barrier, which every wave reaches after its reads of tile i).
+  // The first tile is peeled off the loop (`tile` is called once before it): the loop is then entered, like its back edge,
+  // with "6 patch loads, then 4 stores" outstanding, and the compiler's wait before the patch write is vmcnt(7) / vmcnt(4)
+  // -- the loads -- on both paths instead of the vmcnt(0) a merge with the store-less prologue forces.
+  int buf = 0;
+  bool last = false;
+  auto tile = [&]() {
+    T* const pt = patch[buf];
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const bool ok = (okm >> it) & 1u;
+      const uint2 v = make_uint2(Half<T>::pack(ok ? xin[it][0] : 0.f, ok ? xin[it][1] : 0.f), Half<T>::pack(ok ? xin[it][2] : 0.f, 0.f));
+      if (tid + it * CONV_THREADS < PW * PW) *reinterpret_cast<uint2*>(pt + (tid + it * CONV_THREADS) * 4) = v;
+    }
+    FSTAMP(1);
+    __syncthreads();
+    FSTAMP(2);
+    last = item + stride >= band_end;
+    const int next = last ? item : item + stride;                            // (the last tile is loaded once more: no branch around the loads)
+    int nimg, ny0, nx0;
+    decode(next, nimg, ny0, nx0);
+    issue_patch(nimg, ny0, nx0);
+
+    // pooled output: lane (lq, lp) of subtile ps stores channels n0 + 4lp .. +3 of pooled pixel (y0/2 + 2*wave + ps/2, x0/2 + 4*(ps%2) + lq)
+    char* const obase = a.e.out + ((((size_t)img * Ho + (y0 >> 1) + 2 * wave) * Wo + (x0 >> 1)) * a.e.out_stride + n0) * sizeof(T);   // wave-uniform
+    const bool col_in[2] = {x0 + 2 * lq < a.e.W, x0 + 8 + 2 * lq < a.e.W};
+    auto gather = [&](int ps, uint4 (&xf)[2]) {
+      const int d = ((2 * (ps >> 1)) * PW + 8 * (ps & 1)) * 4;             // compile-time: an immediate of the ds_read
+      const uint2 pa = *reinterpret_cast<const uint2*>(pt + ga + d), pb = *reinterpret_cast<const uint2*>(pt + gb + d), pc = *reinterpret_cast<const uint2*>(pt + gc + d);
+      xf[0] = make_uint4(pa.x, pa.y, pb.x, pb.y);
+      xf[1] = make_uint4(pc.x, pc.y, pc.x, pc.y);
+    };
+    uint4 xf[2][2];
+    gather(0, xf[0]);
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      if (ps + 1 < NPS) gather(ps + 1, xf[(ps + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc[NCS];
+#pragma unroll
+      for (int cs = 0; cs < NCS; ++cs) acc[cs] = mma16<T>(xf[ps & 1][0], wf[0][cs], f32x4{0.f, 0.f, 0.f, 0.f});   // rows = pixels, columns = channels
+#pragma unroll
+      for (int cs = 0; cs < NCS; ++cs) acc[cs] = mma16<T>(xf[ps & 1][1], wf[1][cs], acc[cs]);
+      // All 8 MFMAs, then the epilogue -- pinned.  Left free, the compiler (ROCm 7.2) interleaves them in the branch-free FULL
+      // form: "D1 = mfma(.., C = D0); 2 VALU; D0 = mfma(.., 0); s_nop 4; VALU reads D1", and rows 12..15 of D1 (the last
+      // pass) then come out wrong on gfx950 (channel 4j+1 of every 4th pooled pixel; found by tests/test_gpu_parity.py).
+      __builtin_amdgcn_sched_barrier(0);
+      float m[NCS];
+#pragma unroll
+      for (int cs = 0; cs < NCS; ++cs) {
+        const f32x2 lo = __builtin_elementwise_fma(f32x2{acc[cs][0], acc[cs][1]}, f32x2{sc[cs], sc[cs]}, f32x2{sh[cs], sh[cs]});
+        const f32x2 hi = __builtin_elementwise_fma(f32x2{acc[cs][2], acc[cs][3]}, f32x2{sc[cs], sc[cs]}, f32x2{sh[cs], sh[cs]});
+        m[cs] = fmaxf(fmaxf(fmaxf(fmaxf(lo[0], lo[1]), hi[0]), hi[1]), 0.f);   // max-pool and ReLU: two v_max3_f32
+      }
+#ifdef EXP_NO_STORE
+      if (m[0] == 1234.5f)
+#endif
+      if (FULL || (y0 + 4 * wave + 2 * (ps >> 1) < a.e.H && col_in[ps & 1])) {
+        char* const o = obase + ((size_t)(ps >> 1) * Wo + 4 * (ps & 1)) * a.e.out_stride * sizeof(T);     // wave-uniform
+        *reinterpret_cast<uint2*>(o + olane) = make_uint2(Half<T>::pack(m[0], m[1]), Half<T>::pack(m[2], m[3]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      FSTAMP(3 + ps);
+    }
+    item = next; img = nimg; y0 = ny0; x0 = nx0; buf ^= 1;
+  };
+  tile();
+  while (!last) tile();
+#ifdef EXP_FSTAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  FSTAMP(7);
+  if (dbg && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dbg[(size_t)blockIdx.x * 12 + 9] = t_; }
+#endif
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------
@@ -842,6 +1028,9 @@ __global__ __launch_bounds__(CONV_THREADS) void stem7_kernel(const StemArgs a) {
   conv_epilogue<T, NCS, NPS, TILE>(a.e, esc, esh, acc, img, y0, x0, 0, wave * NPS, lq, lp);
 }
 
+#ifdef EXP_FSTAMPS
+static void* g_exp_dbg = nullptr;
+#endif
 template <typename T>
 static int dispatch_first(const mdie_conv_first_desc* d, hipStream_t stream) {
   FirstArgs a{};
@@ -849,10 +1038,25 @@ static int dispatch_first(const mdie_conv_first_desc* d, hipStream_t stream) {
   a.tiles_x = cdiv(d->W, 16); a.tiles_y = cdiv(d->H, 16);
   a.x = d->x; a.weight = reinterpret_cast<const char*>(d->weight);
   fill_epi(a.e, d->H, d->W, d->post_scale, d->post_shift, d->act, d->pool, nullptr, 0, d->out, d->out_stride);
+#ifdef EXP_FSTAMPS
+  if (g_exp_dbg) { a.e.residual = (const char*)g_exp_dbg; a.e.res_stride = -12345; }
+#endif
   const int bn = (d->cout % 64 == 0) ? 64 : 16;
   a.n_tiles = d->cout / bn;
   const int grid = a.n_tiles * a.tiles_x * a.tiles_y * a.B;
   TimedLaunch tl(MDIE_K_CONV3);
+  static const bool no_pool_kernel = getenv("MDIE_FIRST_POOL_KERNEL") && atoi(getenv("MDIE_FIRST_POOL_KERNEL")) == 0;   // A/B switch
+  if constexpr (sizeof(T) == 2) {
+    if (bn == 64 && d->pool && d->act == MDIE_ACT_RELU && !no_pool_kernel && (size_t)18 * d->W * 4 < (1ull << 32)) {
+      static const int per_cu = getenv("MDIE_FIRST_WGS_PER_CU") ? atoi(getenv("MDIE_FIRST_WGS_PER_CU")) : 4;   // (experiments)
+      const int tiles = a.tiles_x * a.tiles_y * a.B;
+      const int wgs = 8 * cdiv(per_cu > 0 ? std::min(tiles, std::max(256 * per_cu / a.n_tiles, 8)) : tiles, 8);   // persistent: resident workgroups walk the tiles
+      if (d->H % 16 == 0 && d->W % 16 == 0) hipLaunchKernelGGL((conv_first_pool_kernel<T, true>), dim3(wgs, a.n_tiles), dim3(CONV_THREADS), 0, stream, a, tiles);
+      else hipLaunchKernelGGL((conv_first_pool_kernel<T, false>), dim3(wgs, a.n_tiles), dim3(CONV_THREADS), 0, stream, a, tiles);
+      MDIE_LAUNCH_CHECK("mdie_conv_first_fwd");
+      return MDIE_OK;
+    }
+  }
   if (bn == 64) hipLaunchKernelGGL((conv_first_kernel<T, 64>), dim3(grid), dim3(CONV_THREADS), 0, stream, a);
   else hipLaunchKernelGGL((conv_first_kernel<T, 16>), dim3(grid), dim3(CONV_THREADS), 0, stream, a);
   MDIE_LAUNCH_CHECK("mdie_conv_first_fwd");
@@ -861,6 +1065,9 @@ static int dispatch_first(const mdie_conv_first_desc* d, hipStream_t stream) {
 
 }  // namespace mdie
 
+#ifdef EXP_FSTAMPS
+extern "C" void mdie_exp_set_dbg(void* p) { mdie::g_exp_dbg = p; }
+#endif
 extern "C" int mdie_conv_fwd(const mdie_conv_desc* d, void* stream) {
   using namespace mdie;
   MDIE_REQUIRE(d != nullptr, "mdie_conv_fwd: null descriptor");

@@ -105,7 +105,7 @@ static size_t conv_weight_bytes(int dtype, int ks, int cin_st, int cout_st) {
   return (size_t)cdiv(cin_st, kc) * ks * ks * cout_st * 64;
 }
 
-static size_t first_weight_bytes(int dtype, int cout_st) { return (size_t)(dtype == MDIE_F32 ? 2 : 1) * cout_st * 64; }
+static size_t first_weight_bytes(int dtype, int cout_st) { (void)dtype; return (size_t)2 * cout_st * 64; }   // two MFMA steps for every type
 
 static BlobLayout blob_layout(int dtype) {
   BlobLayout L{};
@@ -169,7 +169,10 @@ static void pack_first_weight(int dtype, const float* w, int cout, int cout_st, 
       const int tap = k / 3, c = k % 3;
       const float v = w[((size_t)o * 3 + c) * 9 + tap];
       if (dtype == MDIE_F32) reinterpret_cast<float*>(dst)[((size_t)(k / 16) * cout_st + o) * 16 + k % 16] = v;
-      else reinterpret_cast<uint16_t*>(dst)[(size_t)o * 32 + k] = f32_to_half_bits(dtype, v);
+      else {   // 16-bit: k' = tap*4 + c (a patch pixel's 4 stored channels = 8 aligned bytes), step = k' / 32: taps 0..7 | tap 8
+        const int kp = tap * 4 + c;
+        reinterpret_cast<uint16_t*>(dst)[((size_t)(kp / 32) * cout_st + o) * 32 + kp % 32] = f32_to_half_bits(dtype, v);
+      }
     }
 }
 

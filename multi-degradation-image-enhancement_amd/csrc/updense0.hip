@@ -8,8 +8,8 @@
 // with the base padded to one 16-byte K group) they cost 24 + 45 us at B = 32, 256x256, bf16 -- nine K = 32 MFMAs and nine
 // LDS fragment reads per 16 pixels on 3 channels, a second staging pass over a tensor the first launch had in registers.
 // Here the tile's 18x18 base patch is computed straight from t4 (4 taps, channels 0..3 in one load each) and the fp32 NCHW
-// input planes, activated and laid out [pixel][4] in LDS; K = 9 taps x 3 channels = 27 is im2col'ed into ONE 32-deep MFMA
-// step per 16 pixels (two 16-deep steps in fp32), exactly as conv_first_kernel does for encoder.conv1.  The halo ring of
+// input planes, activated and laid out [pixel][4] in LDS; the 9 taps x (3 + 1 zero) channels are im2col'ed into two MFMA steps
+// per 16 pixels (taps 0..7 | tap 8; fp32: 2 x 16 of k = tap*3 + c), exactly as conv_first_kernel does for encoder.conv1.  The halo ring of
 // the patch is recomputed by the neighbouring tiles (324 / 256 pixels): cheaper than a round trip through HBM.
 // Arithmetic is kept identical to the unfused pair: the base is rounded to the storage type before the pre-activation,
 // the pre-activation is one fused multiply-add rounded once, zero padding applies to the ACTIVATED tensor.
@@ -27,7 +27,7 @@ struct UpDense0Args {
   const char* lo; int lo_stride;  // decoder.conv4 output, NHWC, >= 4 stored channels per pixel
   const float* x;                 // network input, fp32 NCHW [B,3,H,W]
   char* base; int base_ch;        // out: NHWC, base_ch stored channels per pixel (one 16-byte group, or 16)
-  const char* weight;             // mdie_pack_conv_first_weight layout: [step][16][64 B], k = tap*3 + c
+  const char* weight;             // mdie_pack_conv_first_weight layout: [2 steps][16][64 B]
   const float *pre_scale, *pre_shift;   // folded BatchNorm of dense layer 0, >= 3 entries
   const float* bias;              // [16]
   char* g0; int g0_stride;        // out: NHWC, 16 channels
@@ -61,7 +61,7 @@ template <typename T, int BASE_CH>
 __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0Args a) {
   constexpr int E = sizeof(T);
   constexpr int VEC = Traits<T>::VEC;
-  constexpr int STEPS = E == 2 ? 1 : 2;
+  constexpr int STEPS = 2;   // (as conv_first_kernel: fp32 2 x 16 of k = tap*3 + c; 16-bit k' = tap*4 + c, taps 0..7 | tap 8)
   constexpr int NPS = 4;
   constexpr int PW = UD_PW;
   __shared__ __attribute__((aligned(16))) T patch[PW * PW * 4];
@@ -150,37 +150,41 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
   __syncthreads();
 
   // ---- im2col gather (k = tap*3 + c) and one MFMA step per 16 pixels ----
-  constexpr int KPL = 16 / E;
+  constexpr int KPL = E == 2 ? 3 : 4;
   int goff[STEPS][KPL];
+  if constexpr (E == 2) {
+    const int ta = 2 * lq, tb = 2 * lq + 1;
+    goff[0][0] = ((ta / 3) * PW + ta % 3) * 4; goff[0][1] = ((tb / 3) * PW + tb % 3) * 4; goff[0][2] = (2 * PW + 2) * 4;
+    goff[1][0] = goff[1][1] = goff[1][2] = 0;
+  } else {
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s)
+    for (int s = 0; s < STEPS; ++s)
 #pragma unroll
-    for (int i = 0; i < KPL; ++i) {
-      const int k = (E == 2 ? 8 * lq : 16 * s + 4 * lq) + i;
-      const int tap = k / 3, c = k - tap * 3;
-      goff[s][i] = tap < 9 ? ((tap / 3) * PW + (tap % 3)) * 4 + c : 3;   // k >= 27: the zero channel of the pixel
-    }
+      for (int i = 0; i < KPL; ++i) {
+        const int k = 16 * s + 4 * lq + i;
+        const int tap = k / 3, c = k - tap * 3;
+        goff[s][i] = tap < 9 ? ((tap / 3) * PW + (tap % 3)) * 4 + c : 3;   // k >= 27: the zero channel of the pixel
+      }
+  }
 #pragma unroll
   for (int ps = 0; ps < NPS; ++ps) {
     const int blk = (wave * NPS + ps) * 4 + (lp >> 2);
     const int y = 2 * (blk / (UD_TILE / 2)) + ((lp >> 1) & 1), x = 2 * (blk % (UD_TILE / 2)) + (lp & 1);
     const T* bp = patch + (y * PW + x) * 4;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (E == 2) {   // a patch pixel = 8 aligned bytes = half an operand
+      const uint2 pa = *reinterpret_cast<const uint2*>(bp + goff[0][0]), pb = *reinterpret_cast<const uint2*>(bp + goff[0][1]);
+      const uint2 pc = *reinterpret_cast<const uint2*>(bp + goff[0][2]);
+      acc = ud_mma<T>(wf[0], make_uint4(pa.x, pa.y, pb.x, pb.y), acc);
+      acc = ud_mma<T>(wf[1], make_uint4(pc.x, pc.y, pc.x, pc.y), acc);
+    } else {
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      uint4 xf;
-      if constexpr (E == 2) {
-        uint32_t h[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) h[i] = *reinterpret_cast<const unsigned short*>(bp + goff[s][i]);
-        xf = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-      } else {
+      for (int s = 0; s < STEPS; ++s) {
         uint32_t h[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) h[i] = *reinterpret_cast<const uint32_t*>(bp + goff[s][i]);
-        xf = make_uint4(h[0], h[1], h[2], h[3]);
+        acc = ud_mma<T>(wf[s], make_uint4(h[0], h[1], h[2], h[3]), acc);
       }
-      acc = ud_mma<T>(wf[s], xf, acc);
     }
     const int gy = y0 + y, gx = x0 + x;
     if (gy < a.H && gx < a.W) {     // lane: output channels 4 lq .. 4 lq + 3 of this pixel

@@ -151,8 +151,13 @@ def test_pack_first_layer_weight(dtype):
     if dtype == L.F32:
         got = dst.numpy().view(np.float32).reshape(2, 64, 16)
         assert np.array_equal(np.concatenate((got[0], got[1]), axis=1), im2col)
-    else:
-        assert np.array_equal(dst.numpy().view(np.uint16).reshape(64, 32), bf16_bits(im2col))
+    else:   # 16-bit: k' = tap*4 + c, 32 per step (taps 0..7 | tap 8), every other element zero
+        pix = np.zeros((64, 64), np.float32)
+        for tap in range(9):
+            for c in range(3):
+                pix[:, tap * 4 + c] = w[:, c, tap // 3, tap % 3]
+        got = dst.numpy().view(np.uint16).reshape(2, 64, 32)
+        assert np.array_equal(np.concatenate((got[0], got[1]), axis=1), bf16_bits(pix))
 
 
 def test_custom_torch_ops_are_registered_and_have_no_cpu_kernel():
