@@ -673,9 +673,22 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_kernel(const First
 // once per workgroup -- no 64-bit vector arithmetic, no integer multiply after the prologue.
 #ifdef EXP_FSTAMPS   // diagnostic build only (tools/stamp_first.py): shader-clock stamps of wave 0 into g_exp_dbg
 #define FSTAMP(slot) do { if (dbg && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dbg[(size_t)blockIdx.x * 12 + (slot)] = t_; } } while (0)
+#define FSEG(k) do { if (dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if ((k) >= 0) tacc[(k) < 0 ? 0 : (k)] += t_ - tprev; tprev = t_; } } while (0)
 #else
+#define FSEG(k) do {} while (0)
 #define FSTAMP(slot) do {} while (0)
 #endif
+// K = 16 MFMA for the ninth tap (4 k per lane group, only group 0's are non-zero): half the K = 32 form's matrix-pipe time
+template <typename T> __device__ __forceinline__ f32x4 mma16_k16(const uint2& a, const uint2& b, f32x4 acc);
+template <> __device__ __forceinline__ f32x4 mma16_k16<bf16>(const uint2& a, const uint2& b, f32x4 acc) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mma16_k16<f16>(const uint2& a, const uint2& b, f32x4 acc) {
+  typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), acc, 0, 0, 0);
+}
+
 template <typename T, bool FULL>   // FULL: H and W are multiples of the tile, no store needs a bounds check (and so no branch: see the waits below)
 __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_pool_kernel(const FirstArgs a, const int n_items) {
   static_assert(sizeof(T) == 2, "16-bit storage types");
@@ -686,8 +699,9 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_pool_kernel(const 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef EXP_FSTAMPS
   unsigned long long* const dbg = a.e.res_stride == -12345 ? (unsigned long long*)a.e.residual : nullptr;
-  if (dbg && tid == 0) { unsigned long long t_; unsigned hw; asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(hw) :: "memory"); dbg[(size_t)blockIdx.x * 12 + 10] = t_; dbg[(size_t)blockIdx.x * 12 + 11] = hw; }
+  if (dbg && tid == 0) { unsigned long long t_; unsigned hw; unsigned xcc; asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(hw), "=s"(xcc) :: "memory"); dbg[(size_t)blockIdx.x * 12 + 10] = t_; dbg[(size_t)blockIdx.x * 12 + 11] = hw | ((unsigned long long)(xcc & 0xf) << 32); }
   FSTAMP(0);
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;   // per-segment sums over this workgroup's tiles (wave 0's clock)
 #endif
   const size_t plane = (size_t)a.H * a.W;
   const int Ho = a.e.H >> 1, Wo = a.e.W >> 1;
@@ -709,19 +723,19 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_pool_kernel(const 
   const int ga = g0 + ((ta / 3) * PW + ta % 3) * 4, gb = g0 + ((tb / 3) * PW + tb % 3) * 4, gc = g0 + (2 * PW + 2) * 4;
   const unsigned olane = ((unsigned)lq * a.e.out_stride + 4u * lp) * (unsigned)sizeof(T);
 
-  // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2: XCD x walks the x-th eighth of the
-  // tile list, its resident workgroups on consecutive tiles at any moment, so the halo rows and the 128-byte lines two
-  // neighbouring tiles share are fetched from HBM by one L2 instead of by several.  (blockIdx.y = the 64-channel tile.)
-  const int per_xcd = (n_items + 7) >> 3, stride = gridDim.x >> 3;          // (gridDim.x is a multiple of 8)
-  const int band_end = min(((int)blockIdx.x & 7) * per_xcd + per_xcd, n_items);
-  int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-  if (item >= band_end) return;
+  // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2: XCD x takes the x-th eighth of the
+  // tile list, and each of its workgroups a CONTIGUOUS run of that eighth -- the halo columns and the 128-byte lines a tile
+  // shares with its right neighbour are re-read by the same workgroup one tile later, and walking a run is an increment with
+  // carry of (x tile, y tile, image): no integer division after the prologue.  (blockIdx.y = the 64-channel tile.)
+  const int per_xcd = (n_items + 7) >> 3, nwg = gridDim.x >> 3;             // (gridDim.x is a multiple of 8)
+  const int band0 = ((int)blockIdx.x & 7) * per_xcd, band1 = min(band0 + per_xcd, n_items);
+  const int run = (per_xcd + nwg - 1) / nwg;
+  int item = band0 + ((int)blockIdx.x >> 3) * run;
+  const int item_end = min(item + run, band1);
+  if (item >= item_end) return;
   const int n0 = blockIdx.y * BN;
-  auto decode = [&](int it_, int& img, int& y0, int& x0) {                  // wave-uniform
-    const int tx = it_ % a.tiles_x; it_ /= a.tiles_x;
-    const int ty = it_ % a.tiles_y; img = it_ / a.tiles_y;
-    y0 = ty * TILE; x0 = tx * TILE;
-  };
+  int tx, ty, img;                                                            // wave-uniform
+  { int r = item; tx = r % a.tiles_x; r /= a.tiles_x; ty = r % a.tiles_y; img = r / a.tiles_y; }
   // Every load is unconditional (a border lane reads the tile's own first pixel instead and is zeroed when the patch is
   // written) and so is every store of the FULL form: with no branch around a memory instruction the compiler's waits stay
   // COUNTED -- the patch write waits for the loads only, not for the acknowledgement of the stores issued after them (which
@@ -748,20 +762,24 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_pool_kernel(const 
   };
 
   // weight fragments (column j of subtile cs = channel 4j + cs) and this lane's 4 channels' constants, once per workgroup
-  uint4 wf[2][NCS];
+  // (step 1 of the packed layout holds tap 8 in its first 4 elements: they go to lane group 0 of a K = 16 MFMA, whose
+  //  other groups get zero weights -- and whatever finite patch pixel their lanes read)
+  uint4 wf[NCS];
+  uint2 wf8[NCS];
   {
     const char* const wbase = a.weight + (size_t)n0 * 64;                    // wave-uniform
-    const unsigned wlane = (unsigned)(4 * lp) * 64u + (unsigned)lq * 16u;
+    const unsigned wlane = (unsigned)(4 * lp) * 64u;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int cs = 0; cs < NCS; ++cs) wf[s][cs] = *reinterpret_cast<const uint4*>(wbase + (size_t)s * a.cout * 64 + cs * 64 + wlane);
+    for (int cs = 0; cs < NCS; ++cs) {
+      wf[cs] = *reinterpret_cast<const uint4*>(wbase + cs * 64 + wlane + (unsigned)lq * 16u);
+      const uint2 w8 = *reinterpret_cast<const uint2*>(wbase + (size_t)a.cout * 64 + cs * 64 + wlane);
+      wf8[cs] = lq == 0 ? w8 : make_uint2(0u, 0u);
+    }
   }
   const float4 psc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.e.post_scale + n0) + (unsigned)lp * 16u);
   const float4 psh = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.e.post_shift + n0) + (unsigned)lp * 16u);
   const float sc[4] = {psc.x, psc.y, psc.z, psc.w}, sh[4] = {psh.x, psh.y, psh.z, psh.w};
-  int img, y0, x0;
-  decode(item, img, y0, x0);
+  int y0 = ty * TILE, x0 = tx * TILE;
   issue_patch(img, y0, x0);
 
   // Persistent over tiles: the next tile's patch loads are issued right after the barrier and fly under this tile's
@@ -770,35 +788,40 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_pool_kernel(const 
   // The first tile is peeled off the loop (`tile` is called once before it): the loop is then entered, like its back edge,
   // with "6 patch loads, then 4 stores" outstanding, and the compiler's wait before the patch write is vmcnt(7) / vmcnt(4)
   // -- the loads -- on both paths instead of the vmcnt(0) a merge with the store-less prologue forces.
+  // (Known remainder, stamps: a CU's four resident workgroups were dispatched one after the other and the SIMDs favour the
+  //  oldest wave, so they finish after 16.5 / 19 / 21 / 24 us and the CU ends on one latency-bound straggler; rotating
+  //  s_setprio with the tile counter, out of phase between them, did not change that.  Evening it out needs a shared tile
+  //  counter per CU-group, i.e. scratch memory in the descriptor: ~4 us of this launch, not done.)
   int buf = 0;
   bool last = false;
   auto tile = [&]() {
     T* const pt = patch[buf];
+    FSEG(-1);
 #pragma unroll
     for (int it = 0; it < PIT; ++it) {
       const bool ok = (okm >> it) & 1u;
       const uint2 v = make_uint2(Half<T>::pack(ok ? xin[it][0] : 0.f, ok ? xin[it][1] : 0.f), Half<T>::pack(ok ? xin[it][2] : 0.f, 0.f));
       if (tid + it * CONV_THREADS < PW * PW) *reinterpret_cast<uint2*>(pt + (tid + it * CONV_THREADS) * 4) = v;
     }
-    FSTAMP(1);
+    FSEG(0);
     __syncthreads();
-    FSTAMP(2);
-    last = item + stride >= band_end;
-    const int next = last ? item : item + stride;                            // (the last tile is loaded once more: no branch around the loads)
-    int nimg, ny0, nx0;
-    decode(next, nimg, ny0, nx0);
+    FSEG(1);
+    last = item + 1 >= item_end;
+    int nimg = img, ny0 = y0, nx0 = x0;                                      // (the last tile is loaded once more: no branch around the loads)
+    if (!last) {
+      if (++tx == a.tiles_x) { tx = 0; if (++ty == a.tiles_y) { ty = 0; ++nimg; } }
+      ny0 = ty * TILE; nx0 = tx * TILE;
+    }
     issue_patch(nimg, ny0, nx0);
 
     // pooled output: lane (lq, lp) of subtile ps stores channels n0 + 4lp .. +3 of pooled pixel (y0/2 + 2*wave + ps/2, x0/2 + 4*(ps%2) + lq)
     char* const obase = a.e.out + ((((size_t)img * Ho + (y0 >> 1) + 2 * wave) * Wo + (x0 >> 1)) * a.e.out_stride + n0) * sizeof(T);   // wave-uniform
     const bool col_in[2] = {x0 + 2 * lq < a.e.W, x0 + 8 + 2 * lq < a.e.W};
-    auto gather = [&](int ps, uint4 (&xf)[2]) {
+    auto gather = [&](int ps, uint2 (&xf)[3]) {
       const int d = ((2 * (ps >> 1)) * PW + 8 * (ps & 1)) * 4;             // compile-time: an immediate of the ds_read
-      const uint2 pa = *reinterpret_cast<const uint2*>(pt + ga + d), pb = *reinterpret_cast<const uint2*>(pt + gb + d), pc = *reinterpret_cast<const uint2*>(pt + gc + d);
-      xf[0] = make_uint4(pa.x, pa.y, pb.x, pb.y);
-      xf[1] = make_uint4(pc.x, pc.y, pc.x, pc.y);
+      xf[0] = *reinterpret_cast<const uint2*>(pt + ga + d); xf[1] = *reinterpret_cast<const uint2*>(pt + gb + d); xf[2] = *reinterpret_cast<const uint2*>(pt + gc + d);
     };
-    uint4 xf[2][2];
+    uint2 xf[2][3];
     gather(0, xf[0]);
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
@@ -806,9 +829,10 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_pool_kernel(const 
       __builtin_amdgcn_sched_barrier(0);
       f32x4 acc[NCS];
 #pragma unroll
-      for (int cs = 0; cs < NCS; ++cs) acc[cs] = mma16<T>(xf[ps & 1][0], wf[0][cs], f32x4{0.f, 0.f, 0.f, 0.f});   // rows = pixels, columns = channels
+      for (int cs = 0; cs < NCS; ++cs)   // rows = pixels, columns = channels
+        acc[cs] = mma16<T>(make_uint4(xf[ps & 1][0].x, xf[ps & 1][0].y, xf[ps & 1][1].x, xf[ps & 1][1].y), wf[cs], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-      for (int cs = 0; cs < NCS; ++cs) acc[cs] = mma16<T>(xf[ps & 1][1], wf[1][cs], acc[cs]);
+      for (int cs = 0; cs < NCS; ++cs) acc[cs] = mma16_k16<T>(xf[ps & 1][2], wf8[cs], acc[cs]);
       // All 8 MFMAs, then the epilogue -- pinned.  Left free, the compiler (ROCm 7.2) interleaves them in the branch-free FULL
       // form: "D1 = mfma(.., C = D0); 2 VALU; D0 = mfma(.., 0); s_nop 4; VALU reads D1", and rows 12..15 of D1 (the last
       // pass) then come out wrong on gfx950 (channel 4j+1 of every 4th pooled pixel; found by tests/test_gpu_parity.py).
@@ -828,16 +852,20 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_pool_kernel(const 
         *reinterpret_cast<uint2*>(o + olane) = make_uint2(Half<T>::pack(m[0], m[1]), Half<T>::pack(m[2], m[3]));
       }
       __builtin_amdgcn_sched_barrier(0);
-      FSTAMP(3 + ps);
+      FSEG(2 + ps);
     }
-    item = next; img = nimg; y0 = ny0; x0 = nx0; buf ^= 1;
+    ++item; img = nimg; y0 = ny0; x0 = nx0; buf ^= 1;
   };
   tile();
   while (!last) tile();
 #ifdef EXP_FSTAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   FSTAMP(7);
-  if (dbg && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dbg[(size_t)blockIdx.x * 12 + 9] = t_; }
+  if (dbg && tid == 0) {
+    unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dbg[(size_t)blockIdx.x * 12 + 9] = t_;
+    for (int k = 0; k < 6; ++k) dbg[(size_t)blockIdx.x * 12 + 1 + k] = tacc[k];
+    dbg[(size_t)blockIdx.x * 12 + 8] = item_end - (band0 + ((int)blockIdx.x >> 3) * run);
+  }
 #endif
 }
 
@@ -902,6 +930,7 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   fill_epi(a.e, d->H, d->W, d->post_scale, d->post_shift, d->act, d->pool, d->residual, d->res_stride, d->out, d->out_stride, d->out_nchw3);
   a.pool_partial = d->pool_partial;
   if (conv_wide_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr)) return launch_conv_wide(Traits<T>::DT, a, stream);
+  if (conv_thin_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr)) return launch_conv_thin(Traits<T>::DT, a, stream);
   const int bn = (d->cout % 64 == 0) ? 64 : 16;
   a.n_tiles = d->cout / bn;
   // Small feature maps (32x32 at the network's deep end) do not fill 256 CUs with 16x16 tiles: switch to 8x8 tiles

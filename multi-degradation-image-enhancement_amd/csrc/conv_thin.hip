@@ -1,0 +1,319 @@
+// DenseLayers at full resolution (decoder.final_dense layers 1..3, models/cdan.py:35-46,155):
+//     out[16] = act(conv3x3(relu(bn(concat(base, g0, ..)))) * post_scale + post_shift)
+// with at most 8 live 16-byte channel columns (<= 64 stored input channels) and 16 output channels, 16-bit storage.
+//
+// Why a kernel of their own.  conv_kernel runs these at 40-50 % of their HBM floor (final.l1/l2/l3: 52 / 72 / 78 us against
+// 21 / 29 / 38 us at B = 32, 256x256; this kernel: 47 / 61 / 73 us -- what is left is at the end of this comment).  Stamps of its sibling for the first layer (tools/stamp_first.py) showed what such
+// a tile really pays for: every vector instruction is 4 cycles of a SIMD (integer multiplies and 64-bit address arithmetic
+// 16), a branch around a load or a store turns the compiler's counted waits into vmcnt(0) -- the wave then also waits for the
+// ~2 us acknowledgement of its own stores -- and a workgroup that lives for one tile pays weight staging, constants and
+// launch for 256 pixels.  Here:
+//   * persistent workgroups walk a contiguous run of tiles inside their XCD's share of the picture (increment with carry:
+//     no division after the prologue); the pre-activation constants go to LDS and the weights to registers ONCE;
+//   * one wave stages one 16-byte column of the input at a time (column j = wave + 4c): its segment pointer and pixel stride
+//     are wave-uniform, so a patch load is "scalar base + one 24-bit multiply" and the column's BatchNorm constants are
+//     read once per tile;
+//   * a wave's four pixel subtiles are four ROWS of 16 consecutive pixels, so the operand fragment of input row r and
+//     column shift kw serves three output rows (kh = 0, 1, 2): 18 LDS reads for a chunk's 36 MFMAs instead of 36, and the
+//     weight fragments live in registers for the whole run.  With 16 outputs every pixel fragment feeds exactly one MFMA:
+//     conv_kernel's 5 ds_read_b128 per 4 MFMAs are 2880 LDS cycles of a tile (128 B/clk), 2.5 x its matrix-pipe time;
+//   * the NEXT tile's columns are loaded into registers right after the barrier and fly under this tile's MFMAs and stores;
+//     every load and store is unconditional (border lanes read the tile's own first pixel and are zeroed at the LDS write;
+//     a dead column slot reads one line), the first tile is peeled off the loop, and so the wait before the LDS write is
+//     a counted vmcnt(stores issued after the loads), never vmcnt(0);
+//   * all live columns of a tile are in LDS at once (plane = column, conv_kernel's bank-conflict-free pitch): two barriers
+//     per TILE instead of two per K chunk.
+// What is left (tools/stamp_thin.py): per tile a wave issues ~270 vector instructions for the pre-activation of its 12
+// patch units (unpack, fused multiply-add, round, ReLU: 5 per dword) next to 72 MFMAs, and with the weights in registers
+// only two waves fit a SIMD, so the phases of the CU's two workgroups overlap imperfectly: ~60 % of the issue bound.
+// Arithmetic is conv_kernel's, operation for operation (PreAct on the 16-bit input, fp32 accumulate in the same K order,
+// one fused multiply-add in the epilogue), so results are bit-identical to it (tests/test_gpu_parity.py).
+#include <stdlib.h>
+#include <algorithm>
+
+#include "conv_common.hpp"
+
+namespace mdie {
+
+constexpr int TH_THREADS = 256;                                           // 4 waves: wave w owns pixel rows 4w .. 4w+3 of the tile
+constexpr int TH_TILE = 16, TH_PW = TH_TILE + 2;
+constexpr int TH_PLANE = ((TH_PW * PWP * 16 + 127) / 256) * 256 + 128;   // conv_kernel's ConvGeom<3, 16, 16>::PLANE
+constexpr int TH_WCHUNK = 4 * 9 * 16 * 16;                                // packed weights of one 64-byte K chunk, 16 outputs
+constexpr int TH_MAXCOL = 8;
+constexpr int TH_PIT = (TH_PW * TH_PW + 63) / 64;                         // 6 staging iterations of a wave over the 324 patch pixels
+
+struct ThinArgs {
+  int B, H, W, tiles_x, tiles_y;
+  int ncol, cin;                    // live 16-byte columns, stored input channels
+  const char* col_ptr[TH_MAXCOL];   // first byte of column j at pixel 0 (segment base + channel offset)
+  unsigned col_stride[TH_MAXCOL];   // bytes per pixel of the segment the column lives in
+  const float *pre_scale, *pre_shift;   // [cin] folded BatchNorm of the input channels (stored-channel order)
+  const char* weight;               // mdie_pack_conv_weight layout, cout_stored = 16
+  const float *post_scale, *post_shift;   // [16]
+  char* out; unsigned out_stride;   // bytes per pixel
+  unsigned long long* dbg;          // (diagnostic builds)
+};
+
+#ifdef EXP_TSTAMPS   // diagnostic build only (tools/stamp_thin.py): per-segment shader-clock sums of wave 0 of each workgroup
+static unsigned long long* g_thin_dbg = nullptr;
+#define TSEG(k) do { if (dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if ((k) >= 0) tacc[(k) < 0 ? 0 : (k)] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define TSEG(k) do {} while (0)
+#endif
+
+// NCHUNK = 64-byte K chunks (1: <= 4 columns, 2: <= 8); CPW = NCHUNK = column slots per wave (column j = wave + 4c)
+template <typename T, int NCHUNK, int ACT>
+__global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs a, const int n_items) {
+  static_assert(sizeof(T) == 2, "16-bit storage types");
+  constexpr int PW = TH_PW, PIT = TH_PIT, CPW = NCHUNK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const lds_patch = smem;                                             // [ncol] planes
+  float* const lds_pre = reinterpret_cast<float*>(smem + a.ncol * TH_PLANE);   // [ncol * 8] scale, [ncol * 8] shift
+
+  const int tid = threadIdx.x, lane = tid & 63, lq = lane >> 4, lp = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- this workgroup's run of tiles (see conv_first_pool_kernel) ----
+  const int per_xcd = (n_items + 7) >> 3, nwg = gridDim.x >> 3;
+  const int band0 = ((int)blockIdx.x & 7) * per_xcd, band1 = min(band0 + per_xcd, n_items);
+  const int run = (per_xcd + nwg - 1) / nwg;
+  int item = band0 + ((int)blockIdx.x >> 3) * run;
+  const int item_end = min(item + run, band1);
+  if (item >= item_end) return;
+#ifdef EXP_TSTAMPS
+  unsigned long long* const dbg = a.dbg;
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0, rstart = 0;
+  if (dbg) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart), "=s"(rstart) :: "memory");
+  const int item_first = item;
+#endif
+  int tx, ty, img;
+  { int r = item; tx = r % a.tiles_x; r /= a.tiles_x; ty = r % a.tiles_y; img = r / a.tiles_y; }
+
+  // ---- once per workgroup: weight fragments -> registers (A row lp = output channel, K group lq), constants -> LDS ----
+  uint4 wreg[NCHUNK][9];
+#pragma unroll
+  for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) wreg[k][tap] = *reinterpret_cast<const uint4*>(a.weight + (size_t)k * TH_WCHUNK + ((lq * 9 + tap) * 16 + lp) * 16);
+  {
+    const int nc = a.ncol * 8;
+    for (int c = tid; c < nc; c += TH_THREADS) { lds_pre[c] = c < a.cin ? a.pre_scale[c] : 0.f; lds_pre[nc + c] = c < a.cin ? a.pre_shift[c] : 0.f; }
+  }
+  const float4 esc = *reinterpret_cast<const float4*>(a.post_scale + 4 * lq), esh = *reinterpret_cast<const float4*>(a.post_shift + 4 * lq);
+
+  // ---- lane constants ----
+  // staging: patch pixel p = lane + 64 it: offset in pixels from the patch corner, LDS offset inside a plane, border classes
+  unsigned dp[PIT], ldst[PIT];
+  unsigned m_top = 0, m_bot = 0, m_left = 0, m_right = 0, m_valid = 0;
+#pragma unroll
+  for (int it = 0; it < PIT; ++it) {
+    const unsigned p = lane + 64 * it, py = p / PW, px = p - py * PW;
+    dp[it] = py * (unsigned)a.W + px;
+    ldst[it] = (py * PWP + px) * 16;
+    m_valid |= (p < PW * PW ? 1u : 0u) << it;
+    m_top |= (py == 0 ? 1u : 0u) << it; m_bot |= (py == PW - 1 ? 1u : 0u) << it;
+    m_left |= (px == 0 ? 1u : 0u) << it; m_right |= (px == PW - 1 ? 1u : 0u) << it;
+  }
+  // this wave's column slots
+  const char* cptr[CPW]; unsigned cstr[CPW]; bool clive[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    const int j = wave + 4 * c;
+    clive[c] = j < a.ncol;
+    const int jj = clive[c] ? j : 0;
+    cptr[c] = a.col_ptr[jj]; cstr[c] = a.col_stride[jj];
+  }
+  // operands: B column lp of the wave's subtile ps = pixel (4 wave + ps, lp) -- 16 consecutive pixels of one row, so the
+  // fragment of input row r and column shift kw serves the three output rows r, r-1, r-2 (taps kh = 0, 1, 2): 18 LDS reads
+  // for a chunk's 36 MFMAs instead of 36.  K group lq of chunk k = plane min(4k + lq, ncol - 1) (a plane past the live
+  // columns meets zero weights: any finite data will do).
+  int xoff[NCHUNK];
+#pragma unroll
+  for (int k = 0; k < NCHUNK; ++k) xoff[k] = min(4 * k + lq, a.ncol - 1) * TH_PLANE + ((4 * wave) * PWP + lp) * 16;
+  // output: lane (lq, lp) stores channels 4 lq .. 4 lq + 3 of pixel lp of the row: 512 contiguous bytes per 16 lanes x 4
+  const unsigned olane = (unsigned)lp * a.out_stride + (unsigned)lq * 8u;
+
+  uint4 pv[CPW][PIT];
+  unsigned okm = 0;
+  bool border = false;
+  auto issue = [&](int img_, int y0, int x0) {
+    border = y0 == 0 || x0 == 0 || y0 + TH_TILE == a.H || x0 + TH_TILE == a.W;
+    okm = m_valid & ~((y0 == 0 ? m_top : 0u) | (y0 + TH_TILE == a.H ? m_bot : 0u) | (x0 == 0 ? m_left : 0u) | (x0 + TH_TILE == a.W ? m_right : 0u));
+    const long long gp0 = ((long long)img_ * a.H + (y0 - 1)) * a.W + (x0 - 1);   // pixel index of the patch corner (may lie before the image: never read)
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      const char* const base = cptr[c] + gp0 * (long long)cstr[c];           // wave-uniform
+      const unsigned self = ((unsigned)a.W + 1u) * cstr[c];                  // the tile's own first pixel: always inside
+#pragma unroll
+      for (int it = 0; it < PIT; ++it) {
+        const unsigned off = clive[c] ? (((okm >> it) & 1u) ? __umul24(dp[it], cstr[c]) : self) : self;
+        pv[c][it] = *reinterpret_cast<const uint4*>(base + off);
+      }
+    }
+  };
+
+  int y0 = ty * TH_TILE, x0 = tx * TH_TILE;
+  issue(img, y0, x0);
+  __syncthreads();                                                           // the constants are in LDS
+
+  bool last = false;
+  auto tile = [&]() {
+    TSEG(-1);
+    // ---- this tile's columns: pre-activation, zero padding of the ACTIVATED tensor, -> LDS ----
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      if (clive[c]) {   // wave-uniform; no global memory instruction inside
+        const int j = wave + 4 * c;
+        f32x2 ps_[4], pb_[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float4 s4 = *reinterpret_cast<const float4*>(lds_pre + j * 8 + 4 * i), b4 = *reinterpret_cast<const float4*>(lds_pre + a.ncol * 8 + j * 8 + 4 * i);
+          ps_[2 * i] = f32x2{s4.x, s4.y}; ps_[2 * i + 1] = f32x2{s4.z, s4.w};
+          pb_[2 * i] = f32x2{b4.x, b4.y}; pb_[2 * i + 1] = f32x2{b4.z, b4.w};
+        }
+        char* const plane = lds_patch + j * TH_PLANE;
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+          const uint4 v = PreAct<T>::apply(pv[c][it], ps_, pb_);
+          if (it < PIT - 1 || lane + 64 * it < PW * PW) *reinterpret_cast<uint4*>(plane + ldst[it]) = v;
+        }
+        if (border) {   // wave-uniform, border tiles only: the out-of-image pixels are overwritten with zeros (same lane, in order)
+#pragma unroll
+          for (int it = 0; it < PIT; ++it)
+            if (!((okm >> it) & 1u) && (it < PIT - 1 || lane + 64 * it < PW * PW)) *reinterpret_cast<uint4*>(plane + ldst[it]) = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+    }
+    TSEG(0);
+    __syncthreads();
+    TSEG(1);
+    // ---- next tile's columns into registers ----
+    last = item + 1 >= item_end;
+    int nimg = img, ny0 = y0, nx0 = x0;                                      // (the last tile is loaded once more: no branch around the loads)
+    if (!last) {
+      if (++tx == a.tiles_x) { tx = 0; if (++ty == a.tiles_y) { ty = 0; ++nimg; } }
+      ny0 = ty * TH_TILE; nx0 = tx * TH_TILE;
+    }
+    issue(nimg, ny0, nx0);
+    TSEG(2);
+
+    // ---- MFMA phase, by input row: the three fragments of row r+1 are read before the MFMAs of row r (pinned) ----
+    // Per output the products still arrive in conv_kernel's order (chunk, then tap = 3 kh + kw ascending): bit-identical sums.
+    f32x4 acc[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) acc[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) {
+      const char* const xk = lds_patch + xoff[k];
+      uint4 xf[2][3];
+      auto read_row = [&](int r, int b) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) xf[b][kw] = *reinterpret_cast<const uint4*>(xk + (r * PWP + kw) * 16);
+      };
+      read_row(0, 0);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        if (r + 1 < 6) read_row(r + 1, (r + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kh = 2; kh >= 0; --kh) {          // output row ps = r - kh, ascending
+          const int ps = r - kh;
+          if (ps >= 0 && ps < 4) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) acc[ps] = mma16<T>(wreg[k][kh * 3 + kw], xf[r & 1][kw], acc[ps]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    TSEG(3);
+    // ---- epilogue: affine, activation, one 8-byte store per lane and row (unconditional: tiles are full) ----
+    char* const obase = a.out + ((((size_t)img * a.H + y0 + 4 * wave) * a.W + x0) * a.out_stride);   // wave-uniform
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      f32x2 lo = __builtin_elementwise_fma(f32x2{acc[ps][0], acc[ps][1]}, f32x2{esc.x, esc.y}, f32x2{esh.x, esh.y});
+      f32x2 hi = __builtin_elementwise_fma(f32x2{acc[ps][2], acc[ps][3]}, f32x2{esc.z, esc.w}, f32x2{esh.z, esh.w});
+      i16x2 p0 = half_bits<T>(lo), p1 = half_bits<T>(hi);
+      if constexpr (ACT == MDIE_ACT_RELU) { p0 = __builtin_elementwise_max(p0, i16x2{0, 0}); p1 = __builtin_elementwise_max(p1, i16x2{0, 0}); }
+      char* const o = obase + (size_t)ps * a.W * a.out_stride;                                         // wave-uniform
+      *reinterpret_cast<uint2*>(o + olane) = make_uint2(__builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, p1));
+    }
+    ++item; img = nimg; y0 = ny0; x0 = nx0;
+    TSEG(4);
+    __syncthreads();                                                         // every wave is done reading the planes
+    TSEG(5);
+  };
+  // (first tile peeled: the loop is entered, like its back edge, with "this wave's loads, then 4 stores" outstanding)
+  tile();
+  while (!last) tile();
+#ifdef EXP_TSTAMPS
+  if (dbg && tid == 0) {
+    unsigned long long t1, r1; asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+    unsigned long long* o = dbg + (size_t)blockIdx.x * 12;
+    for (int k = 0; k < 6; ++k) o[k] = tacc[k];
+    o[6] = item - item_first; o[7] = t1 - tstart; o[8] = rstart; o[9] = r1;
+  }
+#endif
+}
+
+// ---- host -----------------------------------------------------------------------------------------------------------
+bool conv_thin_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw3) {
+  static const int off = getenv("MDIE_CONV_THIN") ? !atoi(getenv("MDIE_CONV_THIN")) : 0;   // experiments: MDIE_CONV_THIN=0 -> conv_kernel
+  if (off || dtype == MDIE_F32 || ksize != 3 || has_nchw3 || !a.pre_scale || a.cout != 16) return false;
+  if (a.e.pool || a.e.residual || a.pool_partial || (a.e.act != MDIE_ACT_NONE && a.e.act != MDIE_ACT_RELU)) return false;
+  if (a.H % TH_TILE != 0 || a.W % TH_TILE != 0) return false;
+  const int ncol = (a.cin + 7) / 8;
+  if (ncol > TH_MAXCOL || a.nchunk > 2) return false;
+  for (int s = 0; s < a.nseg; ++s)
+    if (a.seg[s].ch_begin % 8 != 0 || a.seg[s].ch_end % 8 != 0 || (size_t)(TH_PW + 1) * a.W * a.seg[s].stride * 2 >= ((size_t)1 << 24) * 16) return false;
+  if ((size_t)a.W * 20 >= ((size_t)1 << 24)) return false;                                      // 24-bit multiply of the pixel offset
+  const long items = (long)a.B * (a.H / TH_TILE) * (a.W / TH_TILE);
+  return items >= 1024;   // fewer: one tile per workgroup, nothing to pipeline -- conv_kernel
+}
+
+template <typename T, int NCHUNK>
+static int launch_thin_t(const ThinArgs& t, int act, int items, hipStream_t stream) {
+  const size_t lds = (size_t)t.ncol * TH_PLANE + (size_t)2 * t.ncol * 8 * sizeof(float);
+  const int per_cu = 2;                                                       // (registers: weights live in them)
+  static const int force = getenv("MDIE_THIN_WGS_PER_CU") ? atoi(getenv("MDIE_THIN_WGS_PER_CU")) : 0;   // (experiments)
+  const int wgs = 8 * cdiv(std::min(items, 256 * (force > 0 ? force : per_cu)), 8);
+  TimedLaunch tl(MDIE_K_CONV3);
+#define MDIE_THIN(ACT)                                                                                            \
+  do {                                                                                                            \
+    static LdsOptIn opt;                                                                                          \
+    if (!opt.ensure(reinterpret_cast<const void*>(&conv_thin_kernel<T, NCHUNK, ACT>), 64 * 1024)) return MDIE_ELAUNCH; \
+    hipLaunchKernelGGL((conv_thin_kernel<T, NCHUNK, ACT>), dim3(wgs), dim3(TH_THREADS), lds, stream, t, items);      \
+  } while (0)
+  if (act == MDIE_ACT_RELU) MDIE_THIN(MDIE_ACT_RELU); else MDIE_THIN(MDIE_ACT_NONE);
+#undef MDIE_THIN
+  MDIE_LAUNCH_CHECK("mdie_conv_fwd");
+  return MDIE_OK;
+}
+
+int launch_conv_thin(int dtype, const ConvArgs& a, hipStream_t stream) {
+  ThinArgs t{};
+  t.B = a.B; t.H = a.H; t.W = a.W; t.tiles_x = a.W / TH_TILE; t.tiles_y = a.H / TH_TILE;
+  t.ncol = (a.cin + 7) / 8; t.cin = a.cin;
+  for (int j = 0; j < t.ncol; ++j) {
+    const int c0 = j * 8;
+    t.col_ptr[j] = nullptr;
+    for (int s = 0; s < a.nseg; ++s)
+      if (c0 >= a.seg[s].ch_begin && c0 < a.seg[s].ch_end) { t.col_ptr[j] = a.seg[s].ptr + (size_t)(c0 - a.seg[s].ch_begin) * 2; t.col_stride[j] = (unsigned)a.seg[s].stride * 2u; }
+    MDIE_REQUIRE(t.col_ptr[j] != nullptr, "mdie_conv_fwd: input channel %d belongs to no segment", c0);
+  }
+  t.pre_scale = a.pre_scale; t.pre_shift = a.pre_shift; t.weight = a.weight;
+  t.post_scale = a.e.post_scale; t.post_shift = a.e.post_shift;
+  t.out = a.e.out; t.out_stride = (unsigned)a.e.out_stride * 2u;
+  const int items = a.B * t.tiles_x * t.tiles_y;
+#ifdef EXP_TSTAMPS
+  t.dbg = g_thin_dbg;
+#endif
+  if (dtype == MDIE_BF16) return t.ncol <= 4 ? launch_thin_t<bf16, 1>(t, a.e.act, items, stream) : launch_thin_t<bf16, 2>(t, a.e.act, items, stream);
+  return t.ncol <= 4 ? launch_thin_t<f16, 1>(t, a.e.act, items, stream) : launch_thin_t<f16, 2>(t, a.e.act, items, stream);
+}
+
+}  // namespace mdie
+
+#ifdef EXP_TSTAMPS
+extern "C" void mdie_exp_set_thin_dbg(void* p) { mdie::g_thin_dbg = (unsigned long long*)p; }
+#endif

@@ -690,6 +690,59 @@ def test_wide_conv_lds_dma_kernel(E, L, prec, case):
         assert torch.equal(part[:, :, 1], o.amax(2))
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cin_segs,act", [([8, 16], "none"), ([8, 16, 16], "none"), ([8, 16, 16, 16], "none"), ([16, 16], "relu"), ([16, 16, 16, 16], "none")])
+def test_thin_persistent_conv_kernel(E, L, prec, cin_segs, act):
+    """conv_thin_kernel (csrc/conv_thin.hip: persistent workgroups, one wave per 16-byte input column, next tile prefetched
+    into registers, all K chunks of a tile in LDS at once) -- the kernel behind decoder.final_dense layers 1..3 at BASELINE
+    sizes (base + 1..3 growth maps = 3, 5, 7 live columns) -- against torch's CPU convolution on the same rounded operands,
+    and bit for bit against conv_kernel, which a batch with fewer than 1024 tiles still runs on: every image border, runs of
+    several tiles per workgroup that cross image boundaries, one and two K chunks, segments with their own strides, the
+    output written into a slice of a wider buffer."""
+    import ctypes as C
+    import torch.nn.functional as F
+    dt, td = E.dtype_id(prec), TORCH_DT[prec]
+    rnd = lambda t: t.to(td).float()
+    B, H, W = 5, 240, 256                  # 5 * 15 * 16 = 1200 tiles: conv_thin; 2 images = 480 tiles: conv_kernel
+    cin, cout = sum(cin_segs), 16
+    g = torch.Generator().manual_seed(cin * 11 + len(cin_segs))
+    strides = [c + (8 if i % 2 else 0) for i, c in enumerate(cin_segs)]
+    bufs = [rnd(torch.randn(B, H, W, st, generator=g)) for st in strides]
+    w = rnd(torch.randn(cout, cin, 3, 3, generator=g) * 0.2)
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ps, pt = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    x = torch.cat([b[..., :c] for b, c in zip(bufs, cin_segs)], 3)
+    xa = rnd(torch.relu(x * ps + pt))
+    ref = (F.conv2d(xa.permute(0, 3, 1, 2), w, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    if act == "relu":
+        ref = torch.relu(ref)
+
+    dbufs = [b.cuda().to(td) for b in bufs]
+    wp = E.pack_conv_weight(w, dt, cin_stored=cin).cuda()
+    dsc, dsh, dps, dpt = sc.cuda(), sh.cuda(), ps.cuda(), pt.cuda()
+
+    def run(nb):
+        out = torch.full((nb, H, W, 40), -7.0, device="cuda", dtype=td)
+        d = L.ConvDesc()
+        d.dtype, d.B, d.H, d.W, d.ksize, d.nseg = dt, nb, H, W, 3, len(dbufs)
+        for i, (b, c) in enumerate(zip(dbufs, cin_segs)):
+            d.inp[i] = L.Seg(b.data_ptr(), c, b.shape[3])
+        d.cin, d.cout = cin, cout
+        d.pre_scale, d.pre_shift = dps.data_ptr(), dpt.data_ptr()
+        d.weight, d.post_scale, d.post_shift = wp.data_ptr(), dsc.data_ptr(), dsh.data_ptr()
+        d.act, d.pool = (L.ACT_RELU if act == "relu" else L.ACT_NONE), 0
+        d.out, d.out_stride = out[..., 16:].data_ptr(), 40
+        L.check(L.lib.mdie_conv_fwd(C.byref(d), None), "mdie_conv_fwd")
+        torch.cuda.synchronize()
+        return out
+
+    out = run(B)
+    assert rel_to_max(out[..., 16:32], ref) <= {"bf16": 8e-3, "fp16": 1e-3}[prec]
+    assert (out[..., :16] == -7.0).all() and (out[..., 32:] == -7.0).all()     # nothing written outside the slice
+    two = run(2)
+    assert torch.equal(two, out[:2]), "the two convolution kernels must agree bit for bit"
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # training mode (SURVEY.md 8a rows a5, a13, a14): HIP convolutions (forward / dgrad / wgrad) under autograd
 # ---------------------------------------------------------------------------------------------------------------------

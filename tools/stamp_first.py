@@ -47,24 +47,40 @@ run(True)
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 20 * 1e3
 st = dbg.view(grid, 12).cpu().double().numpy()
-st = st[st[:, 0] > 0]          # (the pooled 16-bit kernel is persistent: fewer workgroups than tiles; slots 1..6 then hold a workgroup's LAST tile)
+bidx = np.nonzero(st[:, 0] > 0)[0]
+st = st[st[:, 0] > 0]          # the kernel is persistent: fewer workgroups than tiles
 tiles, grid = grid, len(st)
-t = st[:, :8]
-real0, real1, hw = st[:, 10], st[:, 9], st[:, 11].astype(np.int64)
-life = t[:, 7] - t[:, 0]
+real0, real1, hw, ntile = st[:, 10], st[:, 9], st[:, 11].astype(np.int64), st[:, 8]
+life = st[:, 7] - st[:, 0]
 clk = np.median(life / ((real1 - real0) * 10.0 + 1e-9))       # s_memrealtime ticks at 100 MHz
-seg = np.diff(t, axis=1)
-names = ["loads+lds write", "barrier", "ps0", "ps1", "ps2", "ps3", "store drain"]
-print(f"conv_first bf16 B={B} {S}x{S}: {us:.1f} us/launch, {tiles} tiles on {grid} workgroups, shader clock ~{clk:.2f} GHz (median over workgroups)")
-print("  per workgroup (wave 0), cycles, median [p10 .. p90]:")
+seg = st[:, 1:7] / ntile[:, None]                             # per-tile averages of each workgroup
+names = ["wait for loads + patch write", "barrier", "issue next patch + subtile 0", "subtile 1", "subtile 2", "subtile 3"]
+print(f"conv_first (pooled 16-bit kernel) bf16 B={B} {S}x{S}: {us:.1f} us/launch, {tiles} tiles on {grid} workgroups ({np.median(ntile):.0f} tiles each), "
+      f"shader clock ~{clk:.2f} GHz")
+print("  wave 0 of each workgroup, cycles per tile (mean over its tiles), median over workgroups [p10 .. p90]:")
 for i, n in enumerate(names):
-    print(f"    {n:16s} {np.median(seg[:, i]):8.0f} [{np.percentile(seg[:, i], 10):6.0f} .. {np.percentile(seg[:, i], 90):6.0f}]")
-print(f"    {'lifetime':16s} {np.median(life):8.0f} [{np.percentile(life, 10):6.0f} .. {np.percentile(life, 90):6.0f}]")
-# which CU: HW_ID bits (gfx9): wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13 ... (xcc in XCC_ID, not read: 8 XCDs alias)
-cu = (hw >> 8) & 0xF
-se = (hw >> 13) & 0x7
-key = se * 16 + cu
+    print(f"    {n:30s} {np.median(seg[:, i]):8.0f} [{np.percentile(seg[:, i], 10):6.0f} .. {np.percentile(seg[:, i], 90):6.0f}]")
+tot = seg.sum(axis=1)
+print(f"    {'sum':30s} {np.median(tot):8.0f} [{np.percentile(tot, 10):6.0f} .. {np.percentile(tot, 90):6.0f}]")
+print(f"    {'lifetime / tiles':30s} {np.median(life / ntile):8.0f}   (lifetime {np.median(life):.0f})")
 span = (real1.max() - real0.min()) * 10.0   # ns
-print(f"  first start .. last end: {span / 1e3:.1f} us; sum of lifetimes / span / 256 CUs = {np.sum((real1 - real0) * 10.0) / span / 256:.2f} workgroups resident per CU on average")
-order = np.argsort(real0)
-print(f"  start times (us after the first) of workgroups #0, 1k, 2k ...: " + " ".join(f"{(real0[order[i]] - real0.min()) * 0.01:.1f}" for i in range(0, grid, max(grid // 8, 1))))
+print(f"  first start .. last end: {span / 1e3:.1f} us; workgroup lifetimes {np.median((real1 - real0) * 0.01):.1f} us median, {np.max((real1 - real0) * 0.01):.1f} us max")
+cu = ((hw >> 32) & 0xF) * 1024 + ((hw >> 13) & 0x7) * 64 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xF)     # XCC, SE, SH, CU of HW_ID
+ids, cnt = np.unique(cu, return_counts=True)
+print(f"  placement: {len(ids)} distinct CUs used; workgroups per CU: " + ", ".join(f"{n} x{(cnt == n).sum()}" for n in sorted(set(cnt))))
+lt = (real1 - real0) * 0.01
+for n in sorted(set(cnt)):
+    sel = np.isin(cu, ids[cnt == n])
+    print(f"    CUs holding {n}: workgroup lifetime median {np.median(lt[sel]):.1f} us")
+xcc = (hw >> 32) & 0xF
+print("  lifetime median by XCC: " + " ".join(f"{x}:{np.median(lt[xcc == x]):.1f}" for x in sorted(set(xcc))))
+q = (bidx >> 3) * 4 // max((bidx >> 3).max() + 1, 1)
+print("  lifetime median by quarter of the XCD's run list: " + " ".join(f"{np.median(lt[q == k]):.1f}" for k in range(4)))
+simd_wave = hw & 0x3F
+print("  lifetime p10/p50/p90/max: " + " ".join(f"{np.percentile(lt, p):.1f}" for p in (10, 50, 90, 100)))
+if os.environ.get("STAMP_VERBOSE"):
+    j = bidx >> 3
+    for c in ids[:6]:
+        sel = np.nonzero((cu == c) & (xcc == 0))[0]
+        if len(sel):
+            print(f"    CU {c}: " + "  ".join(f"j={j[i]} simd/wave={simd_wave[i]:02x} {lt[i]:.1f}us" for i in sel))
