@@ -37,7 +37,13 @@ namespace mdie {
 
 constexpr int TH_THREADS = 256;                                           // 4 waves: wave w owns pixel rows 4w .. 4w+3 of the tile
 constexpr int TH_TILE = 16, TH_PW = TH_TILE + 2;
-constexpr int TH_PLANE = ((TH_PW * PWP * 16 + 127) / 256) * 256 + 128;   // conv_kernel's ConvGeom<3, 16, 16>::PLANE
+// Plane stride == 0 (mod 256 B).  A ds_read_b128 is served in 4 groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19,
+// 28-31} and the same in the upper half -- each of which must cover 64 distinct banks.  Here a 16-lane K group reads 16
+// CONSECUTIVE pixels (256 contiguous bytes) of its plane, so two K groups meet conflict-free when their planes start on the
+// same bank.  (conv_kernel's planes are == 128 (mod 256) for its 2x2-block pixel order: with that pitch this kernel's reads
+// were 2-way conflicted, SQ_LDS_BANK_CONFLICT = 32 % of SQ_LDS_IDX_ACTIVE.)
+constexpr int TH_PLANE = TH_PW * PWP * 16;
+static_assert(TH_PLANE % 256 == 0, "plane stride must keep the K groups on the same banks");
 constexpr int TH_WCHUNK = 4 * 9 * 16 * 16;                                // packed weights of one 64-byte K chunk, 16 outputs
 constexpr int TH_MAXCOL = 8;
 constexpr int TH_PIT = (TH_PW * TH_PW + 63) / 64;                         // 6 staging iterations of a wave over the 324 patch pixels
@@ -216,13 +222,12 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
         if (r + 1 < 6) read_row(r + 1, (r + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kh = 2; kh >= 0; --kh) {          // output row ps = r - kh, ascending
-          const int ps = r - kh;
-          if (ps >= 0 && ps < 4) {
+        for (int kw = 0; kw < 3; ++kw)             // (kw outside: consecutive MFMAs go to different accumulators)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) acc[ps] = mma16<T>(wreg[k][kh * 3 + kw], xf[r & 1][kw], acc[ps]);
+          for (int kh = 2; kh >= 0; --kh) {        // output row ps = r - kh, ascending
+            const int ps = r - kh;
+            if (ps >= 0 && ps < 4) acc[ps] = mma16<T>(wreg[k][kh * 3 + kw], xf[r & 1][kw], acc[ps]);
           }
-        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
