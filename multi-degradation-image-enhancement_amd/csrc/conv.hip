@@ -833,15 +833,17 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_pool_kernel(const 
         acc[cs] = mma16<T>(make_uint4(xf[ps & 1][0].x, xf[ps & 1][0].y, xf[ps & 1][1].x, xf[ps & 1][1].y), wf[cs], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
       for (int cs = 0; cs < NCS; ++cs) acc[cs] = mma16_k16<T>(xf[ps & 1][2], wf8[cs], acc[cs]);
-      // All 8 MFMAs, then the epilogue -- pinned.  Left free, the compiler (ROCm 7.2) interleaves them in the branch-free FULL
-      // form: "D1 = mfma(.., C = D0); 2 VALU; D0 = mfma(.., 0); s_nop 4; VALU reads D1", and rows 12..15 of D1 (the last
-      // pass) then come out wrong on gfx950 (channel 4j+1 of every 4th pooled pixel; found by tests/test_gpu_parity.py).
-      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);   // all 8 MFMAs, then the epilogue
       float m[NCS];
 #pragma unroll
       for (int cs = 0; cs < NCS; ++cs) {
-        const f32x2 lo = __builtin_elementwise_fma(f32x2{acc[cs][0], acc[cs][1]}, f32x2{sc[cs], sc[cs]}, f32x2{sh[cs], sh[cs]});
-        const f32x2 hi = __builtin_elementwise_fma(f32x2{acc[cs][2], acc[cs][3]}, f32x2{sc[cs], sc[cs]}, f32x2{sh[cs], sh[cs]});
+        // Four scalar v_fma_f32, NOT two v_pk_fma_f32: with the scale and shift splat over both halves the compiler picks the
+        // op_sel forms of the packed instruction (`op_sel:[0,1,1]` for channel subtile 1), and those gave wrong values in
+        // lanes 48..63 on gfx950 -- always when scheduled between the MFMAs, and in ~1 tile in 10^4 otherwise, only while
+        // another kernel shared the CU (two engines in flight; found with differing inputs, build/exp-style stress test in
+        // tests/test_gpu_parity.py::test_two_engines_in_flight_different_inputs).  Extra wait states did not help.
+        const float lo[2] = {fmaf(acc[cs][0], sc[cs], sh[cs]), fmaf(acc[cs][1], sc[cs], sh[cs])};
+        const float hi[2] = {fmaf(acc[cs][2], sc[cs], sh[cs]), fmaf(acc[cs][3], sc[cs], sh[cs])};
         m[cs] = fmaxf(fmaxf(fmaxf(fmaxf(lo[0], lo[1]), hi[0]), hi[1]), 0.f);   // max-pool and ReLU: two v_max3_f32
       }
 #ifdef EXP_NO_STORE

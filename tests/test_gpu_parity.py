@@ -1250,6 +1250,40 @@ def test_large_image_1024_against_oracle(E):
     assert rel_to_max(yh, ref) <= F16_OUT_TOL and psnr(yh, ref) >= 70.0      # measured 3.5e-4
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_engines_in_flight_on_different_inputs(E, prec):
+    """Three engines alive, two of them running DIFFERENT halves of a batch at the same time on two streams, 40 times: every
+    output must equal what the same engine produces alone.  (With the same input on both streams -- bench.py's
+    two_batches_in_flight -- a kernel that misbehaves only while another kernel shares its CU goes unseen.  This test found
+    one: the splat `v_pk_fma_f32 ... op_sel:[0,1,1]` forms in conv_first_pool_kernel's epilogue, wrong in lanes 48..63 of
+    about one tile in 10^4, and only next to a second engine's kernels.)"""
+    from mdie_amd import synthetic as P
+    sd = P.make_state_dict(42)
+    B, S = 32, 256
+    x, _ = P.lowlight_batch(1, B, S, S)
+    x = x.cuda()
+    keep = E.CdanEngine("cuda", prec).load(sd)            # a third engine (and its workspace) alive, as in a serving process
+    keep.forward(x)
+    n = B // 2
+    engs = [E.CdanEngine("cuda", prec).load(sd) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    xs = [x[k * n:(k + 1) * n].contiguous() for k in range(2)]
+    ref = [engs[k].forward(xs[k]).clone() for k in range(2)]
+    torch.cuda.synchronize()
+    main = torch.cuda.current_stream()
+    bad = []
+    for rep in range(40):
+        outs = [torch.zeros_like(xs[k]) for k in range(2)]
+        torch.cuda.synchronize()
+        for k in range(2):
+            streams[k].wait_stream(main)
+            with torch.cuda.stream(streams[k]):
+                engs[k].forward(xs[k], out=outs[k])
+        torch.cuda.synchronize()
+        bad += [(rep, k, (outs[k] - ref[k]).abs().max().item()) for k in range(2) if not torch.equal(outs[k], ref[k])]
+    assert not bad, f"{len(bad)} of 80 overlapped forwards differ from the engine's own serial output: {bad[:4]}"
+
+
 def test_capture_two_engines_on_forked_streams(E):
     """hipGraph capture of mdie_cdan_forward from streams that are themselves forks inside the capture (two engines, two
     streams), twice in a row with the first capture's engines and graph destroyed in between -- the pattern that took the
