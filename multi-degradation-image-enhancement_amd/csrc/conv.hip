@@ -840,8 +840,9 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_pool_kernel(const 
         // Four scalar v_fma_f32, NOT two v_pk_fma_f32: with the scale and shift splat over both halves the compiler picks the
         // op_sel forms of the packed instruction (`op_sel:[0,1,1]` for channel subtile 1), and those gave wrong values in
         // lanes 48..63 on gfx950 -- always when scheduled between the MFMAs, and in ~1 tile in 10^4 otherwise, only while
-        // another kernel shared the CU (two engines in flight; found with differing inputs, build/exp-style stress test in
-        // tests/test_gpu_parity.py::test_two_engines_in_flight_different_inputs).  Extra wait states did not help.
+        // another kernel shared the CU (two engines in flight on different inputs:
+        // tests/test_gpu_parity.py::test_engines_in_flight_on_different_inputs).  32 extra wait states after the MFMAs, a full
+        // vmcnt drain and the K = 32 form of the ninth tap changed nothing; these four instructions did.
         const float lo[2] = {fmaf(acc[cs][0], sc[cs], sh[cs]), fmaf(acc[cs][1], sc[cs], sh[cs])};
         const float hi[2] = {fmaf(acc[cs][2], sc[cs], sh[cs]), fmaf(acc[cs][3], sc[cs], sh[cs])};
         m[cs] = fmaxf(fmaxf(fmaxf(fmaxf(lo[0], lo[1]), hi[0]), hi[1]), 0.f);   // max-pool and ReLU: two v_max3_f32
