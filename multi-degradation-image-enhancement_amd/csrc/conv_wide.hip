@@ -176,7 +176,9 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
     } else {
       const int wp = wave + 8 * (k - WD_PP);   // = q * 9 + tap
       if (wp < WD_W_PIECES)
-        dma_piece(a.weight + (size_t)chunk * (4 * 9 * 16) * a.cout + (size_t)d_n0 * 16 + lane * 16 + (size_t)wp * a.cout * 16,
+        // POOL: LDS row cs*16 + j of the piece holds output channel 4j + cs (see the epilogue): the permutation costs nothing,
+        // it is the lane's SOURCE row
+        dma_piece(a.weight + (size_t)chunk * (4 * 9 * 16) * a.cout + (size_t)d_n0 * 16 + (POOL ? 4 * (lane & 15) + (lane >> 4) : lane) * 16 + (size_t)wp * a.cout * 16,
                   sb + WD_PATCH_BYTES + wp * 1024);
     }
   };
@@ -243,7 +245,9 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
 #pragma unroll
       for (int cs = 0; cs < NCS; ++cs)
 #pragma unroll
-        for (int ps = 0; ps < NPS; ++ps) acc[cs][ps] = mma16<T>(wf[tap & 1][cs], xf[tap & 1][ps], acc[cs][ps]);
+        for (int ps = 0; ps < NPS; ++ps)
+          acc[cs][ps] = POOL ? mma16<T>(xf[tap & 1][ps], wf[tap & 1][cs], acc[cs][ps])    // rows = pixels, columns = channels
+                             : mma16<T>(wf[tap & 1][cs], xf[tap & 1][ps], acc[cs][ps]);
       __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -260,7 +264,31 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
         esc[cs] = *reinterpret_cast<const float4*>(lds_epi + n0 + cs * 16 + lq * 4);
         esh[cs] = *reinterpret_cast<const float4*>(lds_epi + WD_MAX_COUT + n0 + cs * 16 + lq * 4);
       }
-      if constexpr (!STATS) {
+      if constexpr (POOL) {
+        // Pooled form (encoder.conv2/conv3), operand roles exchanged as in conv_first_pool_kernel: a lane's four accumulator
+        // registers are the 2x2 window of ONE pooled pixel (tile_pixel puts a window on 4 consecutive rows) for channel
+        // 4 lp + cs, so affine + ReLU + max-pool are four fma and two v_max3_f32 per subtile and channel group -- no DPP on
+        // all 64 lanes for a result a quarter of them keep -- and the lane stores 4 consecutive channels (8 bytes).  The
+        // epilogue was 3.1 k of the 15 k cycles conv2 spends per item (tools/stamp_wide.py).  Scalar fma on purpose: see
+        // conv_first_pool_kernel about the splat v_pk_fma_f32 forms.
+        const float4 p_sc = *reinterpret_cast<const float4*>(lds_epi + n0 + 4 * lp), p_sh = *reinterpret_cast<const float4*>(lds_epi + WD_MAX_COUT + n0 + 4 * lp);
+        const float sc4[4] = {p_sc.x, p_sc.y, p_sc.z, p_sc.w}, sh4[4] = {p_sh.x, p_sh.y, p_sh.z, p_sh.w};
+        const int Ho = a.e.H >> 1, Wo = a.e.W >> 1;
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+          const int blk = (strip * NPS + ps) * 4 + lq;                       // this lane group's 2x2 window of the 16x16 half tile
+          const int oy = (y0 >> 1) + (blk >> 3), ox = (x0 >> 1) + (blk & 7);
+          float m[NCS];
+#pragma unroll
+          for (int cs = 0; cs < NCS; ++cs) {
+            const float v0 = fmaf(acc[cs][ps][0], sc4[cs], sh4[cs]), v1 = fmaf(acc[cs][ps][1], sc4[cs], sh4[cs]);
+            const float v2 = fmaf(acc[cs][ps][2], sc4[cs], sh4[cs]), v3 = fmaf(acc[cs][ps][3], sc4[cs], sh4[cs]);
+            m[cs] = fmaxf(fmaxf(fmaxf(fmaxf(v0, v1), v2), v3), 0.f);
+          }
+          T* const o = reinterpret_cast<T*>(a.e.out) + (((size_t)img * Ho + oy) * Wo + ox) * a.e.out_stride + n0 + 4 * lp;
+          *reinterpret_cast<uint2*>(o) = make_uint2(Half<T>::pack(m[0], m[1]), Half<T>::pack(m[2], m[3]));
+        }
+      } else if constexpr (!STATS) {
         conv_epilogue_t<T, NCS, NPS, 16, ACT, POOL>(a.e, esc, esh, acc, img, y0, x0, n0, strip * NPS, lq, lp);
       } else {
         // per-channel sum / maximum of what this 16x16 half tile stores: one slab per half tile, in the raster order of
@@ -323,6 +351,7 @@ bool conv_wide_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw
   if (off || dtype == MDIE_F32 || ksize != 3 || has_nchw3 || a.pre_scale || a.nseg != 1) return false;
   if (a.cin % 32 != 0 || a.cin < 64 || a.cout % WD_BN != 0 || a.cout > WD_MAX_COUT) return false;
   if (a.W % WD_TW != 0 || a.H % WD_TH != 0) return false;
+  if (a.e.pool && a.e.residual) return false;                                                       // (the pooled epilogue has no residual input)
   if (a.e.act != MDIE_ACT_RELU && !(a.e.act == MDIE_ACT_NONE && !a.e.pool && !a.pool_partial)) return false;   // (NONE: training forward / dgrad)
   if (a.pool_partial && (a.e.pool || mdie_conv_tile(a.B, a.H, a.W, a.cout) != 16)) return false;   // slabs are 16x16 tiles
   if ((size_t)a.B * a.H * a.W * a.seg[0].stride * 2 >= ((size_t)1 << 32)) return false;            // 32-bit source offsets
