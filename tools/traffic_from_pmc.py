@@ -17,7 +17,7 @@ for f in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursi
     for r in rows:
         by_disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"]})[r["Counter_Name"]] = float(r["Counter_Value"])
     disp = [by_disp[k] for k in sorted(by_disp)]
-    starts = [i for i, d in enumerate(disp) if "conv_first_kernel" in d["name"]]
+    starts = [i for i, d in enumerate(disp) if "conv_first" in d["name"]]     # the first launch of a step (conv_first_kernel / conv_first_pool_kernel)
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         if not disp or cname not in disp[0]:
             continue
@@ -32,7 +32,7 @@ for f in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursi
             split = collections.defaultdict(float)
             for d in disp[a:b]:
                 n = d["name"]
-                key = "conv3x3" if ("conv_kernel" in n and "Li3E" in n) or "conv_first" in n or "conv_wide" in n else "conv1x1" if ("conv_kernel" in n or "conv1x1" in n) else \
+                key = "conv3x3" if ("conv_kernel" in n and "Li3E" in n) or "conv_first" in n or "conv_wide" in n or "conv_thin" in n or "up_dense0" in n else "conv1x1" if ("conv_kernel" in n or "conv1x1" in n) else \
                       "cbam" if "cbam" in n else "upsample_add" if "upsample" in n else "tail" if "tail" in n else "layout"
                 if "conv_kernel<" in n:  # demangled template form
                     key = "conv"
