@@ -288,7 +288,7 @@ enum { MDIE_TAP_SKIP0 = 0, MDIE_TAP_SKIP1, MDIE_TAP_SKIP2, MDIE_TAP_DENSE0, MDIE
 
 /* Last decoder stage + first layer of decoder.final_dense in one launch (models/cdan.py:153-155 and DenseBlock layer 0,
  * :35-36,41-46):  base = bilinear_x2(lo)[:, :3] + x ;  g0 = conv3x3(relu(base * pre_scale + pre_shift)) + bias.
- * K = 27 is one 32-deep MFMA step per 16 pixels (csrc/updense0.hip).  `weight` is the layer's [16,3,3,3] weight in
+ * K = 27 is im2col-ed into two MFMA steps per 16 pixels (csrc/updense0.hip).  `weight` is the layer's [16,3,3,3] weight in
  * mdie_pack_conv_first_weight's layout (cout_stored = 16); `base` gets base_channels (16, or one 16-byte group) stored
  * channels per pixel, channels 3.. zero; g0 is written with 16 channels at pixel stride g0_stride. */
 typedef struct {

@@ -788,10 +788,11 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_pool_kernel(const 
   // The first tile is peeled off the loop (`tile` is called once before it): the loop is then entered, like its back edge,
   // with "6 patch loads, then 4 stores" outstanding, and the compiler's wait before the patch write is vmcnt(7) / vmcnt(4)
   // -- the loads -- on both paths instead of the vmcnt(0) a merge with the store-less prologue forces.
-  // (Known remainder, stamps: a CU's four resident workgroups were dispatched one after the other and the SIMDs favour the
-  //  oldest wave, so they finish after 16.5 / 19 / 21 / 24 us and the CU ends on one latency-bound straggler; rotating
-  //  s_setprio with the tile counter, out of phase between them, did not change that.  Evening it out needs a shared tile
-  //  counter per CU-group, i.e. scratch memory in the descriptor: ~4 us of this launch, not done.)
+  // (Stamps: a CU's four resident workgroups were dispatched one after the other and the SIMDs favour the oldest wave, so
+  //  with the same 8 tiles each they finish after 16.5 / 19 / 21 / 24 us.  That is an ORDER, not a tail to cut: rotating
+  //  s_setprio with the tile counter changed nothing, and runs cut 19 : 16 : 15 : 14 by dispatch quarter left the last
+  //  workgroup at 23 us with 7 tiles -- the CU as a whole needs ~24 us for its 32 tiles, 1.67 x the pace of one workgroup
+  //  alone.)
   int buf = 0;
   bool last = false;
   auto tile = [&]() {
