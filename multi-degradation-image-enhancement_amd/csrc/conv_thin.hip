@@ -1,6 +1,6 @@
 // DenseLayers at full resolution (decoder.final_dense layers 1..3, models/cdan.py:35-46,155):
 //     out[16] = act(conv3x3(relu(bn(concat(base, g0, ..)))) * post_scale + post_shift)
-// with at most 8 live 16-byte channel columns (<= 64 stored input channels) and 16 output channels, 16-bit storage.
+// with at most 7 live 16-byte channel columns (<= 56 stored input channels) and 16 output channels, 16-bit storage.
 //
 // Why a kernel of their own.  conv_kernel runs these at 40-50 % of their HBM floor (final.l1/l2/l3: 52 / 72 / 78 us against
 // 21 / 29 / 38 us at B = 32, 256x256; this kernel: 47 / 61 / 73 us -- what is left is at the end of this comment).  Stamps of its sibling for the first layer (tools/stamp_first.py) showed what such
@@ -268,7 +268,7 @@ bool conv_thin_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw
   if (a.e.pool || a.e.residual || a.pool_partial || (a.e.act != MDIE_ACT_NONE && a.e.act != MDIE_ACT_RELU)) return false;
   if (a.H % TH_TILE != 0 || a.W % TH_TILE != 0) return false;
   const int ncol = (a.cin + 7) / 8;
-  if (ncol > TH_MAXCOL || a.nchunk > 2) return false;
+  if (ncol > TH_MAXCOL - 1 || a.nchunk > 2) return false;   // (8 full columns -- dense1 layer 0, 64 input channels -- measured 7-12 % SLOWER than conv_kernel at every batch size)
   for (int s = 0; s < a.nseg; ++s)
     if (a.seg[s].ch_begin % 8 != 0 || a.seg[s].ch_end % 8 != 0 || (size_t)(TH_PW + 1) * a.W * a.seg[s].stride * 2 >= ((size_t)1 << 24) * 16) return false;
   if ((size_t)a.W * 20 >= ((size_t)1 << 24)) return false;                                      // 24-bit multiply of the pixel offset

@@ -691,7 +691,7 @@ def test_wide_conv_lds_dma_kernel(E, L, prec, case):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("cin_segs,act", [([8, 16], "none"), ([8, 16, 16], "none"), ([8, 16, 16, 16], "none"), ([16, 16], "relu"), ([16, 16, 16, 16], "none")])
+@pytest.mark.parametrize("cin_segs,act", [([8, 16], "none"), ([8, 16, 16], "none"), ([8, 16, 16, 16], "none"), ([16, 16], "relu"), ([16, 16, 16, 8], "none")])
 def test_thin_persistent_conv_kernel(E, L, prec, cin_segs, act):
     """conv_thin_kernel (csrc/conv_thin.hip: persistent workgroups, one wave per 16-byte input column, next tile prefetched
     into registers, all K chunks of a tile in LDS at once) -- the kernel behind decoder.final_dense layers 1..3 at BASELINE
