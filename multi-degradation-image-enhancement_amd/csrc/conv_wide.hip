@@ -48,6 +48,7 @@ static_assert(WD_LDS <= 160 * 1024, "two stages must fit the CU's LDS");
 __device__ __attribute__((aligned(64))) unsigned char g_wd_zero[64];   // zero-initialised: source of every padding pixel
 
 struct WideArgs {
+  int half_width;        // items of 32 outputs (two per staged 64-output weight tile)
   ConvArgs c;
   int tiles_x, tiles_y;     // 32x16 tiles per image
   int items;                // item = (pixel tile, output tile), output tile fastest
@@ -70,7 +71,10 @@ __device__ __forceinline__ void dma_piece(const char* src, unsigned lds) {
 #define WSTAMP(slot) do {} while (0)
 #endif
 
-template <typename T, int ACT, bool POOL, bool STATS>
+// NCS = 16-output subtiles an item computes: 4 (the 64 staged outputs) or 2 -- the HALF-WIDTH form for layers whose 64-wide
+// item count leaves CUs idle (dec.conv2 at B = 32: 128 items on 256 CUs): two workgroups stage the same 64-output weight
+// tile and each runs the MFMAs of one half of it, so a stage's matrix work halves while twice the CUs are busy.
+template <typename T, int ACT, bool POOL, bool STATS, int NCS = 4>
 __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs w) {
 #ifdef EXP_STAMPS
   WideArgs w2 = w;
@@ -89,7 +93,9 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = wave >> 2, strip = wave & 3;           // 16x16 half of the tile, 4-row strip of it
   const int lq = lane >> 4, lp = lane & 15;
-  constexpr int NCS = 4, NPS = 4;
+  constexpr int NPS = 4;
+  constexpr int BNI = NCS * 16;                           // outputs of an item
+  static_assert(NCS == 4 || (NCS == 2 && !POOL && !STATS), "the half-width form has the plain epilogue only");
 
   // Which items a workgroup takes.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD: observed
   // placement, used for speed only).  Each XCD slot owns a contiguous run of `per_xcd` items; its workgroups walk the run
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
     const int img = patch / tpi, trem = patch - img * tpi;
     const int ty = trem / w.tiles_x, tx = trem - ty * w.tiles_x;
     const int y0 = ty * WD_TH - 1, x0 = tx * WD_TW - 1;
-    d_n0 = nt * WD_BN;
+    d_n0 = (nt * BNI) / WD_BN * WD_BN;                    // the 64-output weight tile this item's outputs live in
     pvalid = 0;
 #pragma unroll
     for (int j = 0; j < WD_PP; ++j) {
@@ -214,7 +220,8 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
       if (++d_chunk == a.nchunk) { d_chunk = 0; d_item += istep; }
     }
     WSTAMP(2);
-    const int n0 = (item % a.n_tiles) * WD_BN;
+    const int n0 = (item % a.n_tiles) * BNI;
+    const int csb = (n0 % WD_BN) / 16;                     // first of this item's subtiles inside the staged weight tile
     if (chunk == 0) {
 #pragma unroll
       for (int i = 0; i < NCS; ++i)
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
       const int kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
       for (int cs = 0; cs < NCS; ++cs)
-        wf[b][cs] = *reinterpret_cast<const uint4*>(st + (tap * WD_BN + cs * 16) * 16 + woff);
+        wf[b][cs] = *reinterpret_cast<const uint4*>(st + (tap * WD_BN + (csb + cs) * 16) * 16 + woff);
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps)
         xf[b][ps] = *reinterpret_cast<const uint4*>(st + ((kh + TS::dy(ps)) * WD_PITCH + TS::dx(ps)) * 64 + xaddr[kw][kh & 1]);
@@ -370,27 +377,39 @@ static int launch_wide_t(WideArgs& w, hipStream_t stream) {
     if (!opt.ensure(reinterpret_cast<const void*>(&conv_wide_kernel<T, ACT, POOL, STATS>), WD_LDS)) return MDIE_ELAUNCH; \
     hipLaunchKernelGGL((conv_wide_kernel<T, ACT, POOL, STATS>), dim3(grid), dim3(WD_THREADS), WD_LDS, stream, w); \
   } while (0)
-  if (a.pool_partial) MDIE_WIDE(MDIE_ACT_RELU, false, true);
+#define MDIE_WIDE_HALF(ACT)                                                                                      \
+  do {                                                                                                           \
+    static LdsOptIn opt;                                                                                         \
+    if (!opt.ensure(reinterpret_cast<const void*>(&conv_wide_kernel<T, ACT, false, false, 2>), WD_LDS)) return MDIE_ELAUNCH; \
+    hipLaunchKernelGGL((conv_wide_kernel<T, ACT, false, false, 2>), dim3(grid), dim3(WD_THREADS), WD_LDS, stream, w); \
+  } while (0)
+  if (w.half_width) { if (a.e.act == MDIE_ACT_NONE) MDIE_WIDE_HALF(MDIE_ACT_NONE); else MDIE_WIDE_HALF(MDIE_ACT_RELU); }
+  else if (a.pool_partial) MDIE_WIDE(MDIE_ACT_RELU, false, true);
   else if (a.e.pool) MDIE_WIDE(MDIE_ACT_RELU, true, false);
   else if (a.e.act == MDIE_ACT_NONE) MDIE_WIDE(MDIE_ACT_NONE, false, false);
   else MDIE_WIDE(MDIE_ACT_RELU, false, false);
 #undef MDIE_WIDE
+#undef MDIE_WIDE_HALF
   MDIE_LAUNCH_CHECK("mdie_conv_fwd");
   return MDIE_OK;
 }
 
 int launch_conv_wide(int dtype, ConvArgs& a, hipStream_t stream) {
   WideArgs w{};
-  a.n_tiles = a.cout / WD_BN;
-  w.c = a;
-  w.tiles_x = a.W / WD_TW; w.tiles_y = a.H / WD_TH;
-  w.items = a.B * w.tiles_x * w.tiles_y * a.n_tiles;
   static int cus = 0;
   if (!cus) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     cus = n;
   }
+  w.tiles_x = a.W / WD_TW; w.tiles_y = a.H / WD_TH;
+  // half-width items when the 64-wide ones would leave more than a quarter of the CUs without work
+  static const int no_half = getenv("MDIE_WIDE_HALF") ? !atoi(getenv("MDIE_WIDE_HALF")) : 0;   // A/B switch
+  const long items64 = (long)a.B * w.tiles_x * w.tiles_y * (a.cout / WD_BN);
+  w.half_width = !no_half && !a.e.pool && !a.pool_partial && !a.e.residual && items64 * 4 < (long)cus * 3;
+  a.n_tiles = a.cout / (w.half_width ? WD_BN / 2 : WD_BN);
+  w.c = a;
+  w.items = a.B * w.tiles_x * w.tiles_y * a.n_tiles;
   w.per_xcd = cdiv(w.items, 8);
   w.wgs_per_xcd = w.per_xcd < cus / 8 ? w.per_xcd : cus / 8;      // one persistent workgroup per CU at most
   static const int contiguous = getenv("MDIE_WIDE_ORDER") ? !atoi(getenv("MDIE_WIDE_ORDER")) : 0;
