@@ -248,6 +248,31 @@ def test_first_layer_kernel(E, L, golden_dir, precision):
         assert err <= tol_for(precision), f"pool={pool}: {err:.3e}"
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape,cout", [((3, 40, 24), 64), ((2, 64, 48), 64), ((9, 32, 32), 64), ((2, 48, 80), 128), ((40, 64, 64), 64)])
+def test_first_layer_pooled_kernel(E, L, precision, shape, cout):
+    """conv_first_pool_kernel (csrc/conv.hip: encoder.conv1 as the network runs it -- 16-bit, 64 outputs per workgroup, ReLU +
+    2x2 max-pool, MFMA operand roles exchanged, persistent over tile runs) against torch's CPU convolution + max_pool2d, and
+    bit for bit against the generic first-layer kernel: the same call without pooling, pooled afterwards (max of rounded
+    values = rounding of the max).  Ragged tiles (40x24), several 64-channel tiles per pixel tile (cout 128), tile runs that
+    cross image boundaries, and 640 tiles on the persistent grid."""
+    import torch.nn.functional as F
+    dt, td = E.dtype_id(precision), TORCH_DT[precision]
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * 7 + cout)
+    x = torch.rand(B, 3, H, W, generator=g)
+    w = torch.randn(cout, 3, 3, 3, generator=g) * 0.3
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    y = E.conv_first_fwd(x.cuda(), w, sc.cuda(), sh.cuda(), dtype=dt, act=L.ACT_RELU, pool=True)
+    full = E.conv_first_fwd(x.cuda(), w, sc.cuda(), sh.cuda(), dtype=dt, act=L.ACT_RELU, pool=False)
+    torch.cuda.synchronize()
+    pooled = F.max_pool2d(full.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).to(td)
+    assert torch.equal(y, pooled), "pooled first-layer kernel vs generic kernel + max_pool2d"
+    rnd = lambda t: t.to(td).float()
+    ref = F.max_pool2d(torch.relu(F.conv2d(rnd(x), rnd(w), padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 2, 2).permute(0, 2, 3, 1)
+    assert rel_to_max(y, ref) <= {"bf16": 8e-3, "fp16": 1e-3}[precision]
+
+
 def _dense_block(E, L, p, x_nchw, cin, dt):
     c0 = (cin + 15) // 16 * 16
     gap = c0 - cin
