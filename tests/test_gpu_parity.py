@@ -1257,6 +1257,40 @@ def test_routed_inference_matches_per_task_engines(E):
         routed.forward(x, labels[:3])
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_routed_groups_in_flight_match_serial_groups(E, prec):
+    """BASELINE configs[3] at size: 32 images of 256x256, 9 tasks, the task groups running concurrently on their own streams
+    (RoutedEngine), ten times -- every group's output must equal, bit for bit, what a dedicated engine returns for the same
+    group run alone (same batch size, so the same kernels).  The concurrency counterpart of
+    test_engines_in_flight_on_different_inputs for the routed path: different weights AND different inputs side by side."""
+    from oracle import params as P
+    tasks = [f"t{i}" for i in range(9)]
+    routed = E.RoutedEngine("cuda", prec)
+    sds = {t: P.make_state_dict(20 + i) for i, t in enumerate(tasks)}
+    for t in tasks:
+        routed.load_task(t, sds[t])
+    B = 32
+    x, _ = P.lowlight_batch(5, B, 256, 256)
+    x = x.cuda()
+    labels = [tasks[(i * 7) % 9] for i in range(B)]
+    ref = torch.empty_like(x)
+    for t in tasks:
+        idx = [i for i, l in enumerate(labels) if l == t]
+        eng = E.CdanEngine("cuda", prec).load(sds[t])
+        eng.use_side_streams = False                      # RoutedEngine runs each group without side streams
+        ref[idx] = eng.forward(x[idx].contiguous())
+        del eng
+    torch.cuda.synchronize()
+    bad = []
+    for rep in range(10):
+        y = routed.forward(x, labels)
+        torch.cuda.synchronize()
+        if not torch.equal(y, ref):
+            d = (y - ref).abs().amax(dim=(1, 2, 3))
+            bad.append((rep, [(i, labels[i], round(v, 5)) for i, v in enumerate(d.tolist()) if v > 0][:4]))
+    assert not bad, f"{len(bad)} of 10 routed forwards differ from the serial groups: {bad[:2]}"
+
+
 def test_large_image_1024_against_oracle(E):
     """configs[4] (config/pixelation_hard.json 1024x1024 fp16): one 1024x1024 image at its stated dtype, and the fp32 and
     bf16 paths, vs the CPU oracle"""
