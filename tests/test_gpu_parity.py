@@ -1257,6 +1257,57 @@ def test_routed_inference_matches_per_task_engines(E):
         routed.forward(x, labels[:3])
 
 
+def test_training_steps_in_flight_match_serial_steps():
+    """Two networks training side by side on two streams (different weights, different batches, dropout off so that a step is
+    repeatable): loss and all 140 parameter gradients of every overlapped step equal, bit for bit, those of the same step run
+    alone -- the training-mode kernels are deterministic and hold up next to another launch on the same CUs (what RCCL's
+    all-reduce kernels are to a data-parallel backward)."""
+    from models.cdan import CDAN
+    from mdie_amd import host as H, synthetic as P
+    B, S = 4, 256
+    losses = H.build_losses({"enabled": True, "terms": [{"name": "charbonnier", "weight": 1.0}, {"name": "ssim", "weight": 0.5}]})
+    nets, xs, ts = [], [], []
+    for k in range(2):
+        torch.manual_seed(40 + k)
+        n = CDAN(precision="bf16").cuda().train()
+        n.dropout_p = 0.0
+        nets.append(n)
+        x, t = P.lowlight_batch(100 + k, B, S, S)
+        xs.append(x.cuda())
+        ts.append(t.cuda())
+    state = [{kk: v.clone() for kk, v in n.state_dict().items()} for n in nets]     # (BatchNorm running statistics move with every forward)
+
+    def step(k):
+        nets[k].load_state_dict(state[k])
+        nets[k].zero_grad(set_to_none=True)
+        total, _ = losses(nets[k](xs[k]), ts[k])
+        total.backward()
+        return total
+
+    def grads(k):
+        return [p.grad.detach().clone() for p in nets[k].parameters() if p.grad is not None]
+
+    ref = []
+    for k in range(2):
+        l = step(k)
+        torch.cuda.synchronize()
+        ref.append((l.item(), grads(k)))
+    assert len(ref[0][1]) == 140
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    main = torch.cuda.current_stream()
+    for rep in range(6):
+        ls = [None, None]
+        torch.cuda.synchronize()
+        for k in range(2):
+            streams[k].wait_stream(main)
+            with torch.cuda.stream(streams[k]):
+                ls[k] = step(k)
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert ls[k].item() == ref[k][0], (rep, k)
+            assert all(torch.equal(a, b) for a, b in zip(grads(k), ref[k][1])), (rep, k)
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 def test_routed_groups_in_flight_match_serial_groups(E, prec):
     """BASELINE configs[3] at size: 32 images of 256x256, 9 tasks, the task groups running concurrently on their own streams
