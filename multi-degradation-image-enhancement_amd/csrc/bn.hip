@@ -556,6 +556,74 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnBwdArg
   }
 }
 
+// The same pass for the common case -- element-type running gradient, every segment accumulating (ACC) or none -- with two
+// register sets used alternately instead of `cur = nxt`: handed over by assignment, the freshly loaded registers are copied
+// at the bottom of the loop behind an s_waitcnt vmcnt that waits out the loads just issued (one pixel in flight, not two);
+// and with the ACC load unconditional the waits stay counted.  Past the block's last pixel a thread re-reads its first
+// pixel and stores nothing.
+template <typename T, bool ACC>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply2_kernel(const BnBwdArgs a) {
+  constexpr int VEC = Traits<T>::VEC;
+  const int CV = a.C / VEC;
+  const BlkMap m = blk_map(CV);
+  if (!m.active) return;
+  const int v = m.cv, c0 = v * VEC;
+  const char* xb = nullptr; int xs = 0;
+  char* gb = nullptr; int gs = 0;
+#pragma unroll
+  for (int k = 0; k < MDIE_MAX_SEG; ++k)
+    if (k < a.nseg && c0 >= a.x[k].ch_begin && c0 < a.x[k].ch_end) {
+      xb = a.x[k].ptr + (size_t)(c0 - a.x[k].ch_begin) * sizeof(T); xs = a.x[k].stride;
+      gb = a.g[k].ptr + (size_t)(c0 - a.g[k].ch_begin) * sizeof(T); gs = a.g[k].stride;
+    }
+  float sc[VEC], sh[VEC], mu[VEC], is[VEC], k2[VEC], k3[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    sc[i] = a.scale[c0 + i]; sh[i] = a.shift[c0 + i]; mu[i] = a.mean[c0 + i]; is[i] = a.invstd[c0 + i];
+    k2[i] = a.coef[c0 + i]; k3[i] = a.coef[a.C + c0 + i];
+  }
+  const long b = (long)blockIdx.x * a.chunk, e = min(a.N, b + a.chunk);
+  struct It { uint4 x, d, g; };
+  const long p_first = b + m.row;
+  auto fetch = [&](long p, It& t) {
+    const long pp = p < e ? p : p_first;
+    t.x = *reinterpret_cast<const uint4*>(xb + (size_t)pp * xs * sizeof(T));
+    t.d = *reinterpret_cast<const uint4*>(a.da + (size_t)pp * a.da_stride * sizeof(T) + (size_t)v * 16);
+    if constexpr (ACC) t.g = *reinterpret_cast<const uint4*>(gb + (size_t)pp * gs * sizeof(T));
+  };
+  auto combine = [&](long p, const It& t) {
+    float xv[VEC], d[VEC], r[VEC];
+    Vec16<T>::unpack(t.x, xv);
+    Vec16<T>::unpack(t.d, d);
+    if constexpr (ACC) Vec16<T>::unpack(t.g, r);
+    else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) r[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float dd = (!a.relu || fmaf(xv[i], sc[i], sh[i]) > 0.f) ? d[i] : 0.f;
+      r[i] += sc[i] * (dd - k2[i] - (xv[i] - mu[i]) * is[i] * k3[i]);
+    }
+    *reinterpret_cast<uint4*>(gb + (size_t)p * gs * sizeof(T)) = Vec16<T>::pack(r);
+  };
+  if (p_first >= e) return;
+  It A, B;
+  fetch(p_first, A);
+  long p = p_first;
+  for (; p + m.rows < e; p += 2 * m.rows) {       // whole pairs: no branch around a load or a store (counted waits)
+    fetch(p + m.rows, B);
+    __builtin_amdgcn_sched_barrier(0);
+    combine(p, A);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(p + 2 * m.rows, A);                      // (past the end: the first pixel again, unused)
+    __builtin_amdgcn_sched_barrier(0);
+    combine(p + m.rows, B);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (p < e) combine(p, A);                        // odd tail
+}
+
 template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void sigmoid_bwd_nchw3_kernel(int B, int HW, const float* g, const float* y, T* dz, int dz_stride) {
   const size_t total = (size_t)B * HW;
@@ -786,7 +854,16 @@ extern "C" int mdie_bn_bwd_apply(const mdie_bn_bwd_desc* d, void* stream) {
   if (blocks > 4096) blocks = 4096;
   a.chunk = (a.N + blocks - 1) / blocks;
   blocks = (a.N + a.chunk - 1) / a.chunk;
-  MDIE_SWITCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3((int)blocks), dim3(BN_THREADS), 0, s, a));
+  bool any32 = false;
+  for (int k = 0; k < d->nseg; ++k) any32 = any32 || d->acc32[k].ptr != nullptr;
+  const unsigned all = (1u << d->nseg) - 1u;
+  static const bool old_form = getenv("MDIE_BN_APPLY2") && atoi(getenv("MDIE_BN_APPLY2")) == 0;   // A/B switch
+  if (!any32 && !old_form && ((d->accumulate & all) == all || (d->accumulate & all) == 0)) {
+    if ((d->accumulate & all) == all) MDIE_SWITCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_apply2_kernel<T, true>), dim3((int)blocks), dim3(BN_THREADS), 0, s, a));
+    else MDIE_SWITCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_apply2_kernel<T, false>), dim3((int)blocks), dim3(BN_THREADS), 0, s, a));
+  } else {
+    MDIE_SWITCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3((int)blocks), dim3(BN_THREADS), 0, s, a));
+  }
   MDIE_LAUNCH_CHECK("mdie_bn_bwd_apply");
   return MDIE_OK;
 }

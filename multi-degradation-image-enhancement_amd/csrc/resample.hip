@@ -79,11 +79,15 @@ __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_pool_kernel(int H, 
   for (int i = 0; i < VEC; ++i) { s[i] = 0.f; m[i] = -INFINITY; }
   const char* base = lo + (size_t)img * H * W * lo_stride * sizeof(T) + (size_t)v * 16;
   if (r < rows) {
-    // Latency-bound loop (5 loads per pixel, then their use): the 5 loads of the NEXT pixel are requested before the current
-    // one is blended and stored, so two pixels' loads are always in flight per thread.  (lo / skip / out never overlap.)
+    // Latency-bound loop (5 loads per pixel, then their use).  Two pixels are in flight per thread, in two register sets used
+    // alternately (the loop is unrolled by two): a single set handed over with `cur = nxt` makes the compiler copy the
+    // freshly loaded registers at the bottom of the loop -- behind an s_waitcnt vmcnt that waits out the loads it has
+    // just issued, i.e. one pixel in flight after all (ISA of the round-1 form; the same in bn_bwd_apply_kernel).  Every load
+    // and store is unconditional: past the slab's end a thread re-reads and re-writes the slab's first pixel (the same value)
+    // and leaves it out of the sums.  (lo / skip / out never overlap.)
     struct Px { uint4 a00, a01, a10, a11, sk; float hy0, hy1, wx0, wx1; };
     auto fetch = [&](int p, Px& q) {
-      const int pp = p < p_end ? p : p_begin;            // past the slab: a harmless in-range address, result unused
+      const int pp = p < p_end ? p : p_begin;
       const int oy = pp / Wo, ox = pp - oy * Wo;
       int y0, y1, x0, x1;
       src_index(oy, H, y0, y1, q.hy0, q.hy1);
@@ -92,28 +96,40 @@ __global__ __launch_bounds__(RS_THREADS) void upsample2x_add_pool_kernel(int H, 
       q.a00 = at(y0, x0); q.a01 = at(y0, x1); q.a10 = at(y1, x0); q.a11 = at(y1, x1);
       q.sk = *reinterpret_cast<const uint4*>(skip + ((size_t)img * npix + pp) * skip_stride * sizeof(T) + (size_t)v * 16);
     };
-    Px cur, nxt;
-    if (p_begin + r < p_end) fetch(p_begin + r, cur);
-    for (int p = p_begin + r; p < p_end; p += rows) {
-      fetch(p + rows, nxt);
+    auto blend = [&](int p, const Px& c) {
+      const bool live = p < p_end;
+      const int pp = live ? p : p_begin;
       float a00[VEC], a01[VEC], a10[VEC], a11[VEC], sk[VEC], rr[VEC];
-      Vec16<T>::unpack(cur.a00, a00);
-      Vec16<T>::unpack(cur.a01, a01);
-      Vec16<T>::unpack(cur.a10, a10);
-      Vec16<T>::unpack(cur.a11, a11);
-      Vec16<T>::unpack(cur.sk, sk);
-      const size_t op = (size_t)img * npix + p;
+      Vec16<T>::unpack(c.a00, a00);
+      Vec16<T>::unpack(c.a01, a01);
+      Vec16<T>::unpack(c.a10, a10);
+      Vec16<T>::unpack(c.a11, a11);
+      Vec16<T>::unpack(c.sk, sk);
 #pragma unroll
       for (int i = 0; i < VEC; ++i)
-        rr[i] = cur.hy0 * (cur.wx0 * a00[i] + cur.wx1 * a01[i]) + cur.hy1 * (cur.wx0 * a10[i] + cur.wx1 * a11[i]) + sk[i];
+        rr[i] = c.hy0 * (c.wx0 * a00[i] + c.wx1 * a01[i]) + c.hy1 * (c.wx0 * a10[i] + c.wx1 * a11[i]) + sk[i];
       const uint4 packed = Vec16<T>::pack(rr);
-      *reinterpret_cast<uint4*>(out + op * out_stride * sizeof(T) + (size_t)v * 16) = packed;
+      *reinterpret_cast<uint4*>(out + ((size_t)img * npix + pp) * out_stride * sizeof(T) + (size_t)v * 16) = packed;
       // reduce the STORED values (bf16-rounded), exactly what a separate pool pass over `out` would read
       float q[VEC];
       Vec16<T>::unpack(packed, q);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) { s[i] += q[i]; m[i] = fmaxf(m[i], q[i]); }
-      cur = nxt;
+      for (int i = 0; i < VEC; ++i) { s[i] += live ? q[i] : 0.f; m[i] = live ? fmaxf(m[i], q[i]) : m[i]; }
+    };
+    Px A, B;
+    const int p0 = p_begin + r;
+    if (p0 < p_end) {
+      fetch(p0, A);
+      for (int p = p0; p < p_end; p += 2 * rows) {
+        fetch(p + rows, B);
+        __builtin_amdgcn_sched_barrier(0);      // (pinned: left alone the scheduler sinks these loads below the blend they are meant to fly under)
+        blend(p, A);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(p + 2 * rows, A);
+        __builtin_amdgcn_sched_barrier(0);
+        blend(p + rows, B);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { rsum[r * C + v * VEC + i] = s[i]; rmax[r * C + v * VEC + i] = m[i]; }
