@@ -13,6 +13,8 @@
 // the patch is recomputed by the neighbouring tiles (324 / 256 pixels): cheaper than a round trip through HBM.
 // Arithmetic is kept identical to the unfused pair: the base is rounded to the storage type before the pre-activation,
 // the pre-activation is one fused multiply-add rounded once, zero padding applies to the ACTIVATED tensor.
+#include <algorithm>
+
 #include "common.hpp"
 
 #pragma clang fp contract(off)   // (the interpolation must round like upsample2x_add_nchw3's, resample.hip)
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
   constexpr int PW = UD_PW;
   __shared__ __attribute__((aligned(16))) T patch[PW * PW * 4];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lp = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, lq = lane >> 4, lp = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = blockIdx.x;
   const int tiles_x = (a.W + UD_TILE - 1) / UD_TILE, tiles_y = (a.H + UD_TILE - 1) / UD_TILE;
   const int tx = bid % tiles_x; bid /= tiles_x;
@@ -104,9 +107,11 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
       int ya, yb, xa, xb;
       ud_src(gy, Hl, ya, yb, hy[it][0], hy[it][1]);
       ud_src(gx, Wl, xa, xb, wx[it][0], wx[it][1]);
+      // addresses = wave-uniform image base + 32-bit lane offset from 24-bit multiplies (stamps of the first-layer kernel: a
+      // 32-bit integer multiply or a 64-bit mad is 16 cycles of the SIMD, v_mul_u32_u24 is 4; the host checks the ranges)
       const char* lb = a.lo + (size_t)img * Hl * Wl * a.lo_stride * E;
-      const char* q[4] = {lb + ((size_t)ya * Wl + xa) * a.lo_stride * E, lb + ((size_t)ya * Wl + xb) * a.lo_stride * E,
-                          lb + ((size_t)yb * Wl + xa) * a.lo_stride * E, lb + ((size_t)yb * Wl + xb) * a.lo_stride * E};
+      const unsigned ls = (unsigned)a.lo_stride * E, ra = __umul24(ya, Wl), rb = __umul24(yb, Wl);
+      const char* q[4] = {lb + __umul24(ra + xa, ls), lb + __umul24(ra + xb, ls), lb + __umul24(rb + xa, ls), lb + __umul24(rb + xb, ls)};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if constexpr (E == 2) {
@@ -117,8 +122,11 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
           t[it][k][0] = u.x; t[it][k][1] = u.y; t[it][k][2] = u.z;
         }
       }
-      const float* xp = a.x + (size_t)img * 3 * plane + (size_t)gy * a.W + gx;
-      xin[it][0] = xp[0]; xin[it][1] = xp[plane]; xin[it][2] = xp[2 * plane];
+      const float* xbase = a.x + (size_t)img * 3 * plane;                    // wave-uniform
+      const unsigned xo = (__umul24(gy, a.W) + gx) * 4u;
+      xin[it][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xbase) + xo);
+      xin[it][1] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xbase + plane) + xo);
+      xin[it][2] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xbase + 2 * plane) + xo);
     }
   }
 #pragma unroll
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
         float o[BASE_CH];
 #pragma unroll
         for (int c = 0; c < BASE_CH; ++c) o[c] = c < 3 ? f[c] : 0.f;
-        uint4* dst = reinterpret_cast<uint4*>(a.base + (((size_t)img * a.H + (y0 + py - 1)) * a.W + (x0 + px - 1)) * BASE_CH * E);
+        uint4* dst = reinterpret_cast<uint4*>(a.base + (size_t)img * plane * (BASE_CH * E) + (__umul24(y0 + py - 1, a.W) + (x0 + px - 1)) * (unsigned)(BASE_CH * E));
 #pragma unroll
         for (int v = 0; v < BASE_CH / VEC; ++v) dst[v] = Vec16<T>::pack(o + v * VEC);
       }
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
     const int gy = y0 + y, gx = x0 + x;
     if (gy < a.H && gx < a.W) {     // lane: output channels 4 lq .. 4 lq + 3 of this pixel
       const float v0 = acc[0] + bias.x, v1 = acc[1] + bias.y, v2 = acc[2] + bias.z, v3 = acc[3] + bias.w;
-      char* dst = a.g0 + (((size_t)img * a.H + gy) * a.W + gx) * a.g0_stride * E + lq * 4 * E;
+      char* dst = a.g0 + (size_t)img * plane * ((size_t)a.g0_stride * E) + __umul24(__umul24(gy, a.W) + gx, (unsigned)a.g0_stride * E) + lq * 4 * E;
       if constexpr (E == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(Half<T>::pack(v0, v1), Half<T>::pack(v2, v3));
       else *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
     }
@@ -211,6 +219,9 @@ extern "C" int mdie_up_add_dense0_fwd(const mdie_up_dense0_desc* d, void* stream
   MDIE_REQUIRE(d->base_channels == 16 || d->base_channels == vec, "mdie_up_add_dense0_fwd: base_channels %d (16 or %d)", d->base_channels, vec);
   MDIE_REQUIRE(d->g0_stride >= 16 && d->g0_stride % 4 == 0 && (((uintptr_t)d->g0 | (uintptr_t)d->base | (uintptr_t)d->weight) & 15) == 0,
                "mdie_up_add_dense0_fwd: g0_stride %d / alignment", d->g0_stride);
+  MDIE_REQUIRE((size_t)d->H * d->W < ((size_t)1 << 24) && (size_t)d->H * d->W * (size_t)std::max(d->g0_stride, 16) * dtype_size(d->dtype) < ((size_t)1 << 32) &&
+               (size_t)(d->H / 2) * (d->W / 2) * d->lo_stride * dtype_size(d->dtype) < ((size_t)1 << 32) && d->lo_stride * 4 < (1 << 24) && d->g0_stride * 4 < (1 << 24),
+               "mdie_up_add_dense0_fwd: image too large for the kernel's 24-bit pixel / 32-bit byte offsets (%dx%d)", d->H, d->W);
   UpDense0Args a{};
   a.B = d->B; a.H = d->H; a.W = d->W;
   a.lo = reinterpret_cast<const char*>(d->lo); a.lo_stride = d->lo_stride;
