@@ -8,6 +8,8 @@
 // finish), and the global pools are deterministic two-level reductions (no float atomics).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.hpp"
 
 // No implicit FMA contraction in this file: its loops are unrolled, and the unrolled body and the remainder loop must
@@ -340,22 +342,28 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_spatial_kernel(const CbamArgs
   // outside the image, and the first batch is requested before the gate / 7x7 phases so that it arrives under them.
   // (out may coincide with x -- every unit is read before it is written by the same thread -- but not overlap it otherwise.)
   constexpr int U = 4;
-  const int CV = a.C / VEC;
+  const int CV = a.C / VEC;                      // a power of two
+  const int cv_shift = __builtin_ctz(CV);
   const int total = TS * TS * CV;
-  const char* __restrict__ xsrc = a.x;
-  const char* __restrict__ msrc = a.mul;
-  char* __restrict__ odst = a.out;
-  const size_t gp_origin = ((size_t)img * a.H + y0) * a.W + x0;
+  // Addresses: wave-uniform image base + a 32-bit lane offset from 24-bit multiplies (a 32-bit integer multiply or a 64-bit
+  // mad is 16 cycles of the SIMD, v_mul_u32_u24 4: this kernel spent 141 of them per thread on index arithmetic); the host
+  // checks that a picture's pixels fit 24 bits and its bytes 32.
+  const size_t img_pix = (size_t)img * a.H * a.W;
+  const unsigned xs = (unsigned)a.x_stride * sizeof(T), ms = (unsigned)a.mul_stride * sizeof(T), os = (unsigned)a.out_stride * sizeof(T);
+  const char* __restrict__ xsrc = a.x + img_pix * xs;
+  const char* __restrict__ msrc = a.mul ? a.mul + img_pix * ms : nullptr;
+  char* __restrict__ odst = a.out + img_pix * os;
+  const unsigned p_origin = __umul24(y0, a.W) + x0;
   auto load_batch = [&](int u0, uint4 (&xv)[U], uint4 (&mv)[U]) {
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const int u = u0 + j * CB_THREADS;
       const int uu = u < total ? u : tid;
-      const int pix = uu / CV, v = uu - pix * CV;
+      const int pix = uu >> cv_shift, v = uu & (CV - 1);
       const int gy = y0 + pix / TS, gx = x0 + pix % TS;
-      const size_t gp = (gy < a.H && gx < a.W) ? ((size_t)img * a.H + gy) * a.W + gx : gp_origin;
-      xv[j] = *reinterpret_cast<const uint4*>(xsrc + gp * a.x_stride * sizeof(T) + (size_t)v * 16);
-      if (msrc) mv[j] = *reinterpret_cast<const uint4*>(msrc + gp * a.mul_stride * sizeof(T) + (size_t)v * 16);
+      const unsigned gp = (gy < a.H && gx < a.W) ? __umul24(gy, a.W) + gx : p_origin;
+      xv[j] = *reinterpret_cast<const uint4*>(xsrc + __umul24(gp, xs) + (unsigned)v * 16u);
+      if (msrc) mv[j] = *reinterpret_cast<const uint4*>(msrc + __umul24(gp, ms) + (unsigned)v * 16u);
     }
   };
   uint4 xv[U], mv[U];
@@ -399,10 +407,10 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_spatial_kernel(const CbamArgs
     for (int j = 0; j < U; ++j) {
       const int u = u0 + j * CB_THREADS;
       if (u < total) {
-        const int pix = u / CV, v = u - pix * CV;
+        const int pix = u >> cv_shift, v = u & (CV - 1);
         const int gy = y0 + pix / TS, gx = x0 + pix % TS;
         if (gy < a.H && gx < a.W) {
-          const size_t gp = ((size_t)img * a.H + gy) * a.W + gx;
+          const unsigned gp = __umul24(gy, a.W) + gx;
           float f[VEC];
           Vec16<T>::unpack(xv[j], f);
           const float sv = sg[pix];
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_spatial_kernel(const CbamArgs
 #pragma unroll
             for (int i = 0; i < VEC; ++i) f[i] *= m[i];
           }
-          *reinterpret_cast<uint4*>(odst + gp * a.out_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(f);
+          *reinterpret_cast<uint4*>(odst + __umul24(gp, os) + (unsigned)v * 16u) = Vec16<T>::pack(f);
         }
       }
     }
@@ -513,6 +521,10 @@ static int check_cbam(const mdie_cbam_desc* d) {
   MDIE_REQUIRE(d->x_stride % 16 == 0 && d->out_stride % 16 == 0 && (!d->mul || d->mul_stride % 16 == 0), "mdie_cbam_fwd: strides must be multiples of 16");
   MDIE_REQUIRE(((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->out & 15) == 0 && ((uintptr_t)d->mul & 15) == 0, "mdie_cbam_fwd: alignment");
   MDIE_REQUIRE(!d->pool_partial || (d->pool_slabs >= 1 && d->pool_slabs <= MDIE_POOL_SLABS_MAX), "mdie_cbam_fwd: pool_slabs %d", d->pool_slabs);
+  {   // the spatial pass indexes a picture with 24-bit pixel and 32-bit byte offsets
+    const size_t npx = (size_t)d->H * d->W, smax = (size_t)std::max(std::max(d->x_stride, d->out_stride), d->mul ? d->mul_stride : 0) * 4;
+    MDIE_REQUIRE(npx < ((size_t)1 << 24) && smax < ((size_t)1 << 24) && npx * smax < ((size_t)1 << 32), "mdie_cbam_fwd: picture too large (%dx%d)", d->H, d->W);
+  }
   if (d->workspace_bytes < mdie_cbam_workspace_bytes(d->B, d->H, d->W, d->C)) {
     set_error("mdie_cbam_fwd: workspace %zu < %zu", d->workspace_bytes, mdie_cbam_workspace_bytes(d->B, d->H, d->W, d->C));
     return MDIE_ENOSPC;
