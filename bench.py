@@ -99,14 +99,20 @@ def cpu_baseline(sd, x_cpu, seconds_budget=16.0):
 
 
 def source_sha16():
-    """hash of the kernel sources + C header: ties a committed rocprofv3 traffic file to the build it was measured on"""
+    """hash of the kernel sources + C header, comments and white space removed: ties a committed rocprofv3 traffic file to
+    the CODE it was measured on (a reworded comment does not make a measurement stale)"""
     import glob
     import hashlib
+    import re
     h = hashlib.sha256()
     pk = os.path.join(ROOT, "multi-degradation-image-enhancement_amd", "csrc")
     for f in sorted(glob.glob(os.path.join(pk, "*.hip")) + glob.glob(os.path.join(pk, "*.hpp")) + [os.path.join(ROOT, "include", "mdie.h")]):
-        with open(f, "rb") as fh:
-            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+        with open(f, encoding="utf-8", errors="replace") as fh:
+            t = fh.read()
+        t = re.sub(r"/\*.*?\*/", "", t, flags=re.S)
+        t = re.sub(r"//[^\n]*", "", t)
+        t = re.sub(r"\s+", " ", t)
+        h.update(os.path.basename(f).encode() + b"\0" + t.encode())
     return h.hexdigest()[:16]
 
 

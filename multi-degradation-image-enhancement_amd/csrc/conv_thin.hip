@@ -16,7 +16,8 @@
 //   * a wave's four pixel subtiles are four ROWS of 16 consecutive pixels, so the operand fragment of input row r and
 //     column shift kw serves three output rows (kh = 0, 1, 2): 18 LDS reads for a chunk's 36 MFMAs instead of 36, and the
 //     weight fragments live in registers for the whole run.  With 16 outputs every pixel fragment feeds exactly one MFMA:
-//     conv_kernel's 5 ds_read_b128 per 4 MFMAs are 2880 LDS cycles of a tile (128 B/clk), 2.5 x its matrix-pipe time;
+//     conv_kernel's 5 ds_read_b128 per 4 MFMAs are 360 LDS read instructions per tile = 1440 LDS cycles at the 256 B/clk
+//     peak, more than the 1152 cycles the tile's MFMAs need (here: 144 reads);
 //   * the NEXT tile's columns are loaded into registers right after the barrier and fly under this tile's MFMAs and stores;
 //     every load and store is unconditional (border lanes read the tile's own first pixel and are zeroed at the LDS write;
 //     a dead column slot reads one line), the first tile is peeled off the loop, and so the wait before the LDS write is
