@@ -249,7 +249,7 @@ def test_first_layer_kernel(E, L, golden_dir, precision):
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
-@pytest.mark.parametrize("shape,cout", [((3, 40, 24), 64), ((2, 64, 48), 64), ((9, 32, 32), 64), ((2, 48, 80), 128), ((40, 64, 64), 64)])
+@pytest.mark.parametrize("shape,cout", [((3, 40, 24), 64), ((2, 64, 48), 64), ((9, 32, 32), 64), ((2, 48, 80), 128), ((3, 40, 24), 128), ((40, 64, 64), 64)])
 def test_first_layer_pooled_kernel(E, L, precision, shape, cout):
     """conv_first_pool_kernel (csrc/conv.hip: encoder.conv1 as the network runs it -- 16-bit, 64 outputs per workgroup, ReLU +
     2x2 max-pool, MFMA operand roles exchanged, persistent over tile runs) against torch's CPU convolution + max_pool2d, and
