@@ -74,13 +74,13 @@ def cpu_baseline(sd, x_cpu, seconds_budget=16.0):
     # a one-GPU box owns a 16-core share of its host; more threads than that only oversubscribe
     cores = int(os.environ.get("MDIE_CPU_THREADS", min(avail, 16)))
 
-    def timed(x, threads, budget, max_reps):
+    def timed(x, threads, budget, max_reps, min_reps=1):
         torch.set_num_threads(threads)
         with torch.no_grad():
             t0 = time.perf_counter()
             ref = O.cdan_forward(sd, x)          # warm-up (also the parity reference)
             warm = time.perf_counter() - t0
-            reps = max(1, min(max_reps, int(budget / max(warm, 1e-3)) - 1))
+            reps = max(min_reps, min(max_reps, int(budget / max(warm, 1e-3)) - 1))
             times = []
             for _ in range(reps):
                 t0 = time.perf_counter()
@@ -88,7 +88,7 @@ def cpu_baseline(sd, x_cpu, seconds_budget=16.0):
                 times.append(time.perf_counter() - t0)
         return ref, sorted(times)[len(times) // 2], reps
 
-    ref, med, reps = timed(x_cpu, cores, seconds_budget, 3)
+    ref, med, reps = timed(x_cpu, cores, seconds_budget, 3, min_reps=3)     # >= 3 timed forwards, whatever the host's pace
     _, med1, reps1 = timed(x_cpu[:2], 1, 6.0, 2)
     torch.set_num_threads(cores)
     return ref, {"value": round(x_cpu.shape[0] / med, 3), "unit": "images/sec", "cores": cores, "kind": "port",

@@ -857,8 +857,7 @@ extern "C" int mdie_bn_bwd_apply(const mdie_bn_bwd_desc* d, void* stream) {
   bool any32 = false;
   for (int k = 0; k < d->nseg; ++k) any32 = any32 || d->acc32[k].ptr != nullptr;
   const unsigned all = (1u << d->nseg) - 1u;
-  static const bool old_form = getenv("MDIE_BN_APPLY2") && atoi(getenv("MDIE_BN_APPLY2")) == 0;   // A/B switch
-  if (!any32 && !old_form && ((d->accumulate & all) == all || (d->accumulate & all) == 0)) {
+  if (!any32 && ((d->accumulate & all) == all || (d->accumulate & all) == 0)) {
     if ((d->accumulate & all) == all) MDIE_SWITCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_apply2_kernel<T, true>), dim3((int)blocks), dim3(BN_THREADS), 0, s, a));
     else MDIE_SWITCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_apply2_kernel<T, false>), dim3((int)blocks), dim3(BN_THREADS), 0, s, a));
   } else {

@@ -488,8 +488,7 @@ static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
     // weights are 32-128 KB (L2 reads per block)
     // (32 per image, not 64: a block's prelude -- fold of the pooled partials + the gate MLP, ~4 us -- is then paid for twice
     //  the pixels; cbam2 18.8 -> 14.9 us, cbam3 21.9 -> 19.2 at B = 32; 16 no better, 128 worse)
-    static const int cap_env = getenv("MDIE_CHANPOOL_CAP") ? atoi(getenv("MDIE_CHANPOOL_CAP")) : 0;   // (experiments)
-    int cap = cap_env ? cap_env : (d->C >= 256 && !split_gate) ? 16 : 32;
+    int cap = (d->C >= 256 && !split_gate) ? 16 : 32;
     if (cap < 1024 / d->B) cap = 1024 / d->B;   // small batches: more blocks per image
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;

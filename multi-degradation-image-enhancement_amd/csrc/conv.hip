@@ -941,12 +941,10 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   // (4x the workgroups) when the 16x16 grid would have fewer than 2 workgroups per CU.  (Measured, B=32 256x256: a
   // threshold of 1024 for the 16-output layers put the 64x64 dense2 layers on 8x8 tiles and cost 1.5 % of the step.)
   const long wgs16 = (long)cdiv(d->H, 16) * cdiv(d->W, 16) * d->B * a.n_tiles;
-  static const int force8 = getenv("MDIE_CONV_TILE8") ? atoi(getenv("MDIE_CONV_TILE8")) : 0;  // experiments: 1 = thin, 2 = all
-  const bool small = wgs16 < SMALL_GRID_WGS || (force8 == 1 && bn == 16) || force8 == 2;
-  static const int no_stream = getenv("MDIE_CONV1_STREAM") ? !atoi(getenv("MDIE_CONV1_STREAM")) : 0;   // experiments: 0 = staged kernel
+  const bool small = wgs16 < SMALL_GRID_WGS;
   // (64-wide output tiles only: with 16 outputs there are 4 MFMAs per 4 loads and the staged kernel is faster -- measured
   //  final.tr 85 us staged vs 92 us streaming, dense1.tr 58 us staged vs 47 us streaming, B=32 256x256 bf16)
-  if (d->ksize == 1 && !d->pool && !no_stream && bn == 64 &&
+  if (d->ksize == 1 && !d->pool && bn == 64 &&
       (size_t)a.nchunk * 4 * bn * 16 + (size_t)2 * a.nchunk * KC * sizeof(float) <= 96 * 1024)
     return launch_conv1x1_stream<T, 4>(a, stream);
   if (d->pool_partial) {   // 3x3, 64-wide, ReLU, no max-pool: checked by the caller below
@@ -1078,12 +1076,11 @@ static int dispatch_first(const mdie_conv_first_desc* d, hipStream_t stream) {
   a.n_tiles = d->cout / bn;
   const int grid = a.n_tiles * a.tiles_x * a.tiles_y * a.B;
   TimedLaunch tl(MDIE_K_CONV3);
-  static const bool no_pool_kernel = getenv("MDIE_FIRST_POOL_KERNEL") && atoi(getenv("MDIE_FIRST_POOL_KERNEL")) == 0;   // A/B switch
   if constexpr (sizeof(T) == 2) {
-    if (bn == 64 && d->pool && d->act == MDIE_ACT_RELU && !no_pool_kernel && (size_t)18 * d->W * 4 < (1ull << 32)) {
-      static const int per_cu = getenv("MDIE_FIRST_WGS_PER_CU") ? atoi(getenv("MDIE_FIRST_WGS_PER_CU")) : 4;   // (experiments)
+    if (bn == 64 && d->pool && d->act == MDIE_ACT_RELU && (size_t)18 * d->W * 4 < (1ull << 32)) {
+      constexpr int per_cu = 4;
       const int tiles = a.tiles_x * a.tiles_y * a.B;
-      const int wgs = 8 * cdiv(per_cu > 0 ? std::min(tiles, std::max(256 * per_cu / a.n_tiles, 8)) : tiles, 8);   // persistent: resident workgroups walk the tiles
+      const int wgs = 8 * cdiv(std::min(tiles, std::max(256 * per_cu / a.n_tiles, 8)), 8);   // persistent: resident workgroups walk the tiles
       if (d->H % 16 == 0 && d->W % 16 == 0) hipLaunchKernelGGL((conv_first_pool_kernel<T, true>), dim3(wgs, a.n_tiles), dim3(CONV_THREADS), 0, stream, a, tiles);
       else hipLaunchKernelGGL((conv_first_pool_kernel<T, false>), dim3(wgs, a.n_tiles), dim3(CONV_THREADS), 0, stream, a, tiles);
       MDIE_LAUNCH_CHECK("mdie_conv_first_fwd");

@@ -264,8 +264,7 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
 
 // ---- host -----------------------------------------------------------------------------------------------------------
 bool conv_thin_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw3) {
-  static const int off = getenv("MDIE_CONV_THIN") ? !atoi(getenv("MDIE_CONV_THIN")) : 0;   // experiments: MDIE_CONV_THIN=0 -> conv_kernel
-  if (off || dtype == MDIE_F32 || ksize != 3 || has_nchw3 || !a.pre_scale || a.cout != 16) return false;
+  if (dtype == MDIE_F32 || ksize != 3 || has_nchw3 || !a.pre_scale || a.cout != 16) return false;
   if (a.e.pool || a.e.residual || a.pool_partial || (a.e.act != MDIE_ACT_NONE && a.e.act != MDIE_ACT_RELU)) return false;
   if (a.H % TH_TILE != 0 || a.W % TH_TILE != 0) return false;
   const int ncol = (a.cin + 7) / 8;
@@ -281,8 +280,7 @@ template <typename T, int NCHUNK>
 static int launch_thin_t(const ThinArgs& t, int act, int items, hipStream_t stream) {
   const size_t lds = (size_t)t.ncol * TH_PLANE + (size_t)2 * t.ncol * 8 * sizeof(float);
   const int per_cu = 2;                                                       // (registers: weights live in them)
-  static const int force = getenv("MDIE_THIN_WGS_PER_CU") ? atoi(getenv("MDIE_THIN_WGS_PER_CU")) : 0;   // (experiments)
-  const int wgs = 8 * cdiv(std::min(items, 256 * (force > 0 ? force : per_cu)), 8);
+  const int wgs = 8 * cdiv(std::min(items, 256 * per_cu), 8);
   TimedLaunch tl(MDIE_K_CONV3);
 #define MDIE_THIN(ACT)                                                                                            \
   do {                                                                                                            \

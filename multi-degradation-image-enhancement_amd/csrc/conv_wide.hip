@@ -53,7 +53,6 @@ struct WideArgs {
   int tiles_x, tiles_y;     // 32x16 tiles per image
   int items;                // item = (pixel tile, output tile), output tile fastest
   int per_xcd, wgs_per_xcd; // item order, below
-  int contiguous;           // experiments (MDIE_WIDE_ORDER=0): every workgroup takes a contiguous run of items instead
 };
 
 // one 1 KiB LDS-DMA piece: lane i's 16 bytes at `src` -> LDS byte address lds + 16 i.  Hidden from the compiler on purpose
@@ -102,20 +101,12 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
   // INTERLEAVED (workgroup j takes items j, j + wgs_per_xcd, ...), so at any moment the workgroups of one XCD work on
   // neighbouring items -- the output tiles of the same few pixel tiles -- and a patch chunk is pulled into that XCD's L2
   // once for all of them instead of once per output tile (FETCH_SIZE of the step: -11 %, profiles/r02*_traffic*).
-  int first, istep, nitems;
-  if (!w.contiguous) {
-    const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3;
-    const int run_lo = xcd * w.per_xcd;
-    const int run_n = min(w.per_xcd, w.items - run_lo);
-    if (wj >= run_n) return;
-    first = run_lo + wj; istep = w.wgs_per_xcd;
-    nitems = (run_n - wj + istep - 1) / istep;
-  } else {
-    const int per = (w.items + gridDim.x - 1) / gridDim.x;
-    first = blockIdx.x * per; istep = 1;
-    nitems = min(per, w.items - first);
-    if (nitems <= 0) return;
-  }
+  const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3;
+  const int run_lo = xcd * w.per_xcd;
+  const int run_n = min(w.per_xcd, w.items - run_lo);
+  if (wj >= run_n) return;
+  const int first = run_lo + wj, istep = w.wgs_per_xcd;
+  const int nitems = (run_n - wj + istep - 1) / istep;
   const int nstages = nitems * a.nchunk;
   const int tpi = w.tiles_x * w.tiles_y;
   const int sbytes = a.seg[0].stride * (int)sizeof(T);    // pixel stride of the input in bytes
@@ -354,8 +345,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
 }
 
 bool conv_wide_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw3) {
-  static const int off = getenv("MDIE_CONV_WIDE") ? !atoi(getenv("MDIE_CONV_WIDE")) : 0;   // experiments: MDIE_CONV_WIDE=0 -> conv_kernel
-  if (off || dtype == MDIE_F32 || ksize != 3 || has_nchw3 || a.pre_scale || a.nseg != 1) return false;
+  if (dtype == MDIE_F32 || ksize != 3 || has_nchw3 || a.pre_scale || a.nseg != 1) return false;
   if (a.cin % 32 != 0 || a.cin < 64 || a.cout % WD_BN != 0 || a.cout > WD_MAX_COUT) return false;
   if (a.W % WD_TW != 0 || a.H % WD_TH != 0) return false;
   if (a.e.pool && a.e.residual) return false;                                                       // (the pooled epilogue has no residual input)
@@ -404,16 +394,13 @@ int launch_conv_wide(int dtype, ConvArgs& a, hipStream_t stream) {
   }
   w.tiles_x = a.W / WD_TW; w.tiles_y = a.H / WD_TH;
   // half-width items when the 64-wide ones would leave more than a quarter of the CUs without work
-  static const int no_half = getenv("MDIE_WIDE_HALF") ? !atoi(getenv("MDIE_WIDE_HALF")) : 0;   // A/B switch
   const long items64 = (long)a.B * w.tiles_x * w.tiles_y * (a.cout / WD_BN);
-  w.half_width = !no_half && !a.e.pool && !a.pool_partial && !a.e.residual && items64 * 4 < (long)cus * 3;
+  w.half_width = !a.e.pool && !a.pool_partial && !a.e.residual && items64 * 4 < (long)cus * 3;
   a.n_tiles = a.cout / (w.half_width ? WD_BN / 2 : WD_BN);
   w.c = a;
   w.items = a.B * w.tiles_x * w.tiles_y * a.n_tiles;
   w.per_xcd = cdiv(w.items, 8);
   w.wgs_per_xcd = w.per_xcd < cus / 8 ? w.per_xcd : cus / 8;      // one persistent workgroup per CU at most
-  static const int contiguous = getenv("MDIE_WIDE_ORDER") ? !atoi(getenv("MDIE_WIDE_ORDER")) : 0;
-  w.contiguous = contiguous;
   if (dtype == MDIE_BF16) return launch_wide_t<bf16>(w, stream);
   return launch_wide_t<f16>(w, stream);
 }

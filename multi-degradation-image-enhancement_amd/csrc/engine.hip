@@ -569,10 +569,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   if (d->launch_ms == nullptr && !(d->flags & MDIE_FWD_SERIAL)) {   // instrumented mode stays serial
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); st = hipStreamCaptureStatusNone; }
-    // (experiments only: MDIE_CAPTURE_SIDE_STREAMS=1 restores round 1's shape -- the library's side streams join the caller's capture)
-    static const bool legacy_capture = getenv("MDIE_CAPTURE_SIDE_STREAMS") && atoi(getenv("MDIE_CAPTURE_SIDE_STREAMS")) != 0;
-    if (st == hipStreamCaptureStatusActive && legacy_capture && d->aux) { br.mode = Branches::STREAMS; br.aux = reinterpret_cast<Aux*>(d->aux); }
-    else if (st == hipStreamCaptureStatusActive) br.mode = Branches::GRAPH;
+    if (st == hipStreamCaptureStatusActive) br.mode = Branches::GRAPH;   // never a library stream inside a caller's capture
     else if (st == hipStreamCaptureStatusNone && d->aux) { br.mode = Branches::STREAMS; br.aux = reinterpret_cast<Aux*>(d->aux); }
     else if (st != hipStreamCaptureStatusNone) { set_error("mdie_cdan_forward: the stream's capture has been invalidated"); return MDIE_EINVAL; }
   }
@@ -627,10 +624,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   RUN(run_conv(c, CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
   if (!(d->flags & MDIE_FWD_FUSED_TAIL)) {
     // bilinear x2 + x (x read from its fp32 NCHW planes), final_dense, sigmoid written straight to NCHW
-    static const bool split_l0 = getenv("MDIE_FUSED_L0") && atoi(getenv("MDIE_FUSED_L0")) == 0;   // experiments: the two-launch form
-    if (split_l0) {
-      RUN(mdie_upsample2x_add_nchw3(d->dtype, B, h1, w1, c.ws + P.t4lo.off, P.t4lo.C, d->x, c.ws + P.t4.off, P.t4.C, stream));
-    } else {   // upsample + x and final_dense layer 0 in one launch (csrc/updense0.hip)
+    {   // upsample + x and final_dense layer 0 in one launch (csrc/updense0.hip)
       const int id0 = CV_DENSE0 + 3 * 5;
       mdie_up_dense0_desc u{};
       u.dtype = d->dtype; u.B = B; u.H = H; u.W = W;
@@ -643,7 +637,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
       u.g0 = c.ws + P.fg[0].off; u.g0_stride = P.fg[0].C;
       RUN(mdie_up_add_dense0_fwd(&u, stream));
     }
-    RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID, d->y, !split_l0));
+    RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID, d->y, true));
   } else {
     mdie_tail_desc t{};
     t.dtype = d->dtype; t.B = B; t.H = H; t.W = W;

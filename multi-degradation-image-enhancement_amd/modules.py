@@ -51,12 +51,19 @@ def _attach(root, spec):
 
 
 def _fingerprint(module):
-    v = 0
+    """Changes whenever a parameter or buffer may have changed: tensor versions (eager updates bump them) plus the
+    module's own counter, which everything that rewrites parameters WITHOUT bumping versions advances -- a replayed
+    hipGraph with the optimizer step inside (train.CapturedStep) -- and which every train() -> eval() transition
+    advances too, so an evaluation never runs on weights packed before the last training phase."""
+    v = getattr(module, "_mdie_epoch", 0)
     for t in module.parameters():
         v += t._version
     for t in module.buffers():
         v += t._version
     return v
+
+
+MAX_ENGINES = 4     # engines (workspace + side streams each) kept per module: least recently used beyond that are released
 
 
 class CDAN(nn.Module):
@@ -73,6 +80,12 @@ class CDAN(nn.Module):
         self.dropout_p = 0.2      # nn.Dropout(0.2), models/cdan.py:68 (training mode only)
         self._engines = {}
         self._packed = {}
+        self._mdie_epoch = 0
+
+    def train(self, mode=True):
+        if self.training and not mode:
+            self._mdie_epoch += 1      # weights may have been rewritten by graph replays (no version bump): repack at the next eval forward
+        return super().train(mode)
 
     def _engine(self, device):
         # one engine (workspace + side streams) per (device, precision, STREAM): forwards issued on different streams may
@@ -81,8 +94,14 @@ class CDAN(nn.Module):
         eng = self._engines.get(key)
         fp = (_fingerprint(self), id(next(self.parameters())))
         if eng is None:
+            while len(self._engines) >= MAX_ENGINES:           # transient streams must not pin a workspace each forever
+                old = next(iter(self._engines))
+                torch.cuda.synchronize(device)                  # its last forward may still be running on its stream
+                del self._engines[old], self._packed[old]
             eng = self._engines[key] = E.CdanEngine(device, self.precision)
             self._packed[key] = None
+        else:
+            self._engines[key] = self._engines.pop(key)         # most recently used last
         if self._packed[key] != fp:
             eng.load(self.state_dict())
             self._packed[key] = fp

@@ -620,14 +620,22 @@ class CapturedStep:
         values = step(x, t)                                     # device tensor [terms..., total]; ONE graph launch
 
     Building it leaves the training state untouched: the warm-up passes run forward + backward only and the BatchNorm /
-    dropout buffers they advanced are put back; the optimizer's state is created by one step on all-zero gradients (no
-    parameter moves) whose step count is reset.  `scale_fn` (e.g. GradScaler.scale) is applied to the total loss before
-    backward inside the graph -- the scaler's factor is a device tensor, so replays follow its updates."""
+    dropout buffers they advanced are put back; an optimizer WITHOUT state gets it from one step on all-zero gradients (no
+    parameter moves) whose step count is reset -- an optimizer that has already stepped (a second batch shape captured in
+    the middle of training: the last, partial batch of an epoch) is left exactly as it is.  `scale_fn` (e.g.
+    GradScaler.scale) is applied to the total loss before backward inside the graph -- the scaler's factor is a device
+    tensor, so replays follow its updates.
+
+    Gradients: the captured backward writes into gradient tensors of the graph's private pool.  Each CapturedStep keeps
+    its own (`self.grads`) and re-points every `p.grad` at them after a replay, so whatever reads `p.grad` next -- the
+    gradient exchange, `GradScaler.step`, an eager optimizer step -- sees THIS replay's gradients no matter which other
+    shape was captured or which eager step (`zero_grad(set_to_none=True)`) ran in between."""
 
     def __init__(self, net, losses, optimizer, x, t, warmup=2, scale_fn=None):
         dev = x.device
         self.net, self.losses, self.opt = net, losses, optimizer
         self.x, self.t = x.clone(), t.clone()
+        self.params = [p for p in net.parameters() if p.requires_grad]
 
         def fwd_bwd():
             total, values = losses(net(self.x), self.t)
@@ -644,8 +652,10 @@ class CapturedStep:
             for _ in range(max(1, warmup)):
                 net.zero_grad(set_to_none=True)
                 fwd_bwd()
-            if optimizer is not None:           # create the optimizer state outside the capture without moving a parameter
-                for p in net.parameters():
+            if optimizer is not None and len(optimizer.state) == 0:
+                # create the optimizer state outside the capture without moving a parameter (fresh optimizers only: with
+                # populated moments a zero-gradient step WOULD move every parameter and decay both moments)
+                for p in self.params:
                     if p.grad is not None:
                         p.grad.zero_()
                 optimizer.step()
@@ -661,11 +671,16 @@ class CapturedStep:
             self.values = fwd_bwd()
             if optimizer is not None:
                 optimizer.step()
+        self.grads = [p.grad for p in self.params]     # the graph's own gradient tensors (rewritten by every replay)
 
     def __call__(self, x, t):
         self.x.copy_(x, non_blocking=True)
         self.t.copy_(t, non_blocking=True)
         self.graph.replay()
+        for p, g in zip(self.params, self.grads):
+            p.grad = g
+        if self.opt is not None and hasattr(self.net, "_mdie_epoch"):
+            self.net._mdie_epoch += 1                  # parameters rewritten without a version bump: modules._fingerprint
         return self.values
 
 

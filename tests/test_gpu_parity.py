@@ -651,19 +651,29 @@ def test_thin_single_chunk_conv(E, L, prec, cin_segs, shape, pre):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("case", ["plain", "pool", "residual", "stats", "convT_ragged_batch"])
+@pytest.mark.parametrize("case", ["plain", "pool", "residual", "stats", "convT_ragged_batch",
+                                  "plain_noact", "plain_noact_half", "convT_noact", "convT_noact_half"])
 def test_wide_conv_lds_dma_kernel(E, L, prec, case):
     """conv_wide_kernel (csrc/conv_wide.hip: 32x16-pixel tiles, LDS-DMA double buffering, persistent workgroups) -- the
     kernel behind encoder.conv2-4 and decoder.conv1-3 at BASELINE sizes -- against torch's CPU convolution on the same
     rounded operands, and bit for bit against conv_kernel (which a single image, too few work items for the persistent
-    grid, still runs on): border tiles, several items per workgroup, 2 and 4 K chunks, every epilogue it has."""
+    grid, still runs on): border tiles, several items per workgroup, 2 and 4 K chunks, every epilogue it has.  The
+    `*_noact` cases are the activation-free instantiations (conv_wide.hip: `MDIE_ACT_NONE`, full-width items and the
+    half-width form taken below 192 items) that the training step selects for the forward and the input gradient of the wide
+    layers at BASELINE configs[2] sizes (the convolutions under `scaler.scale(loss).backward()`, models/model.py:160-164)."""
     import ctypes as C
     import torch.nn.functional as F
     dt, td = E.dtype_id(prec), TORCH_DT[prec]
     rnd = lambda t: t.to(td).float()
     B, H, W, cin, cout = {"plain": (12, 32, 64, 64, 128), "pool": (12, 32, 64, 128, 128), "residual": (12, 32, 32, 128, 256),
-                          "stats": (16, 32, 32, 64, 512), "convT_ragged_batch": (13, 16, 32, 64, 512)}[case]
-    assert B * (H // 16) * (W // 32) * (cout // 64) >= 96 > (H // 16) * (W // 32) * (cout // 64)    # the batch runs conv_wide, one image conv_kernel
+                          "stats": (16, 32, 32, 64, 512), "convT_ragged_batch": (13, 16, 32, 64, 512),
+                          "plain_noact": (12, 32, 64, 64, 256), "plain_noact_half": (12, 32, 64, 128, 128),
+                          "convT_noact": (25, 16, 32, 128, 512), "convT_noact_half": (13, 16, 32, 64, 512)}[case]
+    items = B * (H // 16) * (W // 32) * (cout // 64)
+    assert items >= 96 > (H // 16) * (W // 32) * (cout // 64)    # the batch runs conv_wide, one image conv_kernel
+    noact = "noact" in case
+    if noact:                                                     # half-width items below 3/4 of the 256 CUs (conv_wide.hip: launch_conv_wide)
+        assert (items * 4 < 256 * 3) == case.endswith("_half")
     g = torch.Generator().manual_seed(len(case) * 13 + cin)
     x = rnd(torch.randn(B, H, W, cin, generator=g))
     transposed = case.startswith("convT")
@@ -672,7 +682,9 @@ def test_wide_conv_lds_dma_kernel(E, L, prec, case):
     res = rnd(torch.randn(B, H, W, cout, generator=g)) if case == "residual" else None
     xin = x.permute(0, 3, 1, 2)
     ref = F.conv_transpose2d(xin, w, padding=1) if transposed else F.conv2d(xin, w, padding=1)
-    ref = torch.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ref = ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if not noact:
+        ref = torch.relu(ref)
     if case == "pool":
         ref = F.max_pool2d(ref, 2, 2)
     if res is not None:
@@ -691,7 +703,7 @@ def test_wide_conv_lds_dma_kernel(E, L, prec, case):
         d.inp[0] = L.Seg(dx.data_ptr(), cin, cin)
         d.cin, d.cout = cin, cout
         d.weight, d.post_scale, d.post_shift = wp.data_ptr(), dsc.data_ptr(), dsh.data_ptr()
-        d.act, d.pool = L.ACT_RELU, int(case == "pool")
+        d.act, d.pool = (L.ACT_NONE if noact else L.ACT_RELU), int(case == "pool")
         if dres is not None:
             d.residual, d.res_stride = dres.data_ptr(), cout
         d.out, d.out_stride = out.data_ptr(), cout
@@ -1544,6 +1556,9 @@ def test_router_checkpoint_format_thresholds_and_routing(E, tmp_path):
         router.forward(x)                        # CPU tensor
 
 
+_ORACLE_TRAIN_STEP = {}
+
+
 @pytest.mark.parametrize("precision,shape,min_cos,med_cos,out_tol", [("fp32", (2, 64, 64), 0.9999, 0.99999, 2e-4),
                                                                      ("fp32", (1, 40, 56), 0.9999, 0.99999, 2e-4),    # one image, ragged tiles
                                                                      # 1x1 maps at the deep end: BatchNorm over TWO samples normalises to exactly +-1, the true gradient
@@ -1551,7 +1566,14 @@ def test_router_checkpoint_format_thresholds_and_routing(E, tmp_path):
                                                                      ("fp32", (2, 8, 8), 0.95, 0.9999, 2e-4),
                                                                      ("bf16", (2, 64, 64), 0.87, 0.98, 3e-2),     # measured: worst 0.8934-0.8966, median 0.9870
                                                                      # fp16 = the reference's own autocast dtype: gradients need its GradScaler (models/model.py:31,164)
-                                                                     ("fp16", (2, 64, 64), 0.986, 0.9975, 8e-3)])     # measured: worst 0.9931, median 0.99874, output 3.9e-3
+                                                                     ("fp16", (2, 64, 64), 0.986, 0.9975, 8e-3),      # measured: worst 0.9931, median 0.99874, output 3.9e-3
+                                                                     # 256x256: the kernel selection of BASELINE configs[2] (512x512, B=8/GPU) -- B=2: encoder.conv2 has 2*8*4*2 = 128
+                                                                     # items -> conv_wide_kernel<ACT_NONE> (forward and dgrad of the wide layers), 512 full-resolution tiles -> conv_kernel;
+                                                                     # B=4: 1024 tiles -> conv_thin_kernel for the final DenseBlock's layers and their input gradients
+                                                                     ("bf16", (2, 256, 256), 0.85, 0.975, 3e-2),
+                                                                     ("fp16", (2, 256, 256), 0.98, 0.996, 8e-3),
+                                                                     ("bf16", (4, 256, 256), 0.85, 0.975, 3e-2),
+                                                                     ("fp16", (4, 256, 256), 0.98, 0.996, 8e-3)])
 def test_whole_network_training_step_vs_oracle(E, precision, shape, min_cos, med_cos, out_tol):
     """forward + backward of the whole network in training mode (batch-stat BN, dropout off) at 2x3x64x64 against the CPU
     oracle differentiated by autograd: output, loss, and the direction of EVERY parameter gradient (cosine similarity;
@@ -1563,11 +1585,15 @@ def test_whole_network_training_step_vs_oracle(E, precision, shape, min_cos, med
     from oracle import params as P
     sd = P.make_state_dict(42)
     x, t = P.lowlight_batch(77, *shape)
-    ref_sd = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v))
-              for k, v in sd.items()}
-    ry = O.cdan_forward(ref_sd, x.double(), "train", {})
-    rloss = torch.sqrt((ry - t.double()) ** 2 + 1e-6).mean()
-    rloss.backward()
+    if shape not in _ORACLE_TRAIN_STEP:          # fp64 oracle, once per shape (the 256x256 cases share it between precisions)
+        ref_sd = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v))
+                  for k, v in sd.items()}
+        ry = O.cdan_forward(ref_sd, x.double(), "train", {})
+        rloss = torch.sqrt((ry - t.double()) ** 2 + 1e-6).mean()
+        rloss.backward()
+        _ORACLE_TRAIN_STEP.clear()               # keep one shape at a time (gradients of the whole network in fp64)
+        _ORACLE_TRAIN_STEP[shape] = ({k: v.grad for k, v in ref_sd.items() if getattr(v, "grad", None) is not None}, ry.detach(), rloss.detach())
+    ref_grad, ry, rloss = _ORACLE_TRAIN_STEP[shape]
     net = CDAN(precision=precision)
     net.load_state_dict(sd, strict=True)
     net = net.cuda().train()
@@ -1582,7 +1608,7 @@ def test_whole_network_training_step_vs_oracle(E, precision, shape, min_cos, med
     assert loss.item() == pytest.approx(rloss.item(), rel=out_tol)
     worst, allcos = (1.0, None), []
     for k, p in net.named_parameters():
-        g, r = p.grad.detach().double().cpu().reshape(-1), ref_sd[k].grad.reshape(-1)
+        g, r = p.grad.detach().double().cpu().reshape(-1), ref_grad[k].reshape(-1)
         if r.norm().item() < 1e-9 * max(1.0, float(r.numel()) ** 0.5):   # biases in front of a batch-stat BatchNorm: exact zeros
             assert g.abs().max().item() <= 1e-6, k
             continue
@@ -1635,6 +1661,61 @@ def test_captured_training_step_equals_eager_steps(E):
     assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1])), "parameters differ after 3 steps"
     assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2])), "BatchNorm buffers differ"
     assert not torch.equal(runs[1][0][0], runs[1][0][1])
+
+
+@pytest.mark.parametrize("whole", [True, False])
+def test_captured_steps_two_batch_shapes_and_eager_mix(E, whole):
+    """What `Model.train_step` does with a dataset whose size is not a multiple of the batch size (drop_last=False,
+    models/model.py:154-172 over data/dataset.py's loader): one CapturedStep per batch shape, the second one built in the
+    MIDDLE of training (Adam's moments populated), replays of the two alternating, an eager step in between.  `whole`:
+    Adam inside the graph (single GPU, no GradScaler); otherwise the graph holds forward + loss + backward and the optimizer
+    steps on `p.grad` after the replay (the GradScaler / gradient-exchange path) -- that path reads `p.grad`, which must be
+    the gradient of the replay just made, not of whichever graph was captured last.  Parameters, buffers, losses and the
+    evaluation output afterwards bit-identical to the same schedule stepped eagerly."""
+    from models.cdan import CDAN
+    import mdie_amd.host as H
+    import mdie_amd.train as T
+    from oracle import params as P
+    sd = P.make_state_dict(42)
+    losses = H.build_losses({"enabled": True, "terms": [{"name": "charbonnier", "weight": 1.0}]})
+    full = [tuple(v.cuda() for v in P.lowlight_batch(80 + i, 3, 32, 32)) for i in range(5)]
+    part = [tuple(v.cuda() for v in P.lowlight_batch(90 + i, 2, 32, 32)) for i in range(2)]
+    schedule = [("g", full[0]), ("g", full[1]), ("g", part[0]), ("g", full[2]), ("e", full[3]), ("g", part[1]), ("g", full[4])]
+    xe = P.lowlight_batch(99, 2, 32, 32)[0].cuda()
+    runs = []
+    for mode in ("eager", "graph"):
+        torch.manual_seed(5)
+        net = CDAN(precision="bf16")
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=whole)
+        captured, vals = {}, []
+        for kind, (x, t) in schedule:
+            if mode == "graph" and kind == "g":
+                key = tuple(x.shape)
+                if key not in captured:
+                    captured[key] = T.CapturedStep(net, losses, opt if whole else None, x, t)
+                vals.append(captured[key](x, t).clone())
+                if not whole:
+                    opt.step()
+            else:
+                opt.zero_grad(set_to_none=True)
+                total, v = losses(net(x), t)
+                total.backward()
+                opt.step()
+                vals.append(v.clone())
+        net.eval()
+        with torch.no_grad():
+            ye = net(xe).clone()               # must run on the weights the replays produced (no tensor version was bumped by them)
+        torch.cuda.synchronize()
+        runs.append((vals, [p.detach().clone() for p in net.parameters()], [b.clone() for b in net.buffers()], ye))
+        if mode == "graph":
+            assert len(captured) == 2
+    for i, (a, b) in enumerate(zip(runs[0][0], runs[1][0])):
+        assert torch.equal(a, b), f"loss values differ at step {i}"
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1])), "parameters differ"
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2])), "BatchNorm buffers differ"
+    assert torch.equal(runs[0][3], runs[1][3]), "evaluation after graph-replayed training ran on stale packed weights"
 
 
 def test_training_step_is_bitwise_reproducible(E):

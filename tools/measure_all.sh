@@ -24,6 +24,7 @@ run train_bf16_b8_256 python tools/bench_train.py bf16 8 256
 run train_fp16_b8_512 python tools/bench_train.py fp16 8 512
 run e2e_bf16 python tools/bench_e2e.py bf16
 run inflight_bf16 python tools/bench_inflight.py 1 2 3
+mkdir -p build && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/bandwidth.hip -o build/bandwidth && run achievable_bandwidth_hip build/bandwidth
 run conv_microbench python tools/bench_conv.py bf16 conv2 conv3 conv4 dec1 dec2 dec3 first d1l0 d1l3 fl3 ftr
 
 cd /tmp && export TMPDIR=/tmp

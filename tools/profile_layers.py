@@ -16,8 +16,7 @@ NAMES = ["enc.conv1+pool"] + [f"dense1.l{i}" for i in range(4)] + ["dense1.tr", 
          "cbam1.gate", "cbam1.chanpool", "cbam1.spatial*d3", "dec.conv2", "up2+skip1+pool",
          "cbam2.gate+chanpool", "cbam2.spatial*d2", "dec.conv3", "up3+skip0+pool",
          "cbam3.gate+chanpool", "cbam3.spatial*d1", "dec.conv4"]
-split_l0 = os.environ.get("MDIE_FUSED_L0") == "0"
-NAMES += (["tail(fused)"] if fused else (["up4+x(nchw)", "final.l0"] if split_l0 else ["up4+x+final.l0"]) + [f"final.l{i}" for i in range(1, 4)] + ["final.tr+sigmoid->nchw"])
+NAMES += (["tail(fused)"] if fused else ["up4+x+final.l0"] + [f"final.l{i}" for i in range(1, 4)] + ["final.tr+sigmoid->nchw"])
 net = CDAN(precision=prec)
 net.load_state_dict(P.make_state_dict(42), strict=True)
 net = net.eval().cuda()
