@@ -499,9 +499,12 @@ __global__ __launch_bounds__(TR_THREADS, 1) void wgrad_tile_f32_kernel(const Wgr
 struct WgTilePlan { int cfg, c_tile, o_tile, c_tiles, o_tiles, splits, tiles_per_split, total_tiles, tiles_x, tiles_y; };
 
 // cfg 0: 64c x 64o (2x2 waves of 32x32); 1: 64c x 16o (cout-thin); 2: 16c x 64o (cin-thin)
-static WgTilePlan wgrad_tile_plan(int B, int H, int W, int cin_st, int cout_st) {
+// (pre9: a 3x3 layer with the pre-activation prologue never takes cfg 0 -- that instantiation needs 17 registers more than
+//  the 256 of two waves per SIMD and would spill; CDAN has no such layer, its pre-activated 3x3 layers have 16 outputs, but
+//  the C ABI admits one.  cfg 1 has at least as many (c, o) tiles, so never more splits: the workspace query stays an upper bound.)
+static WgTilePlan wgrad_tile_plan(int B, int H, int W, int cin_st, int cout_st, bool pre9 = false) {
   WgTilePlan p{};
-  if (cout_st % 64 != 0) { p.cfg = 1; p.c_tile = 64; p.o_tile = 16; }
+  if (cout_st % 64 != 0 || pre9) { p.cfg = 1; p.c_tile = 64; p.o_tile = 16; }
   else if (cin_st <= 16) { p.cfg = 2; p.c_tile = 16; p.o_tile = 64; }
   else { p.cfg = 0; p.c_tile = 64; p.o_tile = 64; }
   p.c_tiles = cdiv(cin_st, p.c_tile); p.o_tiles = cdiv(cout_st, p.o_tile);
@@ -548,7 +551,8 @@ static void launch_wgrad_tile_f32(const WgradTileArgs& a, const WgTilePlan& p, h
 // 9-tap 64x64 configuration (never used with a prologue by this network: dense 3x3 layers have 16 outputs) into spills
 template <typename T, int NTAP, int CSW, int OSW, int WC, int WO>
 static void launch_wgrad_tile_h(const WgradTileArgs& a, const WgTilePlan& p, hipStream_t s) {
-  if (a.pre_scale) launch_wgrad_tile_t<T, NTAP, CSW, OSW, WC, WO, true>(a, p, s);
+  if constexpr (NTAP == 9 && CSW * OSW == 4) launch_wgrad_tile_t<T, NTAP, CSW, OSW, WC, WO, false>(a, p, s);   // (wgrad_tile_plan: never with a prologue)
+  else if (a.pre_scale) launch_wgrad_tile_t<T, NTAP, CSW, OSW, WC, WO, true>(a, p, s);
   else launch_wgrad_tile_t<T, NTAP, CSW, OSW, WC, WO, false>(a, p, s);
 }
 template <int NTAP, int CSW, int OSW, int WC, int WO>
@@ -602,7 +606,7 @@ extern "C" int mdie_conv_wgrad(const mdie_wgrad_desc* d, void* stream) {
   }
   MDIE_REQUIRE(c >= d->cin + (d->split < d->cin ? d->gap : 0), "mdie_conv_wgrad: segments hold %d channels < cin %d + gap", c, d->cin);
   const int taps = d->ksize * d->ksize;
-  const WgTilePlan p = wgrad_tile_plan(d->B, d->H, d->W, c, d->cout_stored);
+  const WgTilePlan p = wgrad_tile_plan(d->B, d->H, d->W, c, d->cout_stored, d->pre_scale != nullptr && taps == 9 && d->dtype != MDIE_F32);
   const size_t need = (size_t)p.splits * taps * c * d->cout_stored * sizeof(float);
   if (d->workspace_bytes < need) { set_error("mdie_conv_wgrad: workspace %zu < %zu", d->workspace_bytes, need); return MDIE_ENOSPC; }
   t.cin_st = c; t.cout_st = d->cout_stored;

@@ -174,3 +174,19 @@ def test_custom_torch_ops_are_registered_and_have_no_cpu_kernel():
         torch.ops.mdie.cdan_forward(torch.zeros(1, 3, 8, 8), torch.zeros(8, dtype=torch.uint8), torch.zeros(8, dtype=torch.uint8), 1, 0, 0)
     with pytest.raises(NotImplementedError):
         torch.ops.mdie.psnr_ssim(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16))
+
+
+def test_shipped_code_objects_pass_the_isa_guard():
+    """tools/isa_guard.py on the library the tests load: no kernel that issues MFMAs reads a VGPR pair through the
+    op_sel / op_sel_hi modifiers of a packed-f32 instruction (the combination that produced wrong lanes 48..63 in round 2,
+    DESIGN.md section 4 finding 6), and no kernel of the library spills registers to scratch."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_guard
+    rows = isa_guard.audit(L.LIB_PATH)
+    assert len(rows) > 100 and sum(1 for r in rows if r["mfma"]) > 50, "disassembly found too few kernels: the audit itself is broken"
+    assert any(r["pk_sel"] for r in rows if not r["mfma"]), "the audit no longer recognises the op_sel forms it exists to find"
+    bad = isa_guard.violations(rows)
+    assert not bad, [(r["pretty"], r["pk_sel"][:2]) for r in bad]
+    spills = [r["pretty"] for r in rows if r["scratch"]]
+    assert not spills, spills
