@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 16
+#define MDIE_ABI_VERSION 17
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1,
        MDIE_F16 = 2 /* IEEE half: the reference's mixed-precision dtype (torch.cuda.amp.autocast, models/model.py:15,159) */ };
@@ -69,6 +69,29 @@ typedef struct {
  * ConvTranspose2d(k3,s1,p1) is the same kernel with flipped/transposed weights
  * (mdie_pack_conv_weight(..., transposed=1)).
  * --------------------------------------------------------------------------------- */
+/* The DenseBlock's transition (BatchNorm -> ReLU -> Conv1x1, models/cdan.py:48-53) folded into the producers of its input:
+ *     relu(bn(cat(f0, f1, ..))) . W  ==  sum over the segments f_s of relu(bn_s(f_s)) . W_s,
+ * so the kernel that has just computed a segment adds that segment's term to a running fp32 partial sum of the transition's
+ * (<= 3) outputs, [B,H,W,4] floats, while the segment is still in registers; the last producer finishes the sum with the
+ * transition's epilogue and never stores its own segment.  The engine does this for decoder.final_dense (models/cdan.py:119,
+ * 155-157): one launch, the re-read of all 67 channels and the last growth map's write disappear.  16-bit element types, H and W
+ * multiples of 16 (mdie_conv_fwd returns MDIE_EINVAL otherwise; the unfused chain -- four 3x3 layers, then the 1x1 -- is the
+ * general form).  Arithmetic: the term is formed from the STORED (rounded) segment, pre-activated and rounded exactly as the
+ * transition's own launch would, multiplied on the matrix pipe with fp32 accumulation; only the order of the fp32 sum over
+ * segments differs from the single launch. */
+typedef struct {
+  const void* weight;        /* the transition's 1x1 weights as mdie_pack_conv_weight packs them (cout_stored = 16) */
+  int c0;                    /* stored input channel OF THE TRANSITION at which this layer's output channel 0 sits (multiple of 8) */
+  const float* pre_scale;    /* the transition's folded BatchNorm, indexed by ITS stored input channel */
+  const float* pre_shift;
+  const float* partial_in;   /* partial sums so far (written by the previous producer) */
+  float* partial_out;        /* middle producer: partial sums out (may be partial_in) */
+  const float* post_scale;   /* last producer: the transition's epilogue, [>= 4] each ... */
+  const float* post_shift;
+  int act;                   /* ... MDIE_ACT_SIGMOID ... */
+  float* out_nchw3;          /* ... and the fp32 NCHW [B,3,H,W] destination; NULL marks a middle producer */
+} mdie_tr_fuse;
+
 typedef struct {
   int dtype;
   int B, H, W;             /* input extent; output is H x W, or H/2 x W/2 with pool */
@@ -94,6 +117,7 @@ typedef struct {
                               maxima of the tensor written, [B][tiles per image][2][cout] with tiles of edge
                               mdie_conv_tile(B,H,W,cout) in raster order -- the global pools of the CBAM that consumes
                               it (models/cbam.py:41,44; mdie_cbam_desc.pool_partial) fused into their producer */
+  const mdie_tr_fuse* tr;  /* optional: fold the consuming transition into this layer (above); `out` may be NULL for the last producer */
 } mdie_conv_desc;
 
 int mdie_conv_fwd(const mdie_conv_desc* d, void* stream);
@@ -301,6 +325,8 @@ typedef struct {
   const float* pre_scale; const float* pre_shift;   /* >= 3 entries */
   const float* bias;           /* [16] */
   void* g0; int g0_stride;
+  const mdie_tr_fuse* tr;      /* optional (16-bit types): start the transition's partial sums with the terms of `base` (the transition's
+                                  stored channels 0..2) and of g0 (stored channels tr->c0 ..); partial_in is ignored, partial_out written */
 } mdie_up_dense0_desc;
 int mdie_up_add_dense0_fwd(const mdie_up_dense0_desc* d, void* stream);
 

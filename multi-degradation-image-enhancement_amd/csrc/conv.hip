@@ -934,6 +934,11 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   fill_epi(a.e, d->H, d->W, d->post_scale, d->post_shift, d->act, d->pool, d->residual, d->res_stride, d->out, d->out_stride, d->out_nchw3);
   a.pool_partial = d->pool_partial;
   if (conv_wide_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr)) return launch_conv_wide(Traits<T>::DT, a, stream);
+  if (d->tr) {   // the block's transition folded into this layer: conv_thin_kernel only (csrc/conv_thin.hip)
+    MDIE_REQUIRE(conv_thin_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr, true),
+                 "mdie_conv_fwd: tr needs a 16-bit 3x3 layer with pre-activation, 16 outputs, <= 56 stored input channels and H, W multiples of 16");
+    return launch_conv_thin(Traits<T>::DT, a, stream, d->tr);
+  }
   if (conv_thin_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr)) return launch_conv_thin(Traits<T>::DT, a, stream);
   const int bn = (d->cout % 64 == 0) ? 64 : 16;
   a.n_tiles = d->cout / bn;

@@ -264,7 +264,7 @@ bool conv_wide_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw
 int launch_conv_wide(int dtype, ConvArgs& a, hipStream_t stream);
 // conv_thin.hip: persistent, register-prefetched 3x3 convolution for pre-activated 16-output layers with <= 64 stored input
 // channels on full 16x16 tiles (decoder.final_dense)
-bool conv_thin_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw3);
-int launch_conv_thin(int dtype, const ConvArgs& a, hipStream_t stream);
+bool conv_thin_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw3, bool any_batch = false);
+int launch_conv_thin(int dtype, const ConvArgs& a, hipStream_t stream, const mdie_tr_fuse* tr = nullptr);
 
 }  // namespace mdie

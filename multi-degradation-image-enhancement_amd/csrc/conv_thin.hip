@@ -59,6 +59,11 @@ struct ThinArgs {
   const float *post_scale, *post_shift;   // [16]
   char* out; unsigned out_stride;   // bytes per pixel
   unsigned long long* dbg;          // (diagnostic builds)
+  // TR != 0: the block's transition folded into this layer (mdie_tr_fuse, see below)
+  const char* tr_w; int tr_c0;      // the transition's packed 1x1 weights (16 stored outputs); stored input channel of this layer's output 0
+  const float *tr_scale, *tr_shift; // the transition's folded BatchNorm, this layer's 16 channels
+  const float* tr_in; float* tr_out;    // [pixel][4] fp32 partial sums of the transition (may be the same buffer)
+  const float *tr_post_scale, *tr_post_shift; float* tr_nchw3;   // TR == 2: the transition's epilogue constants and the network output
 };
 
 #ifdef EXP_TSTAMPS   // diagnostic build only (tools/stamp_thin.py): per-segment shader-clock sums of wave 0 of each workgroup
@@ -69,7 +74,19 @@ static unsigned long long* g_thin_dbg = nullptr;
 #endif
 
 // NCHUNK = 64-byte K chunks (1: <= 4 columns, 2: <= 8); CPW = NCHUNK = column slots per wave (column j = wave + 4c)
-template <typename T, int NCHUNK, int ACT>
+//
+// TR: the DenseBlock's transition (BN -> ReLU -> Conv1x1, models/cdan.py:48-53) folded into its producers.
+//     relu(bn(cat(f0, f1, ..))) . W  ==  sum over segments of relu(bn_s(f_s)) . W_s,
+// so a layer can add the term of the 16 channels it has just computed while they are still in registers: the accumulator
+// layout of the MFMA (lane (lq, lp): channels 4 lq .. 4 lq + 3 of pixel lp) IS the B-operand layout of a second MFMA whose
+// K axis is those channels (k = 8 lq + j, j < 4; j >= 4 meets zero weights), so the term costs 10 vector instructions and
+// one MFMA per 16 pixels.  The A operand of row subtile ps holds the transition's rows at 4 ps + o, zeros elsewhere: the
+// four subtiles accumulate into ONE accumulator in which lane (lq, lp) ends up with the 3 outputs of pixel (row 4 wave +
+// lq, column lp) -- one 16-byte fp32 partial per lane and tile, read, added and written back (TR = 1), or finished with
+// the transition's bias and the sigmoid and written as the network's fp32 NCHW output while the layer's own 16 channels
+// are never stored (TR = 2: nothing reads them).  Removes the transition's launch, its re-read of all 67 channels and the
+// last growth map's write from decoder.final_dense (engine.hip).
+template <typename T, int NCHUNK, int ACT, int TR = 0>
 __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs a, const int n_items) {
   static_assert(sizeof(T) == 2, "16-bit storage types");
   constexpr int PW = TH_PW, PIT = TH_PIT, CPW = NCHUNK;
@@ -107,6 +124,24 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
     for (int c = tid; c < nc; c += TH_THREADS) { lds_pre[c] = c < a.cin ? a.pre_scale[c] : 0.f; lds_pre[nc + c] = c < a.cin ? a.pre_shift[c] : 0.f; }
   }
   const float4 esc = *reinterpret_cast<const float4*>(a.post_scale + 4 * lq), esh = *reinterpret_cast<const float4*>(a.post_shift + 4 * lq);
+  // transition term: A fragments (row lp of subtile ps' operand = output lp - 4 ps, K group lq = this layer's channels
+  // 4 lq .. 4 lq + 3 in elements 0..3) and the transition's BatchNorm constants of the lane's 4 channels
+  uint2 tra[4];
+  f32x2 trs[2], trb[2];
+  float4 trps = make_float4(0.f, 0.f, 0.f, 0.f), trpb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (TR != 0) {
+    const int c = a.tr_c0 + 4 * lq;                                          // stored input channel of the transition
+    const char* const wrow = a.tr_w + ((size_t)(c >> 5) * 4 + ((c & 31) >> 3)) * (16 * 16) + (c & 7) * 2;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int o = lp - 4 * ps;
+      const uint2 w = *reinterpret_cast<const uint2*>(wrow + (unsigned)(o & 15) * 16);   // (unconditional load, masked after)
+      tra[ps] = (o >= 0 && o < 4) ? w : make_uint2(0u, 0u);
+    }
+    const float4 s4 = *reinterpret_cast<const float4*>(a.tr_scale + 4 * lq), b4 = *reinterpret_cast<const float4*>(a.tr_shift + 4 * lq);
+    trs[0] = f32x2{s4.x, s4.y}; trs[1] = f32x2{s4.z, s4.w}; trb[0] = f32x2{b4.x, b4.y}; trb[1] = f32x2{b4.z, b4.w};
+    if constexpr (TR == 2) { trps = *reinterpret_cast<const float4*>(a.tr_post_scale); trpb = *reinterpret_cast<const float4*>(a.tr_post_shift); }
+  }
 
   // ---- lane constants ----
   // staging: patch pixel p = lane + 64 it: offset in pixels from the patch corner, LDS offset inside a plane, border classes
@@ -139,6 +174,7 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
   for (int k = 0; k < NCHUNK; ++k) xoff[k] = min(4 * k + lq, a.ncol - 1) * TH_PLANE + ((4 * wave) * PWP + lp) * 16;
   // output: lane (lq, lp) stores channels 4 lq .. 4 lq + 3 of pixel lp of the row: 512 contiguous bytes per 16 lanes x 4
   const unsigned olane = (unsigned)lp * a.out_stride + (unsigned)lq * 8u;
+  const unsigned plane_px = (unsigned)lq * (unsigned)a.W + (unsigned)lp;      // TR: the lane's pixel (row 4 wave + lq, column lp) from the wave's first
 
   uint4 pv[CPW][PIT];
   unsigned okm = 0;
@@ -194,6 +230,11 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
     TSEG(0);
     __syncthreads();
     TSEG(1);
+    // ---- TR: this tile's partial sums, requested ahead of the next tile's columns (older in the vmcnt queue: the epilogue
+    //      waits for them without waiting for the prefetch) ----
+    float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t ppix = ((size_t)img * a.H + y0 + 4 * wave) * a.W + x0;      // wave-uniform
+    if constexpr (TR != 0) part = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.tr_in + 4 * ppix) + plane_px * 16u);   // (unconditional: the host requires tr_in)
     // ---- next tile's columns into registers ----
     last = item + 1 >= item_end;
     int nimg = img, ny0 = y0, nx0 = x0;                                      // (the last tile is loaded once more: no branch around the loads)
@@ -235,14 +276,36 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
     TSEG(3);
     // ---- epilogue: affine, activation, one 8-byte store per lane and row (unconditional: tiles are full) ----
     char* const obase = a.out + ((((size_t)img * a.H + y0 + 4 * wave) * a.W + x0) * a.out_stride);   // wave-uniform
+    f32x4 tacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       f32x2 lo = __builtin_elementwise_fma(f32x2{acc[ps][0], acc[ps][1]}, f32x2{esc.x, esc.y}, f32x2{esh.x, esh.y});
       f32x2 hi = __builtin_elementwise_fma(f32x2{acc[ps][2], acc[ps][3]}, f32x2{esc.z, esc.w}, f32x2{esh.z, esh.w});
       i16x2 p0 = half_bits<T>(lo), p1 = half_bits<T>(hi);
       if constexpr (ACT == MDIE_ACT_RELU) { p0 = __builtin_elementwise_max(p0, i16x2{0, 0}); p1 = __builtin_elementwise_max(p1, i16x2{0, 0}); }
-      char* const o = obase + (size_t)ps * a.W * a.out_stride;                                         // wave-uniform
-      *reinterpret_cast<uint2*>(o + olane) = make_uint2(__builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, p1));
+      if constexpr (TR != 2) {
+        char* const o = obase + (size_t)ps * a.W * a.out_stride;                                       // wave-uniform
+        *reinterpret_cast<uint2*>(o + olane) = make_uint2(__builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, p1));
+      }
+      if constexpr (TR != 0) {   // the transition's pre-activation of the STORED values (what its own launch would read back), then its MFMA
+        const uint32_t u0 = __builtin_bit_cast(uint32_t, p0), u1 = __builtin_bit_cast(uint32_t, p1);
+        const f32x2 r0 = __builtin_elementwise_fma(f32x2{Half<T>::lo(u0), Half<T>::hi(u0)}, trs[0], trb[0]);
+        const f32x2 r1 = __builtin_elementwise_fma(f32x2{Half<T>::lo(u1), Half<T>::hi(u1)}, trs[1], trb[1]);
+        const uint32_t t0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(half_bits<T>(r0), i16x2{0, 0}));
+        const uint32_t t1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(half_bits<T>(r1), i16x2{0, 0}));
+        tacc = mma16<T>(make_uint4(tra[ps].x, tra[ps].y, 0u, 0u), make_uint4(t0, t1, 0u, 0u), tacc);
+      }
+    }
+    if constexpr (TR == 1) {
+      *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.tr_out + 4 * ppix) + plane_px * 16u) =
+          make_float4(part.x + tacc[0], part.y + tacc[1], part.z + tacc[2], 0.f);
+    } else if constexpr (TR == 2) {   // transition bias, sigmoid, fp32 NCHW: 16 consecutive floats per lane group and plane
+      const size_t hw = (size_t)a.H * a.W;
+      float* const ob = a.tr_nchw3 + (size_t)img * 3 * hw + ((size_t)(y0 + 4 * wave) * a.W + x0);   // wave-uniform
+      const float v0 = fmaf(part.x + tacc[0], trps.x, trpb.x), v1 = fmaf(part.y + tacc[1], trps.y, trpb.y), v2 = fmaf(part.z + tacc[2], trps.z, trpb.z);
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(ob) + plane_px * 4u) = sigmoidf(v0);
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(ob + hw) + plane_px * 4u) = sigmoidf(v1);
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(ob + 2 * hw) + plane_px * 4u) = sigmoidf(v2);
     }
     ++item; img = nimg; y0 = ny0; x0 = nx0;
     TSEG(4);
@@ -263,7 +326,9 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
 }
 
 // ---- host -----------------------------------------------------------------------------------------------------------
-bool conv_thin_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw3) {
+// any_batch: the caller needs THIS kernel whatever the batch size (the transition fusion exists only here) -- the item
+// threshold below is a speed choice, not a limit of the kernel
+bool conv_thin_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw3, bool any_batch) {
   if (dtype == MDIE_F32 || ksize != 3 || has_nchw3 || !a.pre_scale || a.cout != 16) return false;
   if (a.e.pool || a.e.residual || a.pool_partial || (a.e.act != MDIE_ACT_NONE && a.e.act != MDIE_ACT_RELU)) return false;
   if (a.H % TH_TILE != 0 || a.W % TH_TILE != 0) return false;
@@ -273,28 +338,31 @@ bool conv_thin_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw
     if (a.seg[s].ch_begin % 8 != 0 || a.seg[s].ch_end % 8 != 0 || (size_t)(TH_PW + 1) * a.W * a.seg[s].stride * 2 >= ((size_t)1 << 24) * 16) return false;
   if ((size_t)a.W * 20 >= ((size_t)1 << 24)) return false;                                      // 24-bit multiply of the pixel offset
   const long items = (long)a.B * (a.H / TH_TILE) * (a.W / TH_TILE);
-  return items >= 1024;   // fewer: one tile per workgroup, nothing to pipeline -- conv_kernel
+  return any_batch || items >= 1024;   // fewer: one tile per workgroup, nothing to pipeline -- conv_kernel
 }
 
 template <typename T, int NCHUNK>
-static int launch_thin_t(const ThinArgs& t, int act, int items, hipStream_t stream) {
+static int launch_thin_t(const ThinArgs& t, int act, int tr, int items, hipStream_t stream) {
   const size_t lds = (size_t)t.ncol * TH_PLANE + (size_t)2 * t.ncol * 8 * sizeof(float);
   const int per_cu = 2;                                                       // (registers: weights live in them)
   const int wgs = 8 * cdiv(std::min(items, 256 * per_cu), 8);
   TimedLaunch tl(MDIE_K_CONV3);
-#define MDIE_THIN(ACT)                                                                                            \
-  do {                                                                                                            \
-    static LdsOptIn opt;                                                                                          \
-    if (!opt.ensure(reinterpret_cast<const void*>(&conv_thin_kernel<T, NCHUNK, ACT>), 64 * 1024)) return MDIE_ELAUNCH; \
-    hipLaunchKernelGGL((conv_thin_kernel<T, NCHUNK, ACT>), dim3(wgs), dim3(TH_THREADS), lds, stream, t, items);      \
+#define MDIE_THIN(ACT, TR)                                                                                            \
+  do {                                                                                                                \
+    static LdsOptIn opt;                                                                                              \
+    if (!opt.ensure(reinterpret_cast<const void*>(&conv_thin_kernel<T, NCHUNK, ACT, TR>), 64 * 1024)) return MDIE_ELAUNCH; \
+    hipLaunchKernelGGL((conv_thin_kernel<T, NCHUNK, ACT, TR>), dim3(wgs), dim3(TH_THREADS), lds, stream, t, items);      \
   } while (0)
-  if (act == MDIE_ACT_RELU) MDIE_THIN(MDIE_ACT_RELU); else MDIE_THIN(MDIE_ACT_NONE);
+  if (tr == 1) MDIE_THIN(MDIE_ACT_NONE, 1);
+  else if (tr == 2) MDIE_THIN(MDIE_ACT_NONE, 2);
+  else if (act == MDIE_ACT_RELU) MDIE_THIN(MDIE_ACT_RELU, 0);
+  else MDIE_THIN(MDIE_ACT_NONE, 0);
 #undef MDIE_THIN
   MDIE_LAUNCH_CHECK("mdie_conv_fwd");
   return MDIE_OK;
 }
 
-int launch_conv_thin(int dtype, const ConvArgs& a, hipStream_t stream) {
+int launch_conv_thin(int dtype, const ConvArgs& a, hipStream_t stream, const mdie_tr_fuse* tr) {
   ThinArgs t{};
   t.B = a.B; t.H = a.H; t.W = a.W; t.tiles_x = a.W / TH_TILE; t.tiles_y = a.H / TH_TILE;
   t.ncol = (a.cin + 7) / 8; t.cin = a.cin;
@@ -308,12 +376,30 @@ int launch_conv_thin(int dtype, const ConvArgs& a, hipStream_t stream) {
   t.pre_scale = a.pre_scale; t.pre_shift = a.pre_shift; t.weight = a.weight;
   t.post_scale = a.e.post_scale; t.post_shift = a.e.post_shift;
   t.out = a.e.out; t.out_stride = (unsigned)a.e.out_stride * 2u;
+  int mode = 0;
+  if (tr) {
+    const bool last = tr->out_nchw3 != nullptr;
+    MDIE_REQUIRE(a.e.act == MDIE_ACT_NONE, "mdie_conv_fwd: the transition fusion takes layers without activation");
+    MDIE_REQUIRE(tr->weight && tr->pre_scale && tr->pre_shift && tr->partial_in && tr->c0 >= 0 && tr->c0 % 8 == 0,
+                 "mdie_conv_fwd: tr needs weight, pre_scale / pre_shift, partial_in and a c0 that is a multiple of 8 (got %d)", tr->c0);
+    MDIE_REQUIRE(last ? (tr->post_scale && tr->post_shift && tr->act == MDIE_ACT_SIGMOID) : (tr->partial_out != nullptr && a.e.out != nullptr),
+                 "mdie_conv_fwd: tr is either a middle producer (partial_out, out) or the last one (out_nchw3, post_scale / post_shift, sigmoid)");
+    MDIE_REQUIRE((((uintptr_t)tr->partial_in | (uintptr_t)tr->partial_out | (uintptr_t)tr->weight) & 15) == 0, "mdie_conv_fwd: tr buffers must be 16-byte aligned");
+    MDIE_REQUIRE((size_t)a.H * a.W * 16 < ((size_t)1 << 32), "mdie_conv_fwd: picture too large for the 32-bit partial offsets");
+    t.tr_w = reinterpret_cast<const char*>(tr->weight); t.tr_c0 = tr->c0;
+    t.tr_scale = tr->pre_scale + tr->c0; t.tr_shift = tr->pre_shift + tr->c0;
+    t.tr_in = tr->partial_in; t.tr_out = tr->partial_out;
+    t.tr_post_scale = tr->post_scale; t.tr_post_shift = tr->post_shift; t.tr_nchw3 = tr->out_nchw3;
+    mode = last ? 2 : 1;
+  } else {
+    MDIE_REQUIRE(a.e.out != nullptr, "mdie_conv_fwd: null output");
+  }
   const int items = a.B * t.tiles_x * t.tiles_y;
 #ifdef EXP_TSTAMPS
   t.dbg = g_thin_dbg;
 #endif
-  if (dtype == MDIE_BF16) return t.ncol <= 4 ? launch_thin_t<bf16, 1>(t, a.e.act, items, stream) : launch_thin_t<bf16, 2>(t, a.e.act, items, stream);
-  return t.ncol <= 4 ? launch_thin_t<f16, 1>(t, a.e.act, items, stream) : launch_thin_t<f16, 2>(t, a.e.act, items, stream);
+  if (dtype == MDIE_BF16) return t.ncol <= 4 ? launch_thin_t<bf16, 1>(t, a.e.act, mode, items, stream) : launch_thin_t<bf16, 2>(t, a.e.act, mode, items, stream);
+  return t.ncol <= 4 ? launch_thin_t<f16, 1>(t, a.e.act, mode, items, stream) : launch_thin_t<f16, 2>(t, a.e.act, mode, items, stream);
 }
 
 }  // namespace mdie

@@ -208,6 +208,7 @@ struct Plan {
   Buf x16, o[3], g[3][4], d[3], e, bott, t1, u1, t2lo, t2, u2, t3lo, t3, u3, t4lo, t4, fg[4], out16;
   size_t cbam_ws, cbam_ws_bytes;
   size_t pool_ws;   // [B][<= 128 slabs][2][128] floats: pooled partials written by upsample+skip
+  size_t tr_ws;     // [B][H][W][4] floats: partial sums of decoder.final_dense's transition (fused chain, forward_impl)
   size_t total;
 };
 
@@ -248,6 +249,7 @@ static Plan make_plan(int dtype, int B, int H, int W) {
     }
     off += align256((size_t)B * floats * sizeof(float));
   }
+  P.tr_ws = off; off += align256((size_t)B * H * W * 4 * sizeof(float));
   P.total = off;
   return P;
 }
@@ -409,7 +411,7 @@ struct Ctx {
 static mdie_seg seg(const Ctx& c, const Buf& b) { return mdie_seg{c.ws + b.off, b.C, b.C}; }
 
 static int run_conv(const Ctx& c, int id, int H, int W, std::initializer_list<Buf> in, const Buf& out, int act, int pool,
-                    const Buf* residual, float* out_nchw3 = nullptr, float* pool_partial = nullptr) {
+                    const Buf* residual, float* out_nchw3 = nullptr, float* pool_partial = nullptr, const mdie_tr_fuse* tr = nullptr) {
   const ConvSpec& s = arch(c.dtype).conv[id];
   mdie_conv_desc d{};
   d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.ksize = s.ks;
@@ -429,6 +431,7 @@ static int run_conv(const Ctx& c, int id, int H, int W, std::initializer_list<Bu
   d.out = c.ws + out.off; d.out_stride = out.C;
   d.out_nchw3 = out_nchw3;
   d.pool_partial = pool_partial;
+  d.tr = tr;
   return mdie_conv_fwd(&d, c.stream);
 }
 
@@ -624,8 +627,21 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   RUN(run_conv(c, CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
   if (!(d->flags & MDIE_FWD_FUSED_TAIL)) {
     // bilinear x2 + x (x read from its fp32 NCHW planes), final_dense, sigmoid written straight to NCHW
-    {   // upsample + x and final_dense layer 0 in one launch (csrc/updense0.hip)
-      const int id0 = CV_DENSE0 + 3 * 5;
+    // upsample + x and final_dense layer 0 in one launch (csrc/updense0.hip); then layers 1..3 and the transition.
+    // 16-bit types on pictures of whole 16x16 tiles: the transition (BN -> ReLU -> Conv1x1 67 -> 3 -> sigmoid) is FOLDED into the
+    // four producers of its input (mdie_tr_fuse, include/mdie.h): each adds the term of the channels it has just computed to
+    // a 16-byte fp32 partial per pixel, the last one applies bias + sigmoid, writes NCHW and never stores its growth map.
+    // The choice depends on the element type and the picture size only, never on the batch: an image's bits do not
+    // depend on what it is batched with.  Everything else (fp32, ragged extents) runs the general chain.
+    const int id0 = CV_DENSE0 + 3 * 5;
+    const bool fold_tr = d->dtype != MDIE_F32 && H % 16 == 0 && W % 16 == 0 && (size_t)W * 20 < ((size_t)1 << 24) && (size_t)H * W * 16 < ((size_t)1 << 32);
+    mdie_tr_fuse tr{};
+    tr.weight = c.params + c.L.conv[id0 + 4].w;
+    tr.pre_scale = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + 4].pre_scale);
+    tr.pre_shift = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + 4].pre_shift);
+    float* const trp = reinterpret_cast<float*>(c.ws + P.tr_ws);
+    tr.partial_in = trp; tr.partial_out = trp;
+    {
       mdie_up_dense0_desc u{};
       u.dtype = d->dtype; u.B = B; u.H = H; u.W = W;
       u.lo = c.ws + P.t4lo.off; u.lo_stride = P.t4lo.C; u.x = d->x;
@@ -635,9 +651,24 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
       u.pre_shift = reinterpret_cast<const float*>(c.params + c.L.conv[id0].pre_shift);
       u.bias = reinterpret_cast<const float*>(c.params + c.L.conv[id0].post_shift);
       u.g0 = c.ws + P.fg[0].off; u.g0_stride = P.fg[0].C;
+      mdie_tr_fuse t0 = tr;
+      t0.c0 = P.t4.C;                                       // g0 follows the base group in the transition's stored input
+      if (fold_tr) u.tr = &t0;
       RUN(mdie_up_add_dense0_fwd(&u, stream));
     }
-    RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID, d->y, true));
+    if (fold_tr) {
+      mdie_tr_fuse t1 = tr, t2 = tr, t3 = tr;
+      t1.c0 = P.t4.C + 16; t2.c0 = P.t4.C + 32; t3.c0 = P.t4.C + 48;
+      t3.partial_out = nullptr;
+      t3.post_scale = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + 4].post_scale);
+      t3.post_shift = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + 4].post_shift);
+      t3.act = MDIE_ACT_SIGMOID; t3.out_nchw3 = d->y;
+      RUN(run_conv(c, id0 + 1, H, W, {P.t4, P.fg[0]}, P.fg[1], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, &t1));
+      RUN(run_conv(c, id0 + 2, H, W, {P.t4, P.fg[0], P.fg[1]}, P.fg[2], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, &t2));
+      RUN(run_conv(c, id0 + 3, H, W, {P.t4, P.fg[0], P.fg[1], P.fg[2]}, P.fg[3], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, &t3));
+    } else {
+      RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID, d->y, true));
+    }
   } else {
     mdie_tail_desc t{};
     t.dtype = d->dtype; t.B = B; t.H = H; t.W = W;

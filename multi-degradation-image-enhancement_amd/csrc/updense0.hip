@@ -33,6 +33,10 @@ struct UpDense0Args {
   const float *pre_scale, *pre_shift;   // folded BatchNorm of dense layer 0, >= 3 entries
   const float* bias;              // [16]
   char* g0; int g0_stride;        // out: NHWC, 16 channels
+  // TR: the block's transition folded into its producers (mdie_tr_fuse; the scheme is described in conv_thin.hip)
+  const char* tr_w; int tr_c0;    // the transition's packed 1x1 weights; its stored input channel of g0's channel 0 (base sits at 0..2)
+  const float *tr_scale, *tr_shift;   // the transition's folded BatchNorm, by its stored input channel
+  float* tr_out;                  // [pixel][4] fp32: the partial sums (base term + g0 term)
 };
 
 __device__ __forceinline__ void ud_src(int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {   // = resample.hip src_index
@@ -59,14 +63,16 @@ template <> __device__ __forceinline__ f32x4 ud_mma<float>(const uint4& w, const
   return acc;
 }
 
-template <typename T, int BASE_CH>
+template <typename T, int BASE_CH, bool TR = false>
 __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0Args a) {
+  static_assert(!TR || sizeof(T) == 2, "the transition fusion is built for the 16-bit storage types");
   constexpr int E = sizeof(T);
   constexpr int VEC = Traits<T>::VEC;
   constexpr int STEPS = 2;   // (as conv_first_kernel: fp32 2 x 16 of k = tap*3 + c; 16-bit k' = tap*4 + c, taps 0..7 | tap 8)
   constexpr int NPS = 4;
   constexpr int PW = UD_PW;
   __shared__ __attribute__((aligned(16))) T patch[PW * PW * 4];
+  __shared__ __attribute__((aligned(16))) T trpatch[TR ? UD_TILE * UD_TILE * 4 : 4];   // TR: relu(bn_tr(base)) of the tile's own pixels, [pixel][4]
 
   const int tid = threadIdx.x, lane = tid & 63, lq = lane >> 4, lp = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,6 +90,27 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
   const float4 bias = *reinterpret_cast<const float4*>(a.bias + lq * 4);
   const float ps0 = a.pre_scale[0], ps1 = a.pre_scale[1], ps2 = a.pre_scale[2];
   const float pb0 = a.pre_shift[0], pb1 = a.pre_shift[1], pb2 = a.pre_shift[2];
+  // transition term (TR): A fragments of the four row subtiles -- row lp = output lp - 4 ps; K group lq: elements 0..3 = g0's
+  // channels 4 lq .. 4 lq + 3, elements 4..7 = the base channels 0..3 in K group 0 (zeros elsewhere) -- and the constants
+  uint4 tra[NPS];
+  f32x2 trs[2], trb[2];
+  float tbs[3] = {0.f, 0.f, 0.f}, tbb[3] = {0.f, 0.f, 0.f};
+  if constexpr (TR) {
+    const int c = a.tr_c0 + 4 * lq;
+    const char* const wrow = a.tr_w + ((size_t)(c >> 5) * 4 + ((c & 31) >> 3)) * (16 * 16) + (c & 7) * 2;
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int o = lp - 4 * ps;
+      const uint2 wg = *reinterpret_cast<const uint2*>(wrow + (unsigned)(o & 15) * 16);
+      const uint2 wb = *reinterpret_cast<const uint2*>(a.tr_w + (unsigned)(o & 15) * 16);        // stored channels 0..3: chunk 0, K group 0
+      const bool live = o >= 0 && o < 4;
+      tra[ps] = make_uint4(live ? wg.x : 0u, live ? wg.y : 0u, live && lq == 0 ? wb.x : 0u, live && lq == 0 ? wb.y : 0u);
+    }
+    const float4 s4 = *reinterpret_cast<const float4*>(a.tr_scale + a.tr_c0 + 4 * lq), b4 = *reinterpret_cast<const float4*>(a.tr_shift + a.tr_c0 + 4 * lq);
+    trs[0] = f32x2{s4.x, s4.y}; trs[1] = f32x2{s4.z, s4.w}; trb[0] = f32x2{b4.x, b4.y}; trb[1] = f32x2{b4.z, b4.w};
+#pragma unroll
+    for (int c3 = 0; c3 < 3; ++c3) { tbs[c3] = a.tr_scale[c3]; tbb[c3] = a.tr_shift[c3]; }
+  }
 
   // ---- the tile's base patch: every load of both iterations is issued before the first use ----
   const int Hl = a.H >> 1, Wl = a.W >> 1;
@@ -152,6 +179,10 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
         uint4* dst = reinterpret_cast<uint4*>(a.base + (size_t)img * plane * (BASE_CH * E) + (__umul24(y0 + py - 1, a.W) + (x0 + px - 1)) * (unsigned)(BASE_CH * E));
 #pragma unroll
         for (int v = 0; v < BASE_CH / VEC; ++v) dst[v] = Vec16<T>::pack(o + v * VEC);
+        if constexpr (TR) {   // the transition's pre-activation of the stored base (f[] is already rounded to T)
+          const float t0 = fmaxf(fmaf(f[0], tbs[0], tbb[0]), 0.f), t1 = fmaxf(fmaf(f[1], tbs[1], tbb[1]), 0.f), t2 = fmaxf(fmaf(f[2], tbs[2], tbb[2]), 0.f);
+          *reinterpret_cast<uint2*>(trpatch + ((py - 1) * UD_TILE + (px - 1)) * 4) = make_uint2(Half<T>::pack(t0, t1), Half<T>::pack(t2, 0.f));
+        }
       }
     }
   }
@@ -174,6 +205,7 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
         goff[s][i] = tap < 9 ? ((tap / 3) * PW + (tap % 3)) * 4 + c : 3;   // k >= 27: the zero channel of the pixel
       }
   }
+  f32x4 tacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ps = 0; ps < NPS; ++ps) {
     const int blk = (wave * NPS + ps) * 4 + (lp >> 2);
@@ -201,6 +233,22 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
       if constexpr (E == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(Half<T>::pack(v0, v1), Half<T>::pack(v2, v3));
       else *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
     }
+    if constexpr (TR) {   // the transition's term of this pixel's g0 channels (from the STORED values) and of its base channels
+      const uint32_t u0 = Half<T>::pack(acc[0] + bias.x, acc[1] + bias.y), u1 = Half<T>::pack(acc[2] + bias.z, acc[3] + bias.w);
+      const f32x2 r0 = __builtin_elementwise_fma(f32x2{Half<T>::lo(u0), Half<T>::hi(u0)}, trs[0], trb[0]);
+      const f32x2 r1 = __builtin_elementwise_fma(f32x2{Half<T>::lo(u1), Half<T>::hi(u1)}, trs[1], trb[1]);
+      const uint32_t t0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(half_bits<T>(r0), i16x2{0, 0}));
+      const uint32_t t1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(half_bits<T>(r1), i16x2{0, 0}));
+      const uint2 tb = *reinterpret_cast<const uint2*>(trpatch + (y * UD_TILE + x) * 4);
+      tacc = ud_mma<T>(tra[ps], make_uint4(t0, t1, tb.x, tb.y), tacc);
+    }
+  }
+  if constexpr (TR) {   // lane (lq, lp): the 3 partial outputs of pixel lp of row subtile lq
+    const int blk = (wave * NPS + lq) * 4 + (lp >> 2);
+    const int y = 2 * (blk / (UD_TILE / 2)) + ((lp >> 1) & 1), x = 2 * (blk % (UD_TILE / 2)) + (lp & 1);
+    const int gy = y0 + y, gx = x0 + x;
+    if (gy < a.H && gx < a.W)
+      *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.tr_out + (size_t)img * plane * 4) + (__umul24(gy, a.W) + gx) * 16u) = make_float4(tacc[0], tacc[1], tacc[2], 0.f);
   }
 }
 
@@ -230,9 +278,21 @@ extern "C" int mdie_up_add_dense0_fwd(const mdie_up_dense0_desc* d, void* stream
   a.weight = reinterpret_cast<const char*>(d->weight);
   a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift; a.bias = d->bias;
   a.g0 = reinterpret_cast<char*>(d->g0); a.g0_stride = d->g0_stride;
+  if (d->tr) {
+    MDIE_REQUIRE(d->dtype != MDIE_F32 && d->base_channels == vec, "mdie_up_add_dense0_fwd: tr needs a 16-bit type with the base stored as one 16-byte group");
+    MDIE_REQUIRE(d->tr->weight && d->tr->pre_scale && d->tr->pre_shift && d->tr->partial_out && d->tr->c0 >= vec && d->tr->c0 % 8 == 0 && !d->tr->out_nchw3,
+                 "mdie_up_add_dense0_fwd: tr needs weight, pre_scale / pre_shift, partial_out and c0 (a multiple of 8 behind the base group); it is never the last producer");
+    MDIE_REQUIRE((((uintptr_t)d->tr->partial_out | (uintptr_t)d->tr->weight) & 15) == 0 && (size_t)d->H * d->W * 16 < ((size_t)1 << 32), "mdie_up_add_dense0_fwd: tr alignment / extent");
+    a.tr_w = reinterpret_cast<const char*>(d->tr->weight); a.tr_c0 = d->tr->c0;
+    a.tr_scale = d->tr->pre_scale; a.tr_shift = d->tr->pre_shift; a.tr_out = d->tr->partial_out;
+  }
   const int grid = cdiv(d->W, UD_TILE) * cdiv(d->H, UD_TILE) * d->B;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   TimedLaunch tl(MDIE_K_CONV3);
+  if (d->tr) {
+    if (d->dtype == MDIE_BF16) hipLaunchKernelGGL((up_dense0_kernel<bf16, 8, true>), dim3(grid), dim3(UD_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((up_dense0_kernel<f16, 8, true>), dim3(grid), dim3(UD_THREADS), 0, s, a);
+  } else
   MDIE_SWITCH_T(d->dtype,
     if (d->base_channels == 16) hipLaunchKernelGGL((up_dense0_kernel<T, 16>), dim3(grid), dim3(UD_THREADS), 0, s, a);
     else hipLaunchKernelGGL((up_dense0_kernel<T, Traits<T>::VEC>), dim3(grid), dim3(UD_THREADS), 0, s, a));

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 16
+ABI_VERSION = 17
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 FWD_SERIAL = 2
@@ -30,13 +30,20 @@ class Seg(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("channels", C.c_int), ("stride", C.c_int)]
 
 
+class TrFuse(C.Structure):
+    """mdie_tr_fuse: a DenseBlock transition folded into the producers of its input (include/mdie.h)"""
+    _fields_ = [("weight", C.c_void_p), ("c0", C.c_int), ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p),
+                ("partial_in", C.c_void_p), ("partial_out", C.c_void_p), ("post_scale", C.c_void_p), ("post_shift", C.c_void_p),
+                ("act", C.c_int), ("out_nchw3", C.c_void_p)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("ksize", C.c_int),
                 ("nseg", C.c_int), ("inp", Seg * MAX_SEG), ("cin", C.c_int), ("cout", C.c_int),
                 ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("weight", C.c_void_p),
                 ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int), ("pool", C.c_int),
                 ("residual", C.c_void_p), ("res_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int),
-                ("out_nchw3", C.c_void_p), ("pool_partial", C.c_void_p)]
+                ("out_nchw3", C.c_void_p), ("pool_partial", C.c_void_p), ("tr", C.POINTER(TrFuse))]
 
 
 class WgradDesc(C.Structure):
@@ -101,7 +108,8 @@ class ConvFirstDesc(C.Structure):
 class UpDense0Desc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("lo", C.c_void_p), ("lo_stride", C.c_int),
                 ("x", C.c_void_p), ("base", C.c_void_p), ("base_channels", C.c_int), ("weight", C.c_void_p),
-                ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("bias", C.c_void_p), ("g0", C.c_void_p), ("g0_stride", C.c_int)]
+                ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("bias", C.c_void_p), ("g0", C.c_void_p), ("g0_stride", C.c_int),
+                ("tr", C.POINTER(TrFuse))]
 
 
 class CbamDesc(C.Structure):
