@@ -366,7 +366,9 @@ typedef struct {
 } mdie_cdan_fwd_desc;
 
 enum { MDIE_FWD_FUSED_TAIL = 1 /* run upsample + final_dense + sigmoid as ONE launch (mdie_tail_fwd) instead of 7 */,
-       MDIE_FWD_SERIAL = 2     /* keep the encoder DenseBlocks in line with the main chain (no side streams, no graph branches) */ };
+       MDIE_FWD_SERIAL = 2     /* keep the encoder DenseBlocks in line with the main chain (no side streams, no graph branches) */,
+       MDIE_FWD_GENERAL_TAIL = 4 /* decoder.final_dense as the general chain (3x3 layers, then the 1x1 launch) also where the transition
+                                    could be folded into its producers (mdie_tr_fuse): the form fp32 and ragged extents always take */ };
 
 enum { MDIE_K_LAYOUT = 0, MDIE_K_CONV3 = 1, MDIE_K_CONV1 = 2, MDIE_K_CBAM_POOL = 3, MDIE_K_CBAM_GATE = 4,
        MDIE_K_CBAM_CHANPOOL = 5, MDIE_K_CBAM_SPATIAL = 6, MDIE_K_UPSAMPLE = 7, MDIE_K_TAIL = 8, MDIE_K_COUNT = 9 };

@@ -634,7 +634,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     // The choice depends on the element type and the picture size only, never on the batch: an image's bits do not
     // depend on what it is batched with.  Everything else (fp32, ragged extents) runs the general chain.
     const int id0 = CV_DENSE0 + 3 * 5;
-    const bool fold_tr = d->dtype != MDIE_F32 && H % 16 == 0 && W % 16 == 0 && (size_t)W * 20 < ((size_t)1 << 24) && (size_t)H * W * 16 < ((size_t)1 << 32);
+    const bool fold_tr = !(d->flags & MDIE_FWD_GENERAL_TAIL) && d->dtype != MDIE_F32 && H % 16 == 0 && W % 16 == 0 && (size_t)W * 20 < ((size_t)1 << 24) && (size_t)H * W * 16 < ((size_t)1 << 32);
     mdie_tr_fuse tr{};
     tr.weight = c.params + c.L.conv[id0 + 4].w;
     tr.pre_scale = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + 4].pre_scale);

@@ -90,24 +90,12 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
   const float4 bias = *reinterpret_cast<const float4*>(a.bias + lq * 4);
   const float ps0 = a.pre_scale[0], ps1 = a.pre_scale[1], ps2 = a.pre_scale[2];
   const float pb0 = a.pre_shift[0], pb1 = a.pre_shift[1], pb2 = a.pre_shift[2];
-  // transition term (TR): A fragments of the four row subtiles -- row lp = output lp - 4 ps; K group lq: elements 0..3 = g0's
-  // channels 4 lq .. 4 lq + 3, elements 4..7 = the base channels 0..3 in K group 0 (zeros elsewhere) -- and the constants
-  uint4 tra[NPS];
+  // transition term (TR): the A fragment of row subtile ps has output o in row 4 ps + o (zeros elsewhere); K group lq: elements
+  // 0..3 = g0's channels 4 lq .. 4 lq + 3, elements 4..7 = the base channels 0..3 in K group 0 (zeros elsewhere) -- and the constants
+  uint4 tra = make_uint4(0u, 0u, 0u, 0u);   // the lane's row o = lp & 3 of the transition's weights; subtile ps uses it on the lanes with lp >> 2 == ps
   f32x2 trs[2], trb[2];
   float tbs[3] = {0.f, 0.f, 0.f}, tbb[3] = {0.f, 0.f, 0.f};
   if constexpr (TR) {
-    const int c = a.tr_c0 + 4 * lq;
-    const char* const wrow = a.tr_w + ((size_t)(c >> 5) * 4 + ((c & 31) >> 3)) * (16 * 16) + (c & 7) * 2;
-#pragma unroll
-    for (int ps = 0; ps < NPS; ++ps) {
-      const int o = lp - 4 * ps;
-      const uint2 wg = *reinterpret_cast<const uint2*>(wrow + (unsigned)(o & 15) * 16);
-      const uint2 wb = *reinterpret_cast<const uint2*>(a.tr_w + (unsigned)(o & 15) * 16);        // stored channels 0..3: chunk 0, K group 0
-      const bool live = o >= 0 && o < 4;
-      tra[ps] = make_uint4(live ? wg.x : 0u, live ? wg.y : 0u, live && lq == 0 ? wb.x : 0u, live && lq == 0 ? wb.y : 0u);
-    }
-    const float4 s4 = *reinterpret_cast<const float4*>(a.tr_scale + a.tr_c0 + 4 * lq), b4 = *reinterpret_cast<const float4*>(a.tr_shift + a.tr_c0 + 4 * lq);
-    trs[0] = f32x2{s4.x, s4.y}; trs[1] = f32x2{s4.z, s4.w}; trb[0] = f32x2{b4.x, b4.y}; trb[1] = f32x2{b4.z, b4.w};
 #pragma unroll
     for (int c3 = 0; c3 < 3; ++c3) { tbs[c3] = a.tr_scale[c3]; tbb[c3] = a.tr_shift[c3]; }
   }
@@ -186,6 +174,17 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
       }
     }
   }
+  if constexpr (TR) {   // (loaded here, not at the top: not live across the staging arithmetic, whose registers set the occupancy)
+    const int c = a.tr_c0 + 4 * lq;
+    const char* const wrow = a.tr_w + ((size_t)(c >> 5) * 4 + ((c & 31) >> 3)) * (16 * 16) + (c & 7) * 2;
+    {
+      const uint2 wg = *reinterpret_cast<const uint2*>(wrow + (unsigned)(lp & 3) * 16);
+      const uint2 wb = *reinterpret_cast<const uint2*>(a.tr_w + (unsigned)(lp & 3) * 16);        // stored channels 0..3: chunk 0, K group 0
+      tra = make_uint4(wg.x, wg.y, lq == 0 ? wb.x : 0u, lq == 0 ? wb.y : 0u);
+    }
+    const float4 s4 = *reinterpret_cast<const float4*>(a.tr_scale + a.tr_c0 + 4 * lq), b4 = *reinterpret_cast<const float4*>(a.tr_shift + a.tr_c0 + 4 * lq);
+    trs[0] = f32x2{s4.x, s4.y}; trs[1] = f32x2{s4.z, s4.w}; trb[0] = f32x2{b4.x, b4.y}; trb[1] = f32x2{b4.z, b4.w};
+  }
   __syncthreads();
 
   // ---- im2col gather (k = tap*3 + c) and one MFMA step per 16 pixels ----
@@ -240,7 +239,8 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
       const uint32_t t0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(half_bits<T>(r0), i16x2{0, 0}));
       const uint32_t t1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(half_bits<T>(r1), i16x2{0, 0}));
       const uint2 tb = *reinterpret_cast<const uint2*>(trpatch + (y * UD_TILE + x) * 4);
-      tacc = ud_mma<T>(tra[ps], make_uint4(t0, t1, tb.x, tb.y), tacc);
+      const bool mine = (lp >> 2) == ps;       // (one register set for the four A operands: 92 -> 80 VGPRs, 5 -> 6 waves per SIMD)
+      tacc = ud_mma<T>(make_uint4(mine ? tra.x : 0u, mine ? tra.y : 0u, mine ? tra.z : 0u, mine ? tra.w : 0u), make_uint4(t0, t1, tb.x, tb.y), tacc);
     }
   }
   if constexpr (TR) {   // lane (lq, lp): the 3 partial outputs of pixel lp of row subtile lq
