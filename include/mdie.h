@@ -122,7 +122,7 @@ typedef struct {
 
 int mdie_conv_fwd(const mdie_conv_desc* d, void* stream);
 /* tile edge (8 or 16) mdie_conv_fwd picks for this shape: pool_partial has ceil(H/t) * ceil(W/t) slabs per image */
-int mdie_conv_tile(int B, int H, int W, int cout);
+int mdie_conv_tile(int B, int H, int W, int cout);   /* (a function of H and W alone since ABI 17: an image's pooled sums must not depend on its batch) */
 
 /* Host-side packing of one convolution weight (fp32, PyTorch layout) into the layout
  * mdie_conv_fwd reads: [cin_chunk][q][tap][cout_pad][16 bytes], where a chunk is 64 bytes of

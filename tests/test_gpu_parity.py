@@ -198,6 +198,31 @@ def test_full_batch_properties(E, net, precision):
     assert torch.isfinite(y).all() and y.min() > 0 and y.max() < 1
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_every_image_is_independent_of_its_batch_at_every_stage(E, precision):
+    """Bitwise batch independence, all of it: the batch of 32 at 256x256 (16 for fp32) cut into sub-batches of 8, 4 and 1
+    at EVERY position -- each sub-batch through an engine of its own -- must reproduce its images of the whole batch bit for bit
+    in the output and in every stage tap.  (Round 3 found images 16 and 28 of this very batch one bf16 ulp apart, in ONE
+    element of the bottleneck CBAM's output, between a batch of 32 and a batch of 8: the tile edge of the pooling partials
+    the convolution in front of that CBAM emits followed the batch size, so the pooled average was summed in another
+    grouping -- mdie_conv_tile is a function of the map alone since.  Checking three images of one batch had missed it.)"""
+    from mdie_amd import engine as EG
+    from oracle import params as P
+    dev = torch.device("cuda", 0)
+    sd = P.make_state_dict(42)
+    B = 16 if precision == "fp32" else 32
+    x = P.lowlight_batch(1, B, 256, 256)[0].to(dev)
+    with torch.no_grad():
+        whole = EG.CdanEngine(dev, precision).load(sd)
+        yw, exw = whole.forward(x, want_taps=True)
+        for nb in (8, 4, 1):
+            eng = EG.CdanEngine(dev, precision).load(sd)
+            for i0 in (range(0, B, nb) if nb > 1 else [i for i in (0, 5, 16, 28, B - 1) if i < B]):
+                y, ex = eng.forward(x[i0:i0 + nb].contiguous(), want_taps=True)
+                bad = [n for n in ex["taps"] if not torch.equal(ex["taps"][n], exw["taps"][n][i0:i0 + nb])]
+                assert not bad and torch.equal(y, yw[i0:i0 + nb]), f"images {i0}..{i0 + nb - 1} alone differ from the batch at {bad or 'the output'}"
+
+
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(32, 256, 256), (1, 256, 256), (3, 48, 80)])
 def test_folded_tail_equals_general_chain_in_the_network(E, net, precision, shape):

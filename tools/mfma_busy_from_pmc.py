@@ -45,3 +45,27 @@ for (name, grid), ds in agg.items():
     us = m.get("us", 0.0)
     nominal = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * us * 2400.0) if us else 0.0
     print(f"{name:46s} {grid:9d} {len(ds):4d} {us:8.1f} {busy:9.3f} {nominal:9.3f} {sq:8.3f}", file=out)
+
+
+# ---- the six wide 3x3 layers one by one (north star: MFMA-busy of the MFMA-bound convolutions, per layer) -------------------------------
+# conv_wide_kernel launches all sit on the forward's main stream, so their dispatch order within a step is the network's:
+# encoder.conv2, conv3, conv4, decoder.conv1, conv2, conv3 (models/cdan.py:59-61,103-111) -- the k-th of them (mod 6) is layer k.
+LAYERS = [("enc.conv2+pool", 64, 128, 128), ("enc.conv3+pool", 128, 256, 64), ("enc.conv4", 256, 512, 32), ("dec.conv1", 512, 256, 32),
+          ("dec.conv2", 256, 128, 32), ("dec.conv3", 128, 64, 64)]          # name, cin, cout, map edge at 256x256 input
+wide = [rows[k] for k in sorted(rows) if "conv_wide_kernel" in rows[k].get("name", "") and "SQ_VALU_MFMA_BUSY_CYCLES" in rows[k] and "GRBM_GUI_ACTIVE" in rows[k]]
+if wide and len(wide) % 6 == 0:
+    B = int(os.environ.get("BATCH", 32))
+    print("\n# the six wide 3x3 layers, median over the profiled steps (B = %d, 256x256; PMC passes serialise the launches: times are the" % B, file=out)
+    print("# kernel alone).  TFLOP/s = 2 * 9 * cin * cout * pixels * B / time; frac = TFLOP/s / 2500 (dense bf16 MFMA peak)", file=out)
+    print(f"{'layer':16s} {'n':>3s} {'us':>8s} {'mfma_busy':>9s} {'vs_2.4GHz':>9s} {'sq_busy':>8s} {'TFLOP/s':>8s} {'frac':>6s}", file=out)
+    for i, (name, cin, cout, edge) in enumerate(LAYERS):
+        ds = sorted(wide[i::6], key=lambda d: d.get("us", 0.0))
+        m = ds[len(ds) // 2]
+        cyc, us = m["GRBM_GUI_ACTIVE"] / 8.0, m.get("us", 0.0)
+        busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc) if cyc else 0.0
+        nominal = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * us * 2400.0) if us else 0.0
+        sq = m.get("SQ_BUSY_CYCLES", 0.0) / (32.0 * cyc) if cyc else 0.0
+        tf = 2.0 * 9 * cin * cout * edge * edge * B / (us * 1e-6) / 1e12 if us else 0.0
+        print(f"{name:16s} {len(ds):3d} {us:8.1f} {busy:9.3f} {nominal:9.3f} {sq:8.3f} {tf:8.0f} {tf / 2500.0:6.3f}", file=out)
+elif wide:
+    print(f"\n# {len(wide)} conv_wide dispatches: not a multiple of 6, per-layer table skipped", file=out)
