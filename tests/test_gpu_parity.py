@@ -960,6 +960,55 @@ def test_thin_persistent_conv_kernel(E, L, prec, cin_segs, act):
     assert torch.equal(two, out[:2]), "the two convolution kernels must agree bit for bit"
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cin_segs,hw", [([256], (32, 32)), ([256, 16, 16, 16], (32, 32)), ([128, 16], (24, 40)), ([256, 16], (8, 8))])
+def test_small_map_deep_k_conv_tile8_equals_tile16(E, L, prec, cin_segs, hw):
+    """The DenseLayers on small, deep maps (encoder.dense3 / dense2 at small batches, models/cdan.py:64-65: 16 outputs from
+    128-304 channels) run conv_kernel with 8x8 tiles; inside a batch large enough to fill the chip they run 16x16 tiles.  Both
+    against torch's CPU convolution of the same rounded operands (ragged tiles, several segments, K not a multiple of the
+    chunk) and against each other BIT FOR BIT -- the kernel choice follows the batch, an image's bits must not."""
+    import ctypes as C
+    import torch.nn.functional as F
+    dt, td = E.dtype_id(prec), TORCH_DT[prec]
+    rnd = lambda t: t.to(td).float()
+    H, W = hw
+    cin, cout = sum(cin_segs), 16
+    tiles16 = -(-H // 16) * -(-W // 16)
+    Bbig = -(-512 // tiles16)                  # >= 512 workgroups of 16x16 tiles: the TILE = 16 kernel
+    Bsmall = 3
+    assert Bsmall * tiles16 < 512 and cin >= 128
+    g = torch.Generator().manual_seed(cin + H)
+    bufs = [rnd(torch.randn(Bbig, H, W, c, generator=g)) for c in cin_segs]
+    w = rnd(torch.randn(cout, cin, 3, 3, generator=g) * 0.05)
+    sh = torch.randn(cout, generator=g) * 0.1
+    ps, pt = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    x = torch.cat([b[:Bsmall] for b in bufs], 3)
+    ref = (F.conv2d(rnd(torch.relu(x * ps + pt)).permute(0, 3, 1, 2), w, padding=1) + sh.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    dbufs = [b.cuda().to(td) for b in bufs]
+    wp = E.pack_conv_weight(w, dt, cin_stored=cin).cuda()
+    dsc, dsh, dps, dpt = torch.ones(cout).cuda(), sh.cuda(), ps.cuda(), pt.cuda()
+
+    def run(nb):
+        out = torch.full((nb, H, W, 16), -7.0, device="cuda", dtype=td)
+        d = L.ConvDesc()
+        d.dtype, d.B, d.H, d.W, d.ksize, d.nseg = dt, nb, H, W, 3, len(dbufs)
+        for i, (b, c) in enumerate(zip(dbufs, cin_segs)):
+            d.inp[i] = L.Seg(b.data_ptr(), c, c)
+        d.cin, d.cout = cin, cout
+        d.pre_scale, d.pre_shift = dps.data_ptr(), dpt.data_ptr()
+        d.weight, d.post_scale, d.post_shift = wp.data_ptr(), dsc.data_ptr(), dsh.data_ptr()
+        d.act, d.pool = L.ACT_NONE, 0
+        d.out, d.out_stride = out.data_ptr(), 16
+        L.check(L.lib.mdie_conv_fwd(C.byref(d), None), "mdie_conv_fwd")
+        torch.cuda.synchronize()
+        return out
+
+    small = run(Bsmall)
+    assert rel_to_max(small, ref) <= {"bf16": 8e-3, "fp16": 1e-3}[prec]
+    big = run(Bbig)
+    assert torch.equal(big[:Bsmall], small), "the 8x8-tile kernel must agree with the 16x16-tile kernel bit for bit"
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # training mode (SURVEY.md 8a rows a5, a13, a14): HIP convolutions (forward / dgrad / wgrad) under autograd
 # ---------------------------------------------------------------------------------------------------------------------
