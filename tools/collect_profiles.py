@@ -24,11 +24,16 @@ cp("layers_bf16.txt", "layers_bf16.txt")
 cp("layers_fp16.txt", "layers_fp16.txt")
 cp("mfma_busy.txt", "mfma_busy_bf16_b32.txt")
 cp("conv_microbench.txt", "conv_microbench_bf16_b32.txt")
+cp("achievable_bandwidth_hip.txt", "achievable_bandwidth_hip.txt")
+cp("tail_fold_ab_bf16.txt", "tail_fold_ab_bf16.txt")
+cp("tail_fold_ab_fp16.txt", "tail_fold_ab_fp16.txt")
+cp("layers_bf16_general_tail.txt", "layers_bf16_general_tail.txt")
+cp("batch_independence_probe.txt", "batch_independence_probe.txt")
 with open(os.path.join(dst, f"{pre}_configs.txt"), "w") as f:
     f.write("# BASELINE configs[2] (training step shape), [3] (routed, 9 weight sets) and [4] (1024x1024, its stated dtype fp16), plus the\n"
             "# PCIe-inclusive and batches-in-flight serving rates: output lines of tools/bench_train.py, bench_configs.py, bench_e2e.py,\n"
             "# bench_inflight.py on one MI355X (tools/measure_all.sh)\n")
-    for name in ("configs_large_fp16", "configs_large_bf16", "configs_routed_bf16", "train_bf16_b8_512", "train_bf16_b8_256", "train_fp16_b8_512",
+    for name in ("configs_large_fp16", "configs_large_bf16", "configs_routed_bf16", "train_bf16_b8_512", "train_bf16_b8_256", "train_fp16_b8_512", "train_fp16_b8_256",
                  "e2e_bf16", "inflight_bf16"):
         p = os.path.join(src, name + ".txt")
         if os.path.exists(p):

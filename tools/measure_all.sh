@@ -22,9 +22,14 @@ run configs_routed_bf16 python tools/bench_configs.py routed bf16
 run train_bf16_b8_512 python tools/bench_train.py bf16 8 512
 run train_bf16_b8_256 python tools/bench_train.py bf16 8 256
 run train_fp16_b8_512 python tools/bench_train.py fp16 8 512
+run train_fp16_b8_256 python tools/bench_train.py fp16 8 256
 run e2e_bf16 python tools/bench_e2e.py bf16
 run inflight_bf16 python tools/bench_inflight.py 1 2 3
 mkdir -p build && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/bandwidth.hip -o build/bandwidth && run achievable_bandwidth_hip build/bandwidth
+run tail_fold_ab_bf16 python tools/bench_tail_ab.py bf16
+run tail_fold_ab_fp16 python tools/bench_tail_ab.py fp16
+run layers_bf16_general_tail env GENERAL_TAIL=1 python tools/profile_layers.py bf16
+run batch_independence_probe python tools/probe_concurrent.py bf16 4 5
 run conv_microbench python tools/bench_conv.py bf16 conv2 conv3 conv4 dec1 dec2 dec3 first d1l0 d1l3 fl3 ftr
 
 cd /tmp && export TMPDIR=/tmp
