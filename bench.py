@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="enqueue launches eagerly instead of replaying a hipGraph (= --launch eager)")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
-                    help="how a step is enqueued: one hipGraph replay, 41 eager launches from one host call, or (auto) whichever "
+                    help="how a step is enqueued: one hipGraph replay, the ~40 eager launches of one host call, or (auto) whichever "
                          "of the two ran the untimed warmup steps faster on this box")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-batch", type=int, default=32, help="images of the GPU batch the CPU baseline runs (SURVEY.md 8d: the whole batch)")
@@ -207,7 +207,7 @@ def main():
                 step()
         run = graph.replay if graph is not None else step
         if args.launch == "auto":
-            # Both forms enqueue the same 41 launches; which one keeps the GPU busier depends on the box (graph replay pays a
+            # Both forms enqueue the same launches; which one keeps the GPU busier depends on the box (graph replay pays a
             # few tens of us of inter-node latency per step, eager launching needs a host that stays ahead of the GPU).
             # The warmup steps are run in each form and the faster one is timed.
             def time_form(fn):
@@ -302,7 +302,7 @@ def main():
            "config": {"workload": f"config/low_light.json CDAN forward (eval), {S}x{S}, batch {B}/GPU, {args.precision} storage + fp32 accumulate, "
                                   f"seeded random-init weights, synthetic low-light images resident in HBM",
                       "global_batch": B * world, "parallelism": f"batch-parallel x{world}, no collective",
-                      "launch": ("eager (one host call, 41 launches)" if graph is None else "hipGraph replay") + (", chosen in warmup" if args.launch == "auto" else "")},
+                      "launch": (f"eager (one host call, {sum(v[0] for v in prof.values())} launches)" if graph is None else "hipGraph replay") + (", chosen in warmup" if args.launch == "auto" else "")},
            "roofline": roofline}
 
     if not args.no_extra and world == 1:
