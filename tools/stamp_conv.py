@@ -12,6 +12,8 @@ SHAPES = {
     "d1l3": ([64, 16, 16, 16], 16, 128, 3, False, True), "fl3": ([16, 16, 16, 16], 16, 256, 3, False, True),
     "ftr": ([16, 16, 16, 16, 16], 16, 256, 1, False, True),
     "fl0": ([8], 16, 256, 3, False, True), "fl1": ([8, 16], 16, 256, 3, False, True),
+    "d1l0": ([64], 16, 128, 3, False, True), "d2l0": ([128], 16, 64, 3, False, True), "d2l3": ([128, 16, 16, 16], 16, 64, 3, False, True),
+    "d3l0": ([256], 16, 32, 3, False, True), "d3l3": ([256, 16, 16, 16], 16, 32, 3, False, True),
 }
 dt = L.BF16
 td = torch.bfloat16
