@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 17
+#define MDIE_ABI_VERSION 18
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1,
        MDIE_F16 = 2 /* IEEE half: the reference's mixed-precision dtype (torch.cuda.amp.autocast, models/model.py:15,159) */ };
@@ -118,6 +118,10 @@ typedef struct {
                               mdie_conv_tile(B,H,W,cout) in raster order -- the global pools of the CBAM that consumes
                               it (models/cbam.py:41,44; mdie_cbam_desc.pool_partial) fused into their producer */
   const mdie_tr_fuse* tr;  /* optional: fold the consuming transition into this layer (above); `out` may be NULL for the last producer */
+  long out_group_stride;   /* 0 or 16: channel n of pixel p at out[p * out_stride + n] (NHWC).  Otherwise ONE PLANE PER 16 CHANNELS: channel n at
+                              out[(n / 16) * out_group_stride + p * out_stride + n % 16] (out_stride >= 16; plain epilogue only: no activation,
+                              pooling, residual) -- the layout mdie_bn_bwd_reduce / mdie_bn_bwd_apply_multi take `da` in (da_plane), so that
+                              one feature segment of several layers' input gradients is a set of dense streams */
 } mdie_conv_desc;
 
 int mdie_conv_fwd(const mdie_conv_desc* d, void* stream);
@@ -485,9 +489,32 @@ typedef struct {
   float* dgamma; float* dbeta;
   float* coef;                            /* [2][C] */
   void* workspace; size_t workspace_bytes;
+  int coef_stride;                        /* apply: floats between coef's two rows; 0 = C (a descriptor that covers only the trailing
+                                             segments of the tensor mdie_bn_bwd_reduce ran over passes its pointers advanced and this stride) */
+  long da_plane;                          /* 0: da is [N][da_stride] rows.  Otherwise da is stored one plane per 16 channels (mdie_conv_desc.
+                                             out_group_stride): channel c of pixel p at da[(c / 16) * da_plane + p * da_stride + c % 16] */
 } mdie_bn_bwd_desc;
 int mdie_bn_bwd_reduce(const mdie_bn_bwd_desc* d, void* stream);
 int mdie_bn_bwd_apply(const mdie_bn_bwd_desc* d, void* stream);
+/* The same backward for a tensor that SEVERAL BatchNorm layers normalise -- the input of a DenseBlock, which each of its four
+ * layers and its transition see through cat(features) (models/cdan.py:35,38) -- in ONE pass:
+ *     g = sum_j scale_j * (da_j * [x * scale_j + shift_j > 0] - coef_j[0] - xhat * coef_j[1])      (written, rounded once)
+ * over channels [0, C) of x; da_j is the gradient w.r.t. layer j's activated input, whose row begins with these C channels;
+ * scale_j / shift_j / coef_j are that layer's folded constants and mdie_bn_bwd_reduce's output, indexed from the tensor's
+ * channel 0 (coef_j: [2][coef_stride_j]); mean / invstd are the tensor's batch statistics.  Replaces nlayer read-modify-write
+ * passes of mdie_bn_bwd_apply over the tensor (4 * nlayer passes over its channels) by nlayer + 2. */
+typedef struct {
+  int dtype; long N; int C;
+  const void* x; int x_stride;
+  void* g; int g_stride;
+  const float* mean; const float* invstd;
+  int nlayer;                                 /* 2..5 */
+  const void* da[5]; int da_stride[5];
+  const float* scale[5]; const float* shift[5]; const float* coef[5]; int coef_stride[5];
+  long da_plane[5];                           /* 0, or the plane stride of da[j] (one plane per 16 channels, as mdie_bn_bwd_desc.da_plane);
+                                                 da[j] then points at the plane of the tensor's channel 0 */
+} mdie_bn_bwd_multi_desc;
+int mdie_bn_bwd_apply_multi(const mdie_bn_bwd_multi_desc* d, void* stream);
 /* dz[NHWC16] = grad[NCHW3] * y * (1 - y), padding channels zero (torch.sigmoid, models/cdan.py:157) */
 int mdie_sigmoid_bwd_nchw3(int dtype, int B, int H, int W, const float* grad_nchw, const float* y_nchw, void* dz_nhwc16,
                            int dz_stride, void* stream);

@@ -423,13 +423,22 @@ struct BnBwdArgs {
   SegW acc32[MDIE_MAX_SEG];      // optional fp32 running sums (ptr = nullptr: none); see mdie_bn_bwd_desc
   int final_from[MDIE_MAX_SEG];
   const char* da; int da_stride;
+  long da_plane;                  // 0, or elements between the 16-channel planes da is stored in
   int C;
   const float *mean, *invstd, *scale, *shift;
   int relu;                       // mask da by x * scale + shift > 0
-  const float* coef;              // [2][C]: k2, k3 (apply only)
+  const float* coef;              // [2][coef_stride]: k2, k3 (apply only)
+  int coef_stride;
   float* partial;                 // (reduce only)
   long chunk;
 };
+
+// first byte of channel vector v (VEC channels from c0 = v * VEC) of pixel 0 in a da tensor: rows [N][da_stride], or one plane
+// per 16 channels (da_plane elements apart, pixels da_stride apart inside a plane)
+template <typename T>
+__device__ __forceinline__ const char* da_vec_base(const char* da, long da_plane, int c0) {
+  return da_plane ? da + ((size_t)(c0 >> 4) * da_plane + (c0 & 15)) * sizeof(T) : da + (size_t)c0 * sizeof(T);
+}
 
 template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
@@ -449,12 +458,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const BnBwdAr
     float sc[VEC], sh[VEC], mu[VEC], is[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { sc[i] = a.scale[c0 + i]; sh[i] = a.shift[c0 + i]; mu[i] = a.mean[c0 + i]; is[i] = a.invstd[c0 + i]; }
+    const char* const dab = da_vec_base<T>(a.da, a.da_plane, c0);
     const long b = (long)blockIdx.x * a.chunk, e = min(a.N, b + a.chunk);
 #pragma unroll 4
     for (long p = b + m.row; p < e; p += m.rows) {   // (unrolled: a read-only loop, 8 loads in flight per thread)
       float xv[VEC], d[VEC];
       Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + (size_t)p * xs * sizeof(T)), xv);
-      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.da + (size_t)p * a.da_stride * sizeof(T) + (size_t)v * 16), d);
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(dab + (size_t)p * a.da_stride * sizeof(T)), d);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float dd = (!a.relu || fmaf(xv[i], sc[i], sh[i]) > 0.f) ? d[i] : 0.f;
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnBwdArg
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     sc[i] = a.scale[c0 + i]; sh[i] = a.shift[c0 + i]; mu[i] = a.mean[c0 + i]; is[i] = a.invstd[c0 + i];
-    k2[i] = a.coef[c0 + i]; k3[i] = a.coef[a.C + c0 + i];
+    k2[i] = a.coef[c0 + i]; k3[i] = a.coef[a.coef_stride + c0 + i];
   }
   const long b = (long)blockIdx.x * a.chunk, e = min(a.N, b + a.chunk);
   // Streaming loop, software-pipelined: the 2-3 loads of the NEXT pixel are requested before the current one is combined and
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnBwdArg
   auto fetch = [&](long p, It& t) {
     const long pp = p < e ? p : p_first;
     t.x = *reinterpret_cast<const uint4*>(xb + (size_t)pp * xs * sizeof(T));
-    t.d = *reinterpret_cast<const uint4*>(a.da + (size_t)pp * a.da_stride * sizeof(T) + (size_t)v * 16);
+    t.d = *reinterpret_cast<const uint4*>(da_vec_base<T>(a.da, a.da_plane, c0) + (size_t)pp * a.da_stride * sizeof(T));
     if (acc_t) t.g = *reinterpret_cast<const uint4*>(gb + (size_t)pp * gs * sizeof(T));
     if (acc_f) {
       t.g = *reinterpret_cast<const uint4*>(sb + (size_t)pp * ss);
@@ -580,7 +590,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply2_kernel(const BnBwdAr
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     sc[i] = a.scale[c0 + i]; sh[i] = a.shift[c0 + i]; mu[i] = a.mean[c0 + i]; is[i] = a.invstd[c0 + i];
-    k2[i] = a.coef[c0 + i]; k3[i] = a.coef[a.C + c0 + i];
+    k2[i] = a.coef[c0 + i]; k3[i] = a.coef[a.coef_stride + c0 + i];
   }
   const long b = (long)blockIdx.x * a.chunk, e = min(a.N, b + a.chunk);
   struct It { uint4 x, d, g; };
@@ -588,7 +598,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply2_kernel(const BnBwdAr
   auto fetch = [&](long p, It& t) {
     const long pp = p < e ? p : p_first;
     t.x = *reinterpret_cast<const uint4*>(xb + (size_t)pp * xs * sizeof(T));
-    t.d = *reinterpret_cast<const uint4*>(a.da + (size_t)pp * a.da_stride * sizeof(T) + (size_t)v * 16);
+    t.d = *reinterpret_cast<const uint4*>(da_vec_base<T>(a.da, a.da_plane, c0) + (size_t)pp * a.da_stride * sizeof(T));
     if constexpr (ACC) t.g = *reinterpret_cast<const uint4*>(gb + (size_t)pp * gs * sizeof(T));
   };
   auto combine = [&](long p, const It& t) {
@@ -622,6 +632,95 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply2_kernel(const BnBwdAr
     __builtin_amdgcn_sched_barrier(0);
   }
   if (p < e) combine(p, A);                        // odd tail
+}
+
+// ---- one pass for a tensor that SEVERAL BatchNorm layers consume ---------------------------------------------------------------------
+// The input x of a DenseBlock is normalised by each of its four layers and by the transition (models/cdan.py:35,38: every
+// BatchNorm sees cat(features)), so its gradient is the sum of five BatchNorm-ReLU backward terms.  Adding them layer by layer
+// (mdie_bn_bwd_apply on all segments, accumulate) reads x and the running sum and writes the sum five times: 20 passes over
+// the C channels where 7 do -- x once, each layer's da once, the sum once:
+//     g = sum_j scale_j * (da_j * [x * scale_j + shift_j > 0]) - sum_j scale_j * k2_j - xhat * sum_j scale_j * k3_j
+// with ONE rounding to the element type instead of five.  The x part of a layer's da is the contiguous prefix [0, C) of each of
+// its rows (>= 32 bytes, 128-512 for the encoder blocks), so the five streams are read in whole sectors -- unlike the growth
+// segments, 32-byte slices in the middle of those rows, for which the same idea measured SLOWER and which
+// keep the per-layer pass.
+struct BnMultiArgs {
+  long N; int C;
+  const char* x; int x_stride;
+  char* g; int g_stride;
+  const float *mean, *invstd;
+  const char* da[5]; int da_stride[5]; long da_plane[5];
+  const float *scale[5], *shift[5], *coef[5]; int coef_stride[5];
+  long chunk;
+};
+
+template <typename T, int NL>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_multi_kernel(const BnMultiArgs a) {
+  constexpr int VEC = Traits<T>::VEC;
+  const int CV = a.C / VEC;
+  const BlkMap m = blk_map(CV);
+  if (!m.active) return;
+  const int v = m.cv, c0 = v * VEC;
+  float sc[NL][VEC], sh[NL][VEC], mu[VEC], is[VEC], K2[VEC], K3[VEC];
+  // (the constants as 16-byte loads: c0 is a multiple of 4 and every array starts on a 16-byte boundary -- with 5 layers a
+  //  thread would otherwise open with 176 scalar-sized loads for a few pixels of work)
+  auto ld4 = [&](const float* p, float* dst) {
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) { const float4 v4 = *reinterpret_cast<const float4*>(p + c0 + i); dst[i] = v4.x; dst[i + 1] = v4.y; dst[i + 2] = v4.z; dst[i + 3] = v4.w; }
+  };
+  ld4(a.mean, mu); ld4(a.invstd, is);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { K2[i] = 0.f; K3[i] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    float k2[VEC], k3[VEC];
+    ld4(a.scale[j], sc[j]); ld4(a.shift[j], sh[j]); ld4(a.coef[j], k2); ld4(a.coef[j] + a.coef_stride[j], k3);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { K2[i] += sc[j][i] * k2[i]; K3[i] += sc[j][i] * k3[i]; }
+  }
+  const char* const xb = a.x + (size_t)c0 * sizeof(T);
+  char* const gb = a.g + (size_t)c0 * sizeof(T);
+  const char* dab[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) dab[j] = da_vec_base<T>(a.da[j], a.da_plane[j], c0);
+  const long b = (long)blockIdx.x * a.chunk, e = min(a.N, b + a.chunk);
+  struct It { uint4 x, d[NL]; };
+  const long p_first = b + m.row;
+  auto fetch = [&](long p, It& t) {
+    const long pp = p < e ? p : p_first;
+    t.x = *reinterpret_cast<const uint4*>(xb + (size_t)pp * a.x_stride * sizeof(T));
+#pragma unroll
+    for (int j = 0; j < NL; ++j) t.d[j] = *reinterpret_cast<const uint4*>(dab[j] + (size_t)pp * a.da_stride[j] * sizeof(T));
+  };
+  auto combine = [&](long p, const It& t) {
+    float xv[VEC], r[VEC];
+    Vec16<T>::unpack(t.x, xv);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] = -K2[i] - (xv[i] - mu[i]) * is[i] * K3[i];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      float d[VEC];
+      Vec16<T>::unpack(t.d[j], d);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) r[i] += fmaf(xv[i], sc[j][i], sh[j][i]) > 0.f ? sc[j][i] * d[i] : 0.f;
+    }
+    *reinterpret_cast<uint4*>(gb + (size_t)p * a.g_stride * sizeof(T)) = Vec16<T>::pack(r);
+  };
+  if (p_first >= e) return;
+  It A, B;
+  fetch(p_first, A);
+  long p = p_first;
+  for (; p + m.rows < e; p += 2 * m.rows) {       // whole pairs: no branch around a load or a store (counted waits), as bn_bwd_apply2_kernel
+    fetch(p + m.rows, B);
+    __builtin_amdgcn_sched_barrier(0);
+    combine(p, A);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(p + 2 * m.rows, A);
+    __builtin_amdgcn_sched_barrier(0);
+    combine(p + m.rows, B);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (p < e) combine(p, A);
 }
 
 template <typename T>
@@ -821,11 +920,13 @@ static int fill_bwd_args(const char* what, const mdie_bn_bwd_desc* d, BnBwdArgs&
     c += d->x[k].channels;
   }
   if (int e = bn_check(what, d->dtype, d->N, c)) return e;
-  MDIE_REQUIRE(d->da && d->da_stride >= c && d->mean && d->invstd && d->scale && d->shift && d->coef, "%s: null pointer / da_stride", what);
+  MDIE_REQUIRE(d->da && (d->da_plane ? (d->da_stride >= 16 && d->da_plane % 16 == 0) : d->da_stride >= c) && d->mean && d->invstd && d->scale && d->shift && d->coef, "%s: null pointer / da_stride", what);
   a.N = d->N; a.nseg = d->nseg; a.C = c;
-  a.da = (const char*)d->da; a.da_stride = d->da_stride;
+  a.da = (const char*)d->da; a.da_stride = d->da_stride; a.da_plane = d->da_plane;
   a.mean = d->mean; a.invstd = d->invstd; a.scale = d->scale; a.shift = d->shift;
   a.relu = d->relu; a.coef = d->coef; a.accumulate = d->accumulate;
+  MDIE_REQUIRE(d->coef_stride == 0 || d->coef_stride >= c, "%s: coef_stride %d < %d channels", what, d->coef_stride, c);
+  a.coef_stride = d->coef_stride ? d->coef_stride : c;
   return MDIE_OK;
 }
 
@@ -864,6 +965,37 @@ extern "C" int mdie_bn_bwd_apply(const mdie_bn_bwd_desc* d, void* stream) {
     MDIE_SWITCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3((int)blocks), dim3(BN_THREADS), 0, s, a));
   }
   MDIE_LAUNCH_CHECK("mdie_bn_bwd_apply");
+  return MDIE_OK;
+}
+
+extern "C" int mdie_bn_bwd_apply_multi(const mdie_bn_bwd_multi_desc* d, void* stream) {
+  MDIE_REQUIRE(d != nullptr, "mdie_bn_bwd_apply_multi: null descriptor");
+  if (int e = bn_check("mdie_bn_bwd_apply_multi", d->dtype, d->N, d->C)) return e;
+  MDIE_REQUIRE(d->nlayer >= 1 && d->nlayer <= 5, "mdie_bn_bwd_apply_multi: nlayer %d (1..5)", d->nlayer);
+  MDIE_REQUIRE(d->x && d->g && d->mean && d->invstd && d->x_stride >= d->C && d->g_stride >= d->C && (((uintptr_t)d->mean | (uintptr_t)d->invstd) & 15) == 0,
+               "mdie_bn_bwd_apply_multi: null pointer / stride / alignment");
+  BnMultiArgs a{};
+  a.N = d->N; a.C = d->C;
+  a.x = (const char*)d->x; a.x_stride = d->x_stride; a.g = (char*)d->g; a.g_stride = d->g_stride;
+  a.mean = d->mean; a.invstd = d->invstd;
+  for (int j = 0; j < d->nlayer; ++j) {
+    MDIE_REQUIRE(((((uintptr_t)d->scale[j] | (uintptr_t)d->shift[j] | (uintptr_t)d->coef[j]) & 15) == 0) && d->coef_stride[j] % 4 == 0, "mdie_bn_bwd_apply_multi: layer %d constants must be 16-byte aligned", j);
+    MDIE_REQUIRE(d->da[j] && (d->da_plane[j] ? (d->da_stride[j] >= 16 && d->da_plane[j] % 16 == 0) : d->da_stride[j] >= d->C) && d->scale[j] && d->shift[j] && d->coef[j] && d->coef_stride[j] >= d->C && ((uintptr_t)d->da[j] & 15) == 0,
+                 "mdie_bn_bwd_apply_multi: layer %d", j);
+    a.da[j] = (const char*)d->da[j]; a.da_stride[j] = d->da_stride[j]; a.da_plane[j] = d->da_plane[j];
+    a.scale[j] = d->scale[j]; a.shift[j] = d->shift[j]; a.coef[j] = d->coef[j]; a.coef_stride[j] = d->coef_stride[j];
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int vec = dtype_vec(d->dtype);
+  const int rows = BN_THREADS / (a.C / vec);
+  long blocks = (a.N + (long)rows * 16 - 1) / ((long)rows * 16);         // >= 16 pixels per thread: its constants are 4 * nlayer + 2 vectors
+  if (blocks > 2048) blocks = 2048;
+  a.chunk = (a.N + blocks - 1) / blocks;
+  blocks = (a.N + a.chunk - 1) / a.chunk;
+#define MDIE_MULTI(NL) MDIE_SWITCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_apply_multi_kernel<T, NL>), dim3((int)blocks), dim3(BN_THREADS), 0, s, a))
+  switch (d->nlayer) { case 1: MDIE_MULTI(1); break; case 2: MDIE_MULTI(2); break; case 3: MDIE_MULTI(3); break; case 4: MDIE_MULTI(4); break; default: MDIE_MULTI(5); break; }
+#undef MDIE_MULTI
+  MDIE_LAUNCH_CHECK("mdie_bn_bwd_apply_multi");
   return MDIE_OK;
 }
 

@@ -26,6 +26,7 @@ struct EpiArgs {
   char* out;
   int out_stride;
   float* nchw3;  // optional fp32 NCHW [B,3,Ho,Wo] destination for output channels 0..2
+  long out_gs;   // PLANAR kernels only: elements between consecutive 16-channel groups of the output (mdie_conv_desc.out_group_stride)
 };
 
 struct ConvArgs {
@@ -98,7 +99,11 @@ template <int ACT> __device__ __forceinline__ float act_fn(float v) {
   else return v;
 }
 
-template <typename T, int NCS, int NPS, int TILE, int ACT, bool POOL, bool STATS = false>
+// PLANAR: output channel group n / 16 lives at out + (n / 16) * e.out_gs (its pixels out_stride apart) instead of at out + n -- the
+// input gradient of a DenseBlock layer written one plane per 16 channels, so that the passes which later gather ONE feature
+// segment out of five such tensors read dense streams (mdie_bn_bwd_apply_multi).  Compile-time: only conv_planar.hip's
+// instantiations carry it.
+template <typename T, int NCS, int NPS, int TILE, int ACT, bool POOL, bool STATS = false, bool PLANAR = false>
 __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (&esc)[NCS], const float4 (&esh)[NCS],
                                                 f32x4 (&acc)[NCS][NPS], int img, int y0, int x0, int n0, int ps_base, int lq, int lp,
                                                 float (*st_sum)[4] = nullptr, float (*st_max)[4] = nullptr) {
@@ -110,7 +115,8 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
   const int gy0 = y0 + ty0, gx0 = x0 + tx0;
   const int oy0 = gy0 >> SH, ox0 = gx0 >> SH;
   const size_t opix0 = ((size_t)img * Ho + oy0) * Wo + ox0;
-  T* const orow0 = reinterpret_cast<T*>(e.out) + opix0 * e.out_stride + n0 + lq * 4;
+  const ptrdiff_t ogs = PLANAR ? (ptrdiff_t)e.out_gs : 16;      // elements from one 16-channel group to the next
+  T* const orow0 = reinterpret_cast<T*>(e.out) + opix0 * e.out_stride + (PLANAR ? (ptrdiff_t)(n0 >> 4) * ogs : (ptrdiff_t)n0) + lq * 4;
   const T* const rrow0 = e.residual ? reinterpret_cast<const T*>(e.residual) + opix0 * e.res_stride + n0 + lq * 4 : nullptr;
   if constexpr (sizeof(T) == 2 && (ACT == MDIE_ACT_RELU || (ACT == MDIE_ACT_NONE && !POOL)) && !STATS) {
     // 16-bit output + ReLU (or no activation, unpooled: the DenseLayers), no residual: the whole epilogue in packed form -- v_pk_fma_f32 for the affine, one v_cvt_pk_{bf16,f16}_f32 per pair,
@@ -143,7 +149,7 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
             if ((lp & 3) == cs) sel = packed;
           } else {
             const bool writer = POOL ? (inside && (lp & 3) == 0) : inside;
-            if (writer) *reinterpret_cast<uint2*>(orow + cs * 16) = packed;
+            if (writer) *reinterpret_cast<uint2*>(orow + cs * ogs) = packed;
           }
         }
         if constexpr (POOL && NCS == 4 && NPS == 4) {
@@ -232,9 +238,9 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
           }
         }
         if constexpr (sizeof(T) == 4) {
-          *reinterpret_cast<float4*>(orow + cs * 16) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(orow + cs * ogs) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          *reinterpret_cast<uint2*>(orow + cs * 16) = make_uint2(Half<T>::pack(v[0], v[1]), Half<T>::pack(v[2], v[3]));
+          *reinterpret_cast<uint2*>(orow + cs * ogs) = make_uint2(Half<T>::pack(v[0], v[1]), Half<T>::pack(v[2], v[3]));
         }
       }
     }
@@ -266,5 +272,8 @@ int launch_conv_wide(int dtype, ConvArgs& a, hipStream_t stream);
 // channels on full 16x16 tiles (decoder.final_dense)
 bool conv_thin_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw3, bool any_batch = false);
 int launch_conv_thin(int dtype, const ConvArgs& a, hipStream_t stream, const mdie_tr_fuse* tr = nullptr);
+// conv_planar.hip: conv_kernel with the output written one plane per 16 channels (no activation, pooling, residual): the input
+// gradients of the DenseBlock layers in training
+int launch_conv_planar(int dtype, ConvArgs& a, int ksize, hipStream_t stream);
 
 }  // namespace mdie

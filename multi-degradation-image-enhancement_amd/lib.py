@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 17
+ABI_VERSION = 18
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 FWD_SERIAL = 2
@@ -44,7 +44,7 @@ class ConvDesc(C.Structure):
                 ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("weight", C.c_void_p),
                 ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int), ("pool", C.c_int),
                 ("residual", C.c_void_p), ("res_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int),
-                ("out_nchw3", C.c_void_p), ("pool_partial", C.c_void_p), ("tr", C.POINTER(TrFuse))]
+                ("out_nchw3", C.c_void_p), ("pool_partial", C.c_void_p), ("tr", C.POINTER(TrFuse)), ("out_group_stride", C.c_long)]
 
 
 class WgradDesc(C.Structure):
@@ -80,7 +80,15 @@ class BnBwdDesc(C.Structure):
                 ("mean", C.c_void_p), ("invstd", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", C.c_int),
                 ("c_real", C.c_int), ("split", C.c_int), ("gap", C.c_int),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("coef", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("coef_stride", C.c_int), ("da_plane", C.c_long)]
+
+
+class BnBwdMultiDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("N", C.c_long), ("C", C.c_int), ("x", C.c_void_p), ("x_stride", C.c_int), ("g", C.c_void_p), ("g_stride", C.c_int),
+                ("mean", C.c_void_p), ("invstd", C.c_void_p), ("nlayer", C.c_int),
+                ("da", C.c_void_p * 5), ("da_stride", C.c_int * 5),
+                ("scale", C.c_void_p * 5), ("shift", C.c_void_p * 5), ("coef", C.c_void_p * 5), ("coef_stride", C.c_int * 5),
+                ("da_plane", C.c_long * 5)]
 
 
 class CbamTrainDesc(C.Structure):
@@ -210,6 +218,7 @@ SIGNATURES = {
     "mdie_bn_act_up_bwd": (C.c_int, [C.POINTER(BnUpBwdDesc), C.c_void_p]),
     "mdie_bn_bwd_reduce": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p]),
     "mdie_bn_bwd_apply": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p]),
+    "mdie_bn_bwd_apply_multi": (C.c_int, [C.POINTER(BnBwdMultiDesc), C.c_void_p]),
     "mdie_sigmoid_bwd_nchw3": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mdie_cbam_train_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mdie_cbam_train_fwd": (C.c_int, [C.POINTER(CbamTrainDesc), C.c_void_p]),
