@@ -274,6 +274,7 @@ def main():
     for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
         b, f = model.get(k, (0.0, 0.0))
         per_kernel[k] = {"launches": n, "ms": round(ms, 4), "alg_GB": round(b / 1e9, 4), "GBps": round(b / ms / 1e6, 1) if ms else None,
+                         "hbm_frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4) if ms else None,
                          "TFLOPs": round(f / ms / 1e9, 1) if ms and f else None}
     dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
