@@ -153,6 +153,13 @@ int mdie_pack_conv_weight(int dtype, int ksize, int transposed, const float* w, 
  * --------------------------------------------------------------------------------- */
 int mdie_pack_conv_weight_dev(int dtype, int ksize, int transposed, const float* w_dev, int cout, int cin,
                               int cout_stored, int cin_stored, int split, int gap, void* dst_dev, void* stream);
+/* All weight repacks of a training step in one launch: `jobs_dev` is a DEVICE array of n_jobs descriptors (same meaning as the
+ * arguments of mdie_pack_conv_weight_dev; w and dst are device pointers that stay valid, so the table is built once). */
+typedef struct {
+  const float* w; void* dst;
+  int ksize, transposed, cout, cin, cout_stored, cin_stored, split, gap;
+} mdie_pack_job;
+int mdie_pack_conv_weights_batch(int dtype, const mdie_pack_job* jobs_dev, int n_jobs, void* stream);
 
 typedef struct {
   int dtype;               /* element type of x segments and dy */

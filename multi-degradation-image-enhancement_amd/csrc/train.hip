@@ -54,6 +54,38 @@ __global__ __launch_bounds__(TR_THREADS) void pack_weight_kernel(int ks, int tra
   }
 }
 
+// every weight repack of a training step in ONE launch (blockIdx.y = job): a step repacks each of the 35 convolutions twice
+// (forward form, flipped / transposed input-gradient form) from the fp32 parameters the optimizer has just updated -- 55 launches
+// of 4-5 us each on a GPU-bound step
+template <typename T>
+__global__ __launch_bounds__(TR_THREADS) void pack_weight_batch_kernel(const mdie_pack_job* jobs) {
+  constexpr int VEC = Traits<T>::VEC, KC = Traits<T>::KC;
+  const mdie_pack_job j = jobs[blockIdx.y];
+  const float* const w = j.w;
+  T* const dst = reinterpret_cast<T*>(j.dst);
+  const int ks = j.ksize, ntap = ks * ks;
+  const size_t total = (size_t)cdiv(j.cin_stored, KC) * 4 * ntap * j.cout_stored * VEC;
+  for (size_t u = (size_t)blockIdx.x * TR_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * TR_THREADS) {
+    size_t r = u;
+    const int i = (int)(r % VEC); r /= VEC;
+    const int o = (int)(r % j.cout_stored); r /= j.cout_stored;
+    const int tap = (int)(r % ntap); r /= ntap;
+    const int q = (int)(r % 4);
+    const int chunk = (int)(r / 4);
+    const int cs = chunk * KC + q * VEC + i;
+    int c = -1;
+    if (cs < j.split) c = cs;
+    else if (cs >= j.split + j.gap) c = cs - j.gap;
+    float v = 0.f;
+    if (o < j.cout && c >= 0 && c < j.cin) {
+      const int kh = tap / ks, kw = tap - kh * ks;
+      v = j.transposed ? w[(((size_t)c * j.cout + o) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)]
+                       : w[(((size_t)o * j.cin + c) * ks + kh) * ks + kw];
+    }
+    st(dst + u, v);
+  }
+}
+
 // ---- wgrad ------------------------------------------------------------------------------------------------------------
 // fold the splits and scatter into PyTorch's layout (dropping padded channels):
 //   transposed = 0: dw[o][c][kh][kw]             (nn.Conv2d)
@@ -578,6 +610,15 @@ extern "C" int mdie_pack_conv_weight_dev(int dtype, int ksize, int transposed, c
   MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(tr_grid(total)), dim3(TR_THREADS), 0, s, ksize, transposed, w, cout, cin, cout_stored, cin_stored,
                        split, gap, reinterpret_cast<T*>(dst)));
   MDIE_LAUNCH_CHECK("mdie_pack_conv_weight_dev");
+  return MDIE_OK;
+}
+
+extern "C" int mdie_pack_conv_weights_batch(int dtype, const mdie_pack_job* jobs_dev, int n_jobs, void* stream) {
+  MDIE_REQUIRE(dtype_valid(dtype), "mdie_pack_conv_weights_batch: bad dtype %d", dtype);
+  MDIE_REQUIRE(jobs_dev != nullptr && n_jobs > 0 && n_jobs <= 65535, "mdie_pack_conv_weights_batch: %d jobs", n_jobs);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((pack_weight_batch_kernel<T>), dim3(48, n_jobs), dim3(TR_THREADS), 0, s, jobs_dev));
+  MDIE_LAUNCH_CHECK("mdie_pack_conv_weights_batch");
   return MDIE_OK;
 }
 

@@ -83,6 +83,11 @@ class BnBwdDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("coef_stride", C.c_int), ("da_plane", C.c_long)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("ksize", C.c_int), ("transposed", C.c_int), ("cout", C.c_int), ("cin", C.c_int),
+                ("cout_stored", C.c_int), ("cin_stored", C.c_int), ("split", C.c_int), ("gap", C.c_int)]
+
+
 class BnBwdMultiDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_long), ("C", C.c_int), ("x", C.c_void_p), ("x_stride", C.c_int), ("g", C.c_void_p), ("g_stride", C.c_int),
                 ("mean", C.c_void_p), ("invstd", C.c_void_p), ("nlayer", C.c_int),
@@ -168,6 +173,7 @@ SIGNATURES = {
                                         C.c_int, C.c_int, C.c_void_p]),
     "mdie_pack_conv_weight_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p]),
+    "mdie_pack_conv_weights_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mdie_conv_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mdie_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     "mdie_conv_first_fwd": (C.c_int, [C.POINTER(ConvFirstDesc), C.c_void_p]),

@@ -64,12 +64,61 @@ def _empty(dt, B, Cc, H, W, dev):
     return torch.empty(B, Cc, H, W, dtype=E.TORCH_DTYPE[dt], device=dev, memory_format=torch.channels_last)
 
 
+class _PackPlan:
+    """Every weight repack of a training step in ONE launch.
+
+    A step repacks each convolution's fp32 parameter twice -- the forward form and the flipped / transposed input-gradient
+    form -- into the engine's K-chunk layout, because the optimizer has just changed it: 55 launches of 4-5 us on a GPU-bound
+    step.  The plan learns the jobs from the first (eager) step, whose `_pack` calls run one by one and register themselves;
+    from then on `forward_train` starts with `run()` -- one mdie_pack_conv_weights_batch launch over the device-resident job table
+    -- and `_pack` hands out the buffers that launch has filled.  A job is keyed by the SOURCE tensor's address, so only
+    weights that live where they lived (the module's parameters) are served from the plan; anything else -- the zero-padded
+    copies decoder.final_dense builds per step -- takes the single-launch path, as does any job first seen after the table was
+    uploaded (it joins the table at the next step)."""
+
+    def __init__(self, dt):
+        self.dt, self.jobs, self.table, self.n_uploaded, self.filled, self.param_ptrs = dt, {}, None, 0, False, frozenset()
+
+    def lookup(self, key):
+        j = self.jobs.get(key)
+        return j[1] if (j is not None and self.filled and j[2] < self.n_uploaded) else None
+
+    def register(self, key, src, dst, args):
+        if key not in self.jobs:
+            self.jobs[key] = (src, dst, len(self.jobs), args)      # (keeps src and dst alive: their addresses are in the table)
+
+    def run(self, dev):
+        self.filled = False
+        if not self.jobs:
+            return
+        if self.n_uploaded != len(self.jobs) and not torch.cuda.is_current_stream_capturing():
+            arr = (L.PackJob * len(self.jobs))()
+            for src, dst, i, (ks, transposed, cout, cin, cout_st, cin_st) in self.jobs.values():
+                arr[i] = L.PackJob(src.data_ptr(), dst.data_ptr(), ks, int(transposed), cout, cin, cout_st, cin_st, cin, 0)
+            self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            self.n_uploaded = len(self.jobs)
+        if self.n_uploaded:
+            L.check(L.lib.mdie_pack_conv_weights_batch(self.dt, self.table.data_ptr(), self.n_uploaded, _sp(dev)), "mdie_pack_conv_weights_batch")
+            self.filled = True
+
+
+_PLAN = None     # the plan of the network whose step is running (forward_train sets it; backward runs inside the same step)
+
+
 def _pack(dt, w32, ks, transposed, cout, cin, cout_st=None, cin_st=None):
     cout_st, cin_st = cout_st or cout, cin_st or cin
+    key = (w32.data_ptr(), ks, bool(transposed), cout, cin, cout_st, cin_st)
+    plan = _PLAN if (_PLAN is not None and _PLAN.dt == dt) else None
+    if plan is not None:
+        hit = plan.lookup(key)
+        if hit is not None:
+            return hit
     n = L.lib.mdie_conv_weight_bytes(dt, ks, cin_st, cout_st)
     dst = torch.empty(n, dtype=torch.uint8, device=w32.device)
     L.check(L.lib.mdie_pack_conv_weight_dev(dt, ks, int(transposed), w32.data_ptr(), cout, cin, cout_st, cin_st, cin, 0, dst.data_ptr(), _sp(w32.device)),
             "mdie_pack_conv_weight_dev")
+    if plan is not None and w32.data_ptr() in plan.param_ptrs:
+        plan.register(key, w32, torch.empty_like(dst), (ks, transposed, cout, cin, cout_st, cin_st))
     return dst
 
 
@@ -614,6 +663,14 @@ def forward_train(net, x, precision="fp32", dropout_p=0.2):
     dt = E.dtype_id(precision)
     enc, dec = net.encoder, net.decoder
     _tick(net)
+    global _PLAN
+    plans = net.__dict__.setdefault("_mdie_pack_plans", {})
+    _PLAN = plans.get(dt) or plans.setdefault(dt, _PackPlan(dt))
+    ptrs = frozenset(p.data_ptr() for p in net.parameters() if p.dim() == 4 and p.dtype == torch.float32 and p.is_contiguous())
+    if ptrs != _PLAN.param_ptrs:        # parameters moved (load_state_dict keeps them; .to() / a new optimizer wrapper may not): start over
+        plans[dt] = _PLAN = _PackPlan(dt)
+        _PLAN.param_ptrs = ptrs
+    _PLAN.run(x.device)
     B, ch, H, W = x.shape
     if ch != 3 or H % 8 or W % 8:
         raise L.MdieError(f"forward_train: input must be [B,3,H,W] with H, W multiples of 8, got {tuple(x.shape)}")
