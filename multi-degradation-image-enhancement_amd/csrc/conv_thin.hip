@@ -48,6 +48,8 @@ static_assert(TH_PLANE % 256 == 0, "plane stride must keep the K groups on the s
 constexpr int TH_WCHUNK = 4 * 9 * 16 * 16;                                // packed weights of one 64-byte K chunk, 16 outputs
 constexpr int TH_MAXCOL = 8;
 constexpr int TH_PIT = (TH_PW * TH_PW + 63) / 64;                         // 6 staging iterations of a wave over the 324 patch pixels
+constexpr int TH_PIT2 = (TH_PW * TH_PW + 31) / 32;                        // 11 when a lane is HALF a pixel of a 16-channel segment (PAIR form)
+constexpr int TH_MAXUNIT = 4;                                             // PAIR form: one staging unit (a segment's 1 or 2 columns) per wave
 
 struct ThinArgs {
   int B, H, W, tiles_x, tiles_y;
@@ -63,6 +65,7 @@ struct ThinArgs {
   const char* tr_w; int tr_c0;      // the transition's packed 1x1 weights (16 stored outputs); stored input channel of this layer's output 0
   const float *tr_scale, *tr_shift; // the transition's folded BatchNorm, this layer's 16 channels
   const float* tr_in; float* tr_out;    // [pixel][4] fp32 partial sums of the transition (may be the same buffer)
+  int nunit; int unit_col[TH_MAXUNIT]; int unit_ncol[TH_MAXUNIT];   // PAIR form: unit u = columns unit_col[u] .. + unit_ncol[u] (1 or 2) of ONE segment
   const float *tr_post_scale, *tr_post_shift; float* tr_nchw3;   // TR == 2: the transition's epilogue constants and the network output
 };
 
@@ -86,10 +89,19 @@ static unsigned long long* g_thin_dbg = nullptr;
 // the transition's bias and the sigmoid and written as the network's fp32 NCHW output while the layer's own 16 channels
 // are never stored (TR = 2: nothing reads them).  Removes the transition's launch, its re-read of all 67 channels and the
 // last growth map's write from decoder.final_dense (engine.hip).
-template <typename T, int NCHUNK, int ACT, int TR = 0>
+//
+// PAIR (round 3): who stages what.  In the column form above a wave loads one 16-byte column, lane = pixel: for a 16-channel
+// growth map (32 bytes per pixel) that is 64 lanes x 16 bytes at a 32-byte stride -- every wave instruction touches 64 half-used
+// sectors and the OTHER half of each is fetched by another wave.  Stamps (tools/stamp_thin.py, 7 columns): "issue next tile's
+// loads" 2.2 k of a tile's 7.9 k cycles -- twelve loads per lane -- and 3.0 k in front of the LDS writes: the vector memory path,
+// not arithmetic.  In the PAIR form a wave stages one UNIT -- the one or two columns of a <= 16-channel stretch of ONE segment --
+// with lane = (pixel, 16-byte half): a wave instruction reads 32 pixels x 32 bytes = 1 KiB CONTIGUOUS, 11 loads per lane cover
+// the patch, and the lane writes its half into its own plane.  Single-column units (the 8-channel base) run the same 11
+// iterations with both halves reading the same 16 bytes and the odd lanes writing nothing.  Needs <= 4 units (one per wave).
+template <typename T, int NCHUNK, int ACT, int TR = 0, bool PAIR = false>
 __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs a, const int n_items) {
   static_assert(sizeof(T) == 2, "16-bit storage types");
-  constexpr int PW = TH_PW, PIT = TH_PIT, CPW = NCHUNK;
+  constexpr int PW = TH_PW, PIT = PAIR ? TH_PIT2 : TH_PIT, CPW = PAIR ? 1 : NCHUNK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const lds_patch = smem;                                             // [ncol] planes
   float* const lds_pre = reinterpret_cast<float*>(smem + a.ncol * TH_PLANE);   // [ncol * 8] scale, [ncol * 8] shift
@@ -149,22 +161,27 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
   unsigned m_top = 0, m_bot = 0, m_left = 0, m_right = 0, m_valid = 0;
 #pragma unroll
   for (int it = 0; it < PIT; ++it) {
-    const unsigned p = lane + 64 * it, py = p / PW, px = p - py * PW;
+    const unsigned p = PAIR ? (unsigned)(lane >> 1) + 32u * it : (unsigned)lane + 64u * it, py = p / PW, px = p - py * PW;
     dp[it] = py * (unsigned)a.W + px;
     ldst[it] = (py * PWP + px) * 16;
     m_valid |= (p < PW * PW ? 1u : 0u) << it;
     m_top |= (py == 0 ? 1u : 0u) << it; m_bot |= (py == PW - 1 ? 1u : 0u) << it;
     m_left |= (px == 0 ? 1u : 0u) << it; m_right |= (px == PW - 1 ? 1u : 0u) << it;
   }
-  // this wave's column slots
+  // this wave's column slots (PAIR: its one unit)
   const char* cptr[CPW]; unsigned cstr[CPW]; bool clive[CPW];
+  int ucol = 0; bool upair = false;                 // PAIR: first column of the unit, and whether it has two
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
     const int j = wave + 4 * c;
-    clive[c] = j < a.ncol;
-    const int jj = clive[c] ? j : 0;
+    clive[c] = PAIR ? j < a.nunit : j < a.ncol;
+    int jj = clive[c] ? j : 0;
+    if constexpr (PAIR) { ucol = a.unit_col[jj]; upair = a.unit_ncol[jj] == 2; jj = ucol; }
     cptr[c] = a.col_ptr[jj]; cstr[c] = a.col_stride[jj];
   }
+  const unsigned lhalf = PAIR && upair ? (unsigned)(lane & 1) * 16u : 0u;     // the lane's 16-byte half of its pixel
+  const int mycol = PAIR ? ucol + (upair ? (lane & 1) : 0) : 0;               // PAIR: the column (= LDS plane) this lane fills
+  const bool lwrite = !PAIR || upair || (lane & 1) == 0;                      // (single-column unit: the odd lanes duplicate the even ones)
   // operands: B column lp of the wave's subtile ps = pixel (4 wave + ps, lp) -- 16 consecutive pixels of one row, so the
   // fragment of input row r and column shift kw serves the three output rows r, r-1, r-2 (taps kh = 0, 1, 2): 18 LDS reads
   // for a chunk's 36 MFMAs instead of 36.  K group lq of chunk k = plane min(4k + lq, ncol - 1) (a plane past the live
@@ -186,10 +203,10 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
       const char* const base = cptr[c] + gp0 * (long long)cstr[c];           // wave-uniform
-      const unsigned self = ((unsigned)a.W + 1u) * cstr[c];                  // the tile's own first pixel: always inside
+      const unsigned self = ((unsigned)a.W + 1u) * cstr[c] + lhalf;          // the tile's own first pixel: always inside
 #pragma unroll
       for (int it = 0; it < PIT; ++it) {
-        const unsigned off = clive[c] ? (((okm >> it) & 1u) ? __umul24(dp[it], cstr[c]) : self) : self;
+        const unsigned off = clive[c] ? (((okm >> it) & 1u) ? __umul24(dp[it], cstr[c]) + lhalf : self) : self;
         pv[c][it] = *reinterpret_cast<const uint4*>(base + off);
       }
     }
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
       if (clive[c]) {   // wave-uniform; no global memory instruction inside
-        const int j = wave + 4 * c;
+        const int j = PAIR ? mycol : wave + 4 * c;      // (PAIR: per lane -- the even lanes fill the unit's first column, the odd ones its second)
         f32x2 ps_[4], pb_[4];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -215,15 +232,16 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
           pb_[2 * i] = f32x2{b4.x, b4.y}; pb_[2 * i + 1] = f32x2{b4.z, b4.w};
         }
         char* const plane = lds_patch + j * TH_PLANE;
+        constexpr int LPI = PAIR ? 32 : 64;             // pixels per staging iteration
 #pragma unroll
         for (int it = 0; it < PIT; ++it) {
           const uint4 v = PreAct<T>::apply(pv[c][it], ps_, pb_);
-          if (it < PIT - 1 || lane + 64 * it < PW * PW) *reinterpret_cast<uint4*>(plane + ldst[it]) = v;
+          if (lwrite && (it < PIT - 1 || (PAIR ? (lane >> 1) : lane) + LPI * it < PW * PW)) *reinterpret_cast<uint4*>(plane + ldst[it]) = v;
         }
         if (border) {   // wave-uniform, border tiles only: the out-of-image pixels are overwritten with zeros (same lane, in order)
 #pragma unroll
           for (int it = 0; it < PIT; ++it)
-            if (!((okm >> it) & 1u) && (it < PIT - 1 || lane + 64 * it < PW * PW)) *reinterpret_cast<uint4*>(plane + ldst[it]) = make_uint4(0u, 0u, 0u, 0u);
+            if (lwrite && !((okm >> it) & 1u) && (it < PIT - 1 || (PAIR ? (lane >> 1) : lane) + LPI * it < PW * PW)) *reinterpret_cast<uint4*>(plane + ldst[it]) = make_uint4(0u, 0u, 0u, 0u);
         }
       }
     }
@@ -347,17 +365,19 @@ static int launch_thin_t(const ThinArgs& t, int act, int tr, int items, hipStrea
   const int per_cu = 2;                                                       // (registers: weights live in them)
   const int wgs = 8 * cdiv(std::min(items, 256 * per_cu), 8);
   TimedLaunch tl(MDIE_K_CONV3);
-#define MDIE_THIN(ACT, TR)                                                                                            \
+#define MDIE_THIN_P(ACT, TR, PAIR)                                                                                    \
   do {                                                                                                                \
     static LdsOptIn opt;                                                                                              \
-    if (!opt.ensure(reinterpret_cast<const void*>(&conv_thin_kernel<T, NCHUNK, ACT, TR>), 64 * 1024)) return MDIE_ELAUNCH; \
-    hipLaunchKernelGGL((conv_thin_kernel<T, NCHUNK, ACT, TR>), dim3(wgs), dim3(TH_THREADS), lds, stream, t, items);      \
+    if (!opt.ensure(reinterpret_cast<const void*>(&conv_thin_kernel<T, NCHUNK, ACT, TR, PAIR>), 64 * 1024)) return MDIE_ELAUNCH; \
+    hipLaunchKernelGGL((conv_thin_kernel<T, NCHUNK, ACT, TR, PAIR>), dim3(wgs), dim3(TH_THREADS), lds, stream, t, items);      \
   } while (0)
+#define MDIE_THIN(ACT, TR) do { if (t.nunit > 0) MDIE_THIN_P(ACT, TR, true); else MDIE_THIN_P(ACT, TR, false); } while (0)
   if (tr == 1) MDIE_THIN(MDIE_ACT_NONE, 1);
   else if (tr == 2) MDIE_THIN(MDIE_ACT_NONE, 2);
   else if (act == MDIE_ACT_RELU) MDIE_THIN(MDIE_ACT_RELU, 0);
   else MDIE_THIN(MDIE_ACT_NONE, 0);
 #undef MDIE_THIN
+#undef MDIE_THIN_P
   MDIE_LAUNCH_CHECK("mdie_conv_fwd");
   return MDIE_OK;
 }
@@ -372,6 +392,22 @@ int launch_conv_thin(int dtype, const ConvArgs& a, hipStream_t stream, const mdi
     for (int s = 0; s < a.nseg; ++s)
       if (c0 >= a.seg[s].ch_begin && c0 < a.seg[s].ch_end) { t.col_ptr[j] = a.seg[s].ptr + (size_t)(c0 - a.seg[s].ch_begin) * 2; t.col_stride[j] = (unsigned)a.seg[s].stride * 2u; }
     MDIE_REQUIRE(t.col_ptr[j] != nullptr, "mdie_conv_fwd: input channel %d belongs to no segment", c0);
+  }
+  // staging units of the PAIR form: every segment cut into stretches of <= 16 channels (1 or 2 columns of one pixel's contiguous bytes)
+#ifndef THIN_PAIR_MIN_UNITS
+#define THIN_PAIR_MIN_UNITS 3
+#endif
+  {
+    int nu = 0;
+    bool fits = true;
+    for (int s = 0; s < a.nseg && fits; ++s)
+      for (int c0 = a.seg[s].ch_begin; c0 < a.seg[s].ch_end; c0 += 16) {
+        if (nu == TH_MAXUNIT) { fits = false; break; }
+        t.unit_col[nu] = c0 / 8;
+        t.unit_ncol[nu] = a.seg[s].ch_end - c0 >= 16 ? 2 : 1;
+        ++nu;
+      }
+    t.nunit = (fits && nu >= THIN_PAIR_MIN_UNITS) ? nu : 0;      // (0: the column form)
   }
   t.pre_scale = a.pre_scale; t.pre_shift = a.pre_shift; t.weight = a.weight;
   t.post_scale = a.e.post_scale; t.post_shift = a.e.post_shift;
