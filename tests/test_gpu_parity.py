@@ -908,14 +908,17 @@ def test_wide_conv_lds_dma_kernel(E, L, prec, case):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("cin_segs,act", [([8, 16], "none"), ([8, 16, 16], "none"), ([8, 16, 16, 16], "none"), ([16, 16], "relu"), ([16, 16, 16, 8], "none")])
+@pytest.mark.parametrize("cin_segs,act", [([8, 16], "none"), ([8, 16, 16], "none"), ([8, 16, 16, 16], "none"), ([16, 16], "relu"), ([16, 16, 16, 8], "none"),
+                                          ([24, 16], "none"), ([8, 8, 8, 8, 8], "none"), ([32, 24], "relu")])
 def test_thin_persistent_conv_kernel(E, L, prec, cin_segs, act):
     """conv_thin_kernel (csrc/conv_thin.hip: persistent workgroups, one wave per 16-byte input column, next tile prefetched
     into registers, all K chunks of a tile in LDS at once) -- the kernel behind decoder.final_dense layers 1..3 at BASELINE
     sizes (base + 1..3 growth maps = 3, 5, 7 live columns) -- against torch's CPU convolution on the same rounded operands,
     and bit for bit against conv_kernel, which a batch with fewer than 1024 tiles still runs on: every image border, runs of
     several tiles per workgroup that cross image boundaries, one and two K chunks, segments with their own strides, the
-    output written into a slice of a wider buffer."""
+    output written into a slice of a wider buffer.  Both staging forms: the column form (one 16-byte column per wave: two
+    units, or more than four -- [8]*5) and the PAIR form (a wave stages a <= 16-channel stretch of one segment with lane =
+    (pixel, half): three or four units, single- and two-column units mixed, a 24-channel segment cut into 16 + 8)."""
     import ctypes as C
     import torch.nn.functional as F
     dt, td = E.dtype_id(prec), TORCH_DT[prec]
