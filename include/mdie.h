@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 18
+#define MDIE_ABI_VERSION 19
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1,
        MDIE_F16 = 2 /* IEEE half: the reference's mixed-precision dtype (torch.cuda.amp.autocast, models/model.py:15,159) */ };
@@ -158,8 +158,12 @@ int mdie_pack_conv_weight_dev(int dtype, int ksize, int transposed, const float*
 typedef struct {
   const float* w; void* dst;
   int ksize, transposed, cout, cin, cout_stored, cin_stored, split, gap;
+  int out_split, out_gap;  /* the same placement for the OUTPUT channels: real o >= out_split is stored at o + out_gap (the input-gradient
+                              form of a layer whose input has a gap: decoder.final_dense).  No gap: out_split = cout, out_gap = 0 */
 } mdie_pack_job;
 int mdie_pack_conv_weights_batch(int dtype, const mdie_pack_job* jobs_dev, int n_jobs, void* stream);
+/* one job, given on the HOST (w and dst inside it are device pointers) */
+int mdie_pack_conv_weight_job(int dtype, const mdie_pack_job* job, void* stream);
 
 typedef struct {
   int dtype;               /* element type of x segments and dy */
@@ -434,6 +438,21 @@ size_t mdie_bn_workspace_bytes(int C);
 /* mean[C], var[C] (biased) over N pixels */
 int mdie_bn_stats(int dtype, long N, const void* x, int C, int stride, float* mean, float* var, void* workspace,
                   size_t workspace_bytes, void* stream);
+/* mdie_bn_stats and mdie_bn_fold in two launches instead of three: the statistics of x's C channels go to mean / var, then
+ * (gamma non-null) the fold runs over C_fold stored channels whose statistics are fold_mean / fold_var[0 .. C_fold) -- mean / var
+ * must point INSIDE that range (a DenseBlock layer normalises the concatenation of earlier maps, whose statistics are already
+ * there, and the map just written).  x == NULL: the partial sums [n_partial][2][C] (channel sums, sums of squares) are already
+ * in `workspace`, left there by the convolution that produced the tensor (mdie_conv_desc.bn_partial): one launch. */
+typedef struct {
+  int dtype; long N;                 /* pixels */
+  const void* x; int C, stride;      /* the tensor whose statistics are new (or NULL) */
+  float* mean; float* var;
+  void* workspace; size_t workspace_bytes; int n_partial;
+  int C_fold, C_real, split, gap;    /* as mdie_bn_fold */
+  const float* fold_mean; const float* fold_var; const float* gamma; const float* beta; float eps, momentum;
+  float* running_mean; float* running_var; float* scale; float* shift; float* invstd;
+} mdie_bn_stats_fold_desc;
+int mdie_bn_stats_fold(const mdie_bn_stats_fold_desc* d, void* stream);
 /* scale = gamma / sqrt(var + eps), shift = beta - mean * scale, invstd, per STORED channel (mean / var / outputs are
  * indexed by stored channel; gamma / beta / running_* by real channel: real c >= split is stored at c + gap; padding
  * gets scale = shift = 0).  running_* (nullable) are updated with `momentum` and the unbiased variance. */

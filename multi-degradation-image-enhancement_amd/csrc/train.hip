@@ -27,40 +27,8 @@ struct SegT {
 // ---- weight repack on the device --------------------------------------------------------------------------------
 // same layout as pack_conv_weight() in engine.hip: [chunk][q][tap][cout_st][16 bytes]
 template <typename T>
-__global__ __launch_bounds__(TR_THREADS) void pack_weight_kernel(int ks, int transposed, const float* w, int cout, int cin, int cout_st,
-                                                                 int cin_st, int split, int gap, T* dst) {
+__device__ __forceinline__ void pack_job_run(const mdie_pack_job& j) {
   constexpr int VEC = Traits<T>::VEC, KC = Traits<T>::KC;
-  const int ntap = ks * ks;
-  const int nchunk = cdiv(cin_st, KC);
-  const size_t total = (size_t)nchunk * 4 * ntap * cout_st * VEC;
-  for (size_t u = (size_t)blockIdx.x * TR_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * TR_THREADS) {
-    size_t r = u;
-    const int i = (int)(r % VEC); r /= VEC;
-    const int o = (int)(r % cout_st); r /= cout_st;
-    const int tap = (int)(r % ntap); r /= ntap;
-    const int q = (int)(r % 4);
-    const int chunk = (int)(r / 4);
-    const int cs = chunk * KC + q * VEC + i;             // stored input channel
-    int c = -1;                                          // real input channel, -1 = padding
-    if (cs < split) c = cs;
-    else if (cs >= split + gap) c = cs - gap;
-    float v = 0.f;
-    if (o < cout && c >= 0 && c < cin) {
-      const int kh = tap / ks, kw = tap - kh * ks;
-      v = transposed ? w[(((size_t)c * cout + o) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)]
-                     : w[(((size_t)o * cin + c) * ks + kh) * ks + kw];
-    }
-    st(dst + u, v);
-  }
-}
-
-// every weight repack of a training step in ONE launch (blockIdx.y = job): a step repacks each of the 35 convolutions twice
-// (forward form, flipped / transposed input-gradient form) from the fp32 parameters the optimizer has just updated -- 55 launches
-// of 4-5 us each on a GPU-bound step
-template <typename T>
-__global__ __launch_bounds__(TR_THREADS) void pack_weight_batch_kernel(const mdie_pack_job* jobs) {
-  constexpr int VEC = Traits<T>::VEC, KC = Traits<T>::KC;
-  const mdie_pack_job j = jobs[blockIdx.y];
   const float* const w = j.w;
   T* const dst = reinterpret_cast<T*>(j.dst);
   const int ks = j.ksize, ntap = ks * ks;
@@ -68,16 +36,18 @@ __global__ __launch_bounds__(TR_THREADS) void pack_weight_batch_kernel(const mdi
   for (size_t u = (size_t)blockIdx.x * TR_THREADS + threadIdx.x; u < total; u += (size_t)gridDim.x * TR_THREADS) {
     size_t r = u;
     const int i = (int)(r % VEC); r /= VEC;
-    const int o = (int)(r % j.cout_stored); r /= j.cout_stored;
+    const int os = (int)(r % j.cout_stored); r /= j.cout_stored;
     const int tap = (int)(r % ntap); r /= ntap;
     const int q = (int)(r % 4);
     const int chunk = (int)(r / 4);
-    const int cs = chunk * KC + q * VEC + i;
-    int c = -1;
+    const int cs = chunk * KC + q * VEC + i;             // stored input channel
+    int c = -1, o = -1;                                  // real input / output channel, -1 = padding
     if (cs < j.split) c = cs;
     else if (cs >= j.split + j.gap) c = cs - j.gap;
+    if (os < j.out_split) o = os;
+    else if (os >= j.out_split + j.out_gap) o = os - j.out_gap;
     float v = 0.f;
-    if (o < j.cout && c >= 0 && c < j.cin) {
+    if (o >= 0 && o < j.cout && c >= 0 && c < j.cin) {
       const int kh = tap / ks, kw = tap - kh * ks;
       v = j.transposed ? w[(((size_t)c * j.cout + o) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)]
                        : w[(((size_t)o * j.cin + c) * ks + kh) * ks + kw];
@@ -85,6 +55,15 @@ __global__ __launch_bounds__(TR_THREADS) void pack_weight_batch_kernel(const mdi
     st(dst + u, v);
   }
 }
+
+template <typename T>
+__global__ __launch_bounds__(TR_THREADS) void pack_weight_kernel(const mdie_pack_job j) { pack_job_run<T>(j); }
+
+// every weight repack of a training step in ONE launch (blockIdx.y = job): a step repacks each of the 35 convolutions twice
+// (forward form, flipped / transposed input-gradient form) from the fp32 parameters the optimizer has just updated -- 55 launches
+// of 4-5 us each on a GPU-bound step
+template <typename T>
+__global__ __launch_bounds__(TR_THREADS) void pack_weight_batch_kernel(const mdie_pack_job* jobs) { pack_job_run<T>(jobs[blockIdx.y]); }
 
 // ---- wgrad ------------------------------------------------------------------------------------------------------------
 // fold the splits and scatter into PyTorch's layout (dropping padded channels):
@@ -596,21 +575,34 @@ static void launch_wgrad_tile_f16(const WgradTileArgs& a, const WgTilePlan& p, h
 
 using namespace mdie;
 
-extern "C" int mdie_pack_conv_weight_dev(int dtype, int ksize, int transposed, const float* w, int cout, int cin, int cout_stored,
-                                         int cin_stored, int split, int gap, void* dst, void* stream) {
-  MDIE_REQUIRE(dtype_valid(dtype), "mdie_pack_conv_weight_dev: bad dtype %d", dtype);
-  MDIE_REQUIRE(ksize == 1 || ksize == 3, "mdie_pack_conv_weight_dev: ksize %d", ksize);
-  MDIE_REQUIRE(w && dst && cout > 0 && cin > 0, "mdie_pack_conv_weight_dev: null/empty");
-  MDIE_REQUIRE(cout_stored >= cout && cout_stored % 16 == 0, "mdie_pack_conv_weight_dev: cout_stored %d", cout_stored);
-  MDIE_REQUIRE(cin_stored % 16 == 0 && cin_stored >= cin + (split < cin ? gap : 0) && gap >= 0 && split >= 0,
-               "mdie_pack_conv_weight_dev: cin_stored %d too small for cin %d split %d gap %d", cin_stored, cin, split, gap);
+static int pack_job_check(const char* what, const mdie_pack_job& j) {
+  MDIE_REQUIRE(j.ksize == 1 || j.ksize == 3, "%s: ksize %d", what, j.ksize);
+  MDIE_REQUIRE(j.w && j.dst && j.cout > 0 && j.cin > 0, "%s: null/empty", what);
+  MDIE_REQUIRE(j.cout_stored % 16 == 0 && j.out_gap >= 0 && j.out_split >= 0 && j.cout_stored >= j.cout + (j.out_split < j.cout ? j.out_gap : 0),
+               "%s: cout_stored %d too small for cout %d out_split %d out_gap %d", what, j.cout_stored, j.cout, j.out_split, j.out_gap);
+  MDIE_REQUIRE(j.cin_stored % 16 == 0 && j.cin_stored >= j.cin + (j.split < j.cin ? j.gap : 0) && j.gap >= 0 && j.split >= 0,
+               "%s: cin_stored %d too small for cin %d split %d gap %d", what, j.cin_stored, j.cin, j.split, j.gap);
+  return MDIE_OK;
+}
+
+extern "C" int mdie_pack_conv_weight_job(int dtype, const mdie_pack_job* job, void* stream) {
+  MDIE_REQUIRE(dtype_valid(dtype), "mdie_pack_conv_weight_job: bad dtype %d", dtype);
+  MDIE_REQUIRE(job != nullptr, "mdie_pack_conv_weight_job: null job");
+  if (int e = pack_job_check("mdie_pack_conv_weight_job", *job)) return e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int kc = dtype_kc(dtype);
-  const size_t total = (size_t)cdiv(cin_stored, kc) * 4 * ksize * ksize * cout_stored * (kc / 4);
-  MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(tr_grid(total)), dim3(TR_THREADS), 0, s, ksize, transposed, w, cout, cin, cout_stored, cin_stored,
-                       split, gap, reinterpret_cast<T*>(dst)));
-  MDIE_LAUNCH_CHECK("mdie_pack_conv_weight_dev");
+  const size_t total = (size_t)cdiv(job->cin_stored, kc) * 4 * job->ksize * job->ksize * job->cout_stored * (kc / 4);
+  MDIE_SWITCH_T(dtype, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(tr_grid(total)), dim3(TR_THREADS), 0, s, *job));
+  MDIE_LAUNCH_CHECK("mdie_pack_conv_weight_job");
   return MDIE_OK;
+}
+
+extern "C" int mdie_pack_conv_weight_dev(int dtype, int ksize, int transposed, const float* w, int cout, int cin, int cout_stored,
+                                         int cin_stored, int split, int gap, void* dst, void* stream) {
+  mdie_pack_job j{};
+  j.w = w; j.dst = dst; j.ksize = ksize; j.transposed = transposed; j.cout = cout; j.cin = cin; j.cout_stored = cout_stored; j.cin_stored = cin_stored;
+  j.split = split; j.gap = gap; j.out_split = cout; j.out_gap = 0;
+  return mdie_pack_conv_weight_job(dtype, &j, stream);
 }
 
 extern "C" int mdie_pack_conv_weights_batch(int dtype, const mdie_pack_job* jobs_dev, int n_jobs, void* stream) {

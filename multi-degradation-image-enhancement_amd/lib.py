@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 18
+ABI_VERSION = 19
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 FWD_SERIAL = 2
@@ -85,7 +85,15 @@ class BnBwdDesc(C.Structure):
 
 class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("ksize", C.c_int), ("transposed", C.c_int), ("cout", C.c_int), ("cin", C.c_int),
-                ("cout_stored", C.c_int), ("cin_stored", C.c_int), ("split", C.c_int), ("gap", C.c_int)]
+                ("cout_stored", C.c_int), ("cin_stored", C.c_int), ("split", C.c_int), ("gap", C.c_int), ("out_split", C.c_int), ("out_gap", C.c_int)]
+
+
+class BnStatsFoldDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("N", C.c_long), ("x", C.c_void_p), ("C", C.c_int), ("stride", C.c_int), ("mean", C.c_void_p), ("var", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("n_partial", C.c_int),
+                ("C_fold", C.c_int), ("C_real", C.c_int), ("split", C.c_int), ("gap", C.c_int),
+                ("fold_mean", C.c_void_p), ("fold_var", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("momentum", C.c_float),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("invstd", C.c_void_p)]
 
 
 class BnBwdMultiDesc(C.Structure):
@@ -174,6 +182,8 @@ SIGNATURES = {
     "mdie_pack_conv_weight_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p]),
     "mdie_pack_conv_weights_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mdie_bn_stats_fold": (C.c_int, [C.POINTER(BnStatsFoldDesc), C.c_void_p]),
+    "mdie_pack_conv_weight_job": (C.c_int, [C.c_int, C.POINTER(PackJob), C.c_void_p]),
     "mdie_conv_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mdie_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     "mdie_conv_first_fwd": (C.c_int, [C.POINTER(ConvFirstDesc), C.c_void_p]),

@@ -93,8 +93,8 @@ class _PackPlan:
             return
         if self.n_uploaded != len(self.jobs) and not torch.cuda.is_current_stream_capturing():
             arr = (L.PackJob * len(self.jobs))()
-            for src, dst, i, (ks, transposed, cout, cin, cout_st, cin_st) in self.jobs.values():
-                arr[i] = L.PackJob(src.data_ptr(), dst.data_ptr(), ks, int(transposed), cout, cin, cout_st, cin_st, cin, 0)
+            for src, dst, i, args in self.jobs.values():
+                arr[i] = L.PackJob(src.data_ptr(), dst.data_ptr(), *args)
             self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
             self.n_uploaded = len(self.jobs)
         if self.n_uploaded:
@@ -104,10 +104,32 @@ class _PackPlan:
 
 _PLAN = None     # the plan of the network whose step is running (forward_train sets it; backward runs inside the same step)
 
+# The bias of a convolution that feeds a BatchNorm has an exactly-zero gradient (the batch mean absorbs it): 28 of the 35
+# convolutions.  Autograd still wants a tensor per parameter; they are slices of ONE zero-filled arena per step (one fill
+# launch instead of 28 -- each slice belongs to one parameter, so in-place users of .grad -- GradScaler.unscale_, gradient
+# clipping -- see ordinary separate tensors).
+_ZERO_ARENA = None   # [tensor, next free element]
 
-def _pack(dt, w32, ks, transposed, cout, cin, cout_st=None, cin_st=None):
+
+def _new_zero_arena(dev, n=4096):
+    global _ZERO_ARENA
+    _ZERO_ARENA = [torch.zeros(n, dtype=torch.float32, device=dev), 0]
+
+
+def _zero_grad_vec(n, dev):
+    a = _ZERO_ARENA
+    if a is None or a[0].device != dev or a[1] + n > a[0].numel():
+        return torch.zeros(n, dtype=torch.float32, device=dev)
+    a[1] += n
+    return a[0][a[1] - n:a[1]]
+
+
+def _pack(dt, w32, ks, transposed, cout, cin, cout_st=None, cin_st=None, split=None, gap=0, out_split=None, out_gap=0):
+    """the engine's K-chunk form of an fp32 weight (mdie_pack_job: `split` / `gap` place the real input channels inside a wider
+    stored input, `out_split` / `out_gap` the real output channels inside a wider stored output)"""
     cout_st, cin_st = cout_st or cout, cin_st or cin
-    key = (w32.data_ptr(), ks, bool(transposed), cout, cin, cout_st, cin_st)
+    args = (ks, int(bool(transposed)), cout, cin, cout_st, cin_st, cin if split is None else split, gap, cout if out_split is None else out_split, out_gap)
+    key = (w32.data_ptr(),) + args
     plan = _PLAN if (_PLAN is not None and _PLAN.dt == dt) else None
     if plan is not None:
         hit = plan.lookup(key)
@@ -115,10 +137,10 @@ def _pack(dt, w32, ks, transposed, cout, cin, cout_st=None, cin_st=None):
             return hit
     n = L.lib.mdie_conv_weight_bytes(dt, ks, cin_st, cout_st)
     dst = torch.empty(n, dtype=torch.uint8, device=w32.device)
-    L.check(L.lib.mdie_pack_conv_weight_dev(dt, ks, int(transposed), w32.data_ptr(), cout, cin, cout_st, cin_st, cin, 0, dst.data_ptr(), _sp(w32.device)),
-            "mdie_pack_conv_weight_dev")
+    job = L.PackJob(w32.data_ptr(), dst.data_ptr(), *args)
+    L.check(L.lib.mdie_pack_conv_weight_job(dt, C.byref(job), _sp(w32.device)), "mdie_pack_conv_weight_job")
     if plan is not None and w32.data_ptr() in plan.param_ptrs:
-        plan.register(key, w32, torch.empty_like(dst), (ks, transposed, cout, cin, cout_st, cin_st))
+        plan.register(key, w32, torch.empty_like(dst), args)
     return dst
 
 
@@ -173,7 +195,7 @@ def _pad_vec(v, n):
     return v if v.numel() == n else F.pad(v, (0, n - v.numel()))
 
 
-def _wgrad(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre=None):
+def _wgrad(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre=None, split=None, gap=0):
     """dW in the parameter's layout from the convolution's input segments and dy (stored cout_st channels)."""
     B, _, H, W = dy.shape
     dev = dy.device
@@ -187,7 +209,7 @@ def _wgrad(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre=None):
     for i, s in enumerate(segs):
         ptr, c, st = _nhwc(s)
         d.inp[i] = L.Seg(ptr, c, st)
-    d.cin, d.cout, d.cout_stored, d.split, d.gap = cin, cout, cout_st, cin, 0
+    d.cin, d.cout, d.cout_stored, d.split, d.gap = cin, cout, cout_st, (cin if split is None else split), gap
     ptr, _, st = _nhwc(dy)
     d.dy, d.dy_stride = ptr, st
     d.dw, d.workspace, d.workspace_bytes = dw.data_ptr(), ws.data_ptr(), nws
@@ -206,6 +228,31 @@ class _Bn:
         nws = L.lib.mdie_bn_workspace_bytes(c)
         ws = torch.empty(nws, dtype=torch.uint8, device=t.device)
         L.check(L.lib.mdie_bn_stats(dt, B * H * W, ptr, c, st, mean.data_ptr(), var.data_ptr(), ws.data_ptr(), nws, _sp(t.device)), "mdie_bn_stats")
+
+    @staticmethod
+    def stats_fold(dt, t, mv, off, c_st, c_real, split, gap, bn, momentum, partial=None):
+        """statistics of t -> mv[:, off : off + C_t], then the fold of `bn` over the stored channels mv[:, :c_st] (which end with
+        the new ones) -> consts [3, c_st]: scale, shift, invstd; bn.running_* updated in place.  Two launches
+        (mdie_bn_stats_fold), or one when the convolution that wrote t left its partial sums in `partial` (tensor, count)."""
+        ptr, c, st = _nhwc(t)
+        B, _, H, W = t.shape
+        dev = t.device
+        k = torch.empty(3, c_st, dtype=torch.float32, device=dev)
+        d = L.BnStatsFoldDesc()
+        d.dtype, d.N, d.C, d.stride = dt, B * H * W, c, st
+        d.mean, d.var = mv[0, off:].data_ptr(), mv[1, off:].data_ptr()
+        if partial is None:
+            nws = L.lib.mdie_bn_workspace_bytes(c)
+            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+            d.x, d.workspace, d.workspace_bytes = ptr, ws.data_ptr(), nws
+        else:
+            d.x, d.workspace, d.workspace_bytes, d.n_partial = None, partial[0].data_ptr(), partial[0].numel() * partial[0].element_size(), partial[1]
+        d.C_fold, d.C_real, d.split, d.gap = c_st, c_real, split, gap
+        d.fold_mean, d.fold_var, d.gamma, d.beta, d.eps, d.momentum = mv[0].data_ptr(), mv[1].data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), EPS, momentum
+        d.running_mean, d.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        d.scale, d.shift, d.invstd = k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr()
+        L.check(L.lib.mdie_bn_stats_fold(C.byref(d), _sp(dev)), "mdie_bn_stats_fold")
+        return k
 
     @staticmethod
     def fold(c_st, c_real, split, gap, mean, var, bn, momentum, count, dev):
@@ -245,8 +292,7 @@ class _ConvBnFn(torch.autograd.Function):
         y = _empty(dt, B, cout, H, W, dev)
         _conv_raw(dt, [x], _pack(dt, w32, 3, False, cout, cin, cout, cin_st), _f32(bias), 3, cout, y)
         mv = torch.empty(2, cout, dtype=torch.float32, device=dev)
-        _Bn.stats(dt, y, mv[0], mv[1])
-        k = _Bn.fold(cout, cout, cout, 0, mv[0], mv[1], bn, 0.1, B * H * W, dev)
+        k = _Bn.stats_fold(dt, y, mv, 0, cout, cout, cout, 0, bn, 0.1)
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         o = _empty(dt, B, cout, Ho, Wo, dev) if need_o else None
         t = _empty(dt, B, cout, Ho, Wo, dev) if need_t else None
@@ -296,7 +342,7 @@ class _ConvBnFn(torch.autograd.Function):
             dx = _empty(dt, B, cin_st, H, W, dev)
             _conv_raw(dt, [dz], _pack(dt, w32, 3, True, cin, cout, cin_st, cout), _zeros(cin_st, dev), 3, cin_st, dx)
         dw = _wgrad(dt, [x], dz, w32.shape, 3, False, cin, cout, cout)
-        return dx, dw, torch.zeros(cout, dtype=torch.float32, device=dev), dgb[0], dgb[1], None, None, None, None, None, None, None, None
+        return dx, dw, _zero_grad_vec(cout, dev), dgb[0], dgb[1], None, None, None, None, None, None, None, None
 
 
 class _DenseFn(torch.autograd.Function):
@@ -309,33 +355,36 @@ class _DenseFn(torch.autograd.Function):
         dev, N = x.device, B * H * W
         gap = c0 - real_c
         ct = c0 + 64
-        grow = _empty(dt, B, 64, H, W, dev)
+        # the four growth maps: one 16-channel tensor EACH (not slices of a 64-channel one): a pixel's 32 bytes of one map are then
+        # contiguous with its neighbours', so the layer that writes it, the statistics pass and every later reader move whole
+        # cache lines (a 16-of-64 slice touches a quarter of each 128-byte line: the statistics pass ran at 1.7 TB/s)
+        grow = [_empty(dt, B, 16, H, W, dev) for _ in range(4)]
         mv = torch.empty(2, ct, dtype=torch.float32, device=dev)
-        _Bn.stats(dt, x, mv[0, :c0], mv[1, :c0])
-        ks_, consts, weights = [], [], []
+        bn_of = lambda l: (getattr(blk.layers, str(l)) if l < 4 else blk.transition_layer)._modules["0"]
+        # statistics once per segment (x, then each growth map as it is written), each pass followed in the same call by the
+        # fold of the NEXT layer's BatchNorm over everything written so far
+        k = _Bn.stats_fold(dt, x, mv, 0, c0, real_c, real_c, gap, bn_of(0), 0.1)
+        consts, weights = [], []
         for l in range(5):
-            bn_mod = (getattr(blk.layers, str(l)) if l < 4 else blk.transition_layer)._modules["0"]
-            w = _f32(params[4 * l + 2])
-            if gap:   # real input channels inside their stored positions (zero weights on the padding)
-                w = torch.cat((w[:, :real_c], w.new_zeros(w.shape[0], gap, w.shape[2], w.shape[3]), w[:, real_c:]), 1).contiguous()
-            cin_st = c0 + 16 * l
-            k = _Bn.fold(cin_st, real_c + 16 * l, real_c, gap, mv[0], mv[1], bn_mod, 0.1, N, dev)
-            segs = [x] + ([grow[:, :16 * l]] if l else [])
+            w = _f32(params[4 * l + 2])      # (real input channels; `gap`: they sit at their stored positions, zero weights on the padding)
+            cin_st, cin_real = c0 + 16 * l, real_c + 16 * l
+            segs = [x] + grow[:l]
             if l < 4:
-                out = grow[:, 16 * l:16 * l + 16]
-                _conv_raw(dt, segs, _pack(dt, w, 3, False, 16, cin_st), _f32(params[4 * l + 3]), 3, 16, out, pre=(k[0], k[1]))
-                _Bn.stats(dt, out, mv[0, cin_st:cin_st + 16], mv[1, cin_st:cin_st + 16])
+                out = grow[l]
+                _conv_raw(dt, segs, _pack(dt, w, 3, False, 16, cin_real, 16, cin_st, split=real_c, gap=gap), _f32(params[4 * l + 3]), 3, 16, out, pre=(k[0], k[1]))
+                consts.append(k)
+                k = _Bn.stats_fold(dt, out, mv, cin_st, cin_st + 16, cin_real + 16, real_c, gap, bn_of(l + 1), 0.1)
             else:
                 cout = w.shape[0]
                 cout_st = (cout + 15) // 16 * 16
-                packed = _pack(dt, w, 1, False, cout, cin_st, cout_st, cin_st)
+                packed = _pack(dt, w, 1, False, cout, cin_real, cout_st, cin_st, split=real_c, gap=gap)
                 out = _empty(dt, B, cout_st, H, W, dev)
                 y = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev) if sigmoid else None
                 _conv_raw(dt, segs, packed, _pad_vec(params[4 * l + 3], cout_st), 1, cout_st, out, pre=(k[0], k[1]),
                           act=L.ACT_SIGMOID if sigmoid else L.ACT_NONE, out_nchw3=y)
-            consts.append(k)
+                consts.append(k)
             weights.append(w)
-        ctx.save_for_backward(x, grow, mv, *consts, *weights, *([y] if sigmoid else []))
+        ctx.save_for_backward(x, mv, *grow, *consts, *weights, *([y] if sigmoid else []))
         ctx.meta = (dt, real_c, sigmoid, c0)
         return y if sigmoid else out
 
@@ -343,24 +392,24 @@ class _DenseFn(torch.autograd.Function):
     def backward(ctx, d_out):
         dt, real_c, sigmoid, c0 = ctx.meta
         saved = ctx.saved_tensors
-        x, grow, mv = saved[:3]
-        consts, weights = saved[3:8], saved[8:13]
+        x, mv, grow = saved[0], saved[1], list(saved[2:6])
+        consts, weights = saved[6:11], saved[11:16]
         B, _, H, W = x.shape
         dev, N, td = x.device, B * H * W, E.TORCH_DTYPE[dt]
         gap = c0 - real_c
         if sigmoid:
-            y = saved[13]
+            y = saved[16]
             dz = _empty(dt, B, 16, H, W, dev)
             L.check(L.lib.mdie_sigmoid_bwd_nchw3(dt, B, H, W, _f32(d_out).data_ptr(), y.data_ptr(), dz.data_ptr(), 16, _sp(dev)), "mdie_sigmoid_bwd_nchw3")
         else:
             dz = _cl(d_out.to(td))
-        gx, gg = torch.empty_like(x), torch.empty_like(grow)
+        gx, gg = torch.empty_like(x), [torch.empty_like(g) for g in grow]
         # 16-bit storage: a segment's gradient is the sum over its (up to five) consuming layers -- kept in fp32 until the
         # last consumer has added its part, then rounded ONCE into gx / gg (csrc/bn.hip bn_bwd_apply_kernel, acc32)
         acc32 = dt != L.F32 and ACC32
         if acc32:
             sx = torch.empty(x.shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-            sg = torch.empty(grow.shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+            sg = [torch.empty(g.shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last) for g in grow]
         grads = [None] * 20
         # The gradient of a feature segment (the block input x, a growth map g_s) is the sum of the BatchNorm-ReLU backward
         # terms of every layer that consumed it.  Each layer's da (gradient w.r.t. its activated input) is written ONE PLANE PER
@@ -374,22 +423,21 @@ class _DenseFn(torch.autograd.Function):
             w, k = weights[l], consts[l]
             cin_st = c0 + 16 * l
             cin_real = real_c + 16 * l
-            segs = [x] + ([grow[:, :16 * l]] if l else [])
-            gsegs = [gx] + ([gg[:, :16 * l]] if l else [])
+            segs = [x] + grow[:l]
+            gsegs = [gx] + gg[:l]
             if l == 4:
                 cout, cout_st, ks, dy = w.shape[0], dz.shape[1], 1, dz
                 mean_dy = torch.empty(2, cout_st, dtype=torch.float32, device=dev)
                 _Bn.stats(dt, dy, mean_dy[0], mean_dy[1])
                 grads[4 * l + 3] = (mean_dy[0, :cout] * N)                     # the only bias here that is not followed by a BatchNorm
             else:
-                cout, cout_st, ks, dy = 16, 16, 3, gg[:, 16 * l:16 * l + 16]   # complete: every consumer of this segment has run
-                grads[4 * l + 3] = torch.zeros(16, dtype=torch.float32, device=dev)
+                cout, cout_st, ks, dy = 16, 16, 3, gg[l]   # complete: every consumer of this segment has run
+                grads[4 * l + 3] = _zero_grad_vec(16, dev)
             # gradient w.r.t. the activated input a = relu(bn(cat(segs)))
             planar = not acc32
             da = torch.empty(cin_st // 16, N, 16, dtype=td, device=dev) if planar else _empty(dt, B, cin_st, H, W, dev)
-            _conv_raw(dt, [dy], _pack(dt, w, ks, True, cin_st, cout, cin_st, cout_st), _zeros(cin_st, dev), ks, cin_st, da, planar=planar)
-            dw = _wgrad(dt, segs, dy, (cout, cin_st, ks, ks), ks, False, cin_st, cout, cout_st, pre=(k[0], k[1]))
-            grads[4 * l + 2] = torch.cat((dw[:, :real_c], dw[:, c0:]), 1) if gap else dw
+            _conv_raw(dt, [dy], _pack(dt, w, ks, True, cin_real, cout, cin_st, cout_st, out_split=real_c, out_gap=gap), _zeros(cin_st, dev), ks, cin_st, da, planar=planar)
+            grads[4 * l + 2] = _wgrad(dt, segs, dy, (cout, cin_real, ks, ks), ks, False, cin_real, cout, cout_st, pre=(k[0], k[1]), split=real_c, gap=gap)
             # BatchNorm + ReLU backward: per-channel sums of this layer ...
             dgb = torch.empty(2, cin_real, dtype=torch.float32, device=dev)
             coef = torch.empty(2, cin_st, dtype=torch.float32, device=dev)
@@ -402,13 +450,13 @@ class _DenseFn(torch.autograd.Function):
                 d.x[i] = L.Seg(ptr, c, st)
                 ptr, c, st = _nhwc(g)
                 d.g[i] = L.Seg(ptr, c, st)
-            d.accumulate = 0 if l == 4 else 3
+            d.accumulate = 0 if l == 4 else 31
             if acc32:
                 ptr, c, st = _nhwc(sx)
                 d.acc32[0], d.final_from[0] = L.Seg(ptr, c, st), (0 if l == 0 else c0)        # x: layer 0 is its last consumer
-                if l:
-                    ptr, c, st = _nhwc(sg[:, :16 * l])
-                    d.acc32[1], d.final_from[1] = L.Seg(ptr, c, st), 16 * (l - 1)             # growth map l-1: this layer is its last consumer
+                for j in range(l):
+                    ptr, c, st = _nhwc(sg[j])
+                    d.acc32[1 + j], d.final_from[1 + j] = L.Seg(ptr, c, st), (0 if j == l - 1 else 16)   # growth map l-1: this layer is its last consumer
             if planar:
                 d.da, d.da_stride, d.da_plane = da.data_ptr(), 16, N * 16
             else:
@@ -428,7 +476,7 @@ class _DenseFn(torch.autograd.Function):
             if l == 0 and not ctx.needs_input_grad[0]:
                 continue
             off, Cs = (c0 + 16 * (l - 1), 16) if l else (0, c0)
-            xs, gs = (grow[:, 16 * (l - 1):16 * l], gg[:, 16 * (l - 1):16 * l]) if l else (x, gx)
+            xs, gs = (grow[l - 1], gg[l - 1]) if l else (x, gx)
             m = L.BnBwdMultiDesc()
             m.dtype, m.N, m.C = dt, N, Cs
             ptr, c, st = _nhwc(xs)
@@ -459,8 +507,7 @@ class _DeconvFn(torch.autograd.Function):
         y = _empty(dt, B, cout_st, H, W, dev)
         _conv_raw(dt, [x], _pack(dt, w32, 3, True, cout, cin, cout_st, cin), _pad_vec(bias, cout_st), 3, cout_st, y)
         mv = torch.empty(2, cout_st, dtype=torch.float32, device=dev)
-        _Bn.stats(dt, y, mv[0], mv[1])
-        k = _Bn.fold(cout_st, cout, cout_st, 0, mv[0], mv[1], bn, 0.1, B * H * W, dev)
+        k = _Bn.stats_fold(dt, y, mv, 0, cout_st, cout, cout_st, 0, bn, 0.1)
         Ho, Wo = (2 * H, 2 * W) if up else (H, W)
         out = _empty(dt, B, cout_st, Ho, Wo, dev)
         sptr, sc, sst = _nhwc(skip)
@@ -504,7 +551,7 @@ class _DeconvFn(torch.autograd.Function):
         # input gradient of a transposed convolution = plain convolution with the un-flipped kernel, in/out swapped
         _conv_raw(dt, [dz], _pack(dt, w32, 3, False, cin, cout, cin, cout_st), _zeros(cin, dev), 3, cin, dx)
         dw = _wgrad(dt, [x], dz, w32.shape, 3, True, cin, cout, cout_st)
-        return dx, dw, torch.zeros(cout, dtype=torch.float32, device=dev), dgb[0], dgb[1], (d_out if ctx.needs_input_grad[5] else None), None, None, None
+        return dx, dw, _zero_grad_vec(cout, dev), dgb[0], dgb[1], (d_out if ctx.needs_input_grad[5] else None), None, None, None
 
 
 # ---- the generic convolution Function (kept for callers that compose their own blocks and for the operator tests) -------
@@ -671,6 +718,7 @@ def forward_train(net, x, precision="fp32", dropout_p=0.2):
         plans[dt] = _PLAN = _PackPlan(dt)
         _PLAN.param_ptrs = ptrs
     _PLAN.run(x.device)
+    _new_zero_arena(x.device)
     B, ch, H, W = x.shape
     if ch != 3 or H % 8 or W % 8:
         raise L.MdieError(f"forward_train: input must be [B,3,H,W] with H, W multiples of 8, got {tuple(x.shape)}")

@@ -42,7 +42,7 @@ for mode in modes:
     net = CDAN(precision=prec).cuda().train()
     scaler = torch.amp.GradScaler("cuda", enabled=prec == "fp16")
     whole = mode == "graph" and dist is None and not scaler.is_enabled()
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=whole)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=whole, fused=os.environ.get("ADAM_FUSED", "1") == "1")
     buckets = T.GradBuckets(net.parameters()) if dist is not None else None
     if mode == "graph":
         if buckets is not None:
