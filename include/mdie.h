@@ -477,6 +477,9 @@ typedef struct {
   float* dgamma; float* dbeta;            /* out: [c_real] */
   float* coef;                            /* out: [2][C], consumed by mdie_bn_bwd_apply */
   void* workspace; size_t workspace_bytes;
+  int two_pass;                           /* 1: dz receives dL/dy itself (BatchNorm backward applied: no mdie_bn_bwd_apply call follows) -- a sums-only
+                                             pass, the fold, and a pass that forms the masked gradient again and stores the finished value: the
+                                             full-resolution gradient is written once and never read back */
 } mdie_bn_pool_bwd_desc;
 int mdie_bn_act_pool_bwd(const mdie_bn_pool_bwd_desc* d, void* stream);
 /* out = up2x?(relu(y * scale + shift)) + skip (skip nullable); y at [B,H,W], out / skip at [B,2H,2W] when up */

@@ -240,9 +240,15 @@ struct BnBwdPoolArgs {
   char* dz; int dz_stride;
   float* partial;
   long chunk;    // output pixels per block
+  const float* coef;   // PASS 2: [2][C] k2 = dbeta / N, k3 = dgamma / N
 };
 
-template <typename T, bool POOL>
+// PASS 0: dz and the partial sums (the caller applies mdie_bn_bwd_apply to dz afterwards: dz is written, read and written again).
+// PASS 1 / PASS 2 -- the two-pass form (mdie_bn_pool_bwd_desc.two_pass): 1 = the partial sums only, nothing stored; 2 = dz is
+// formed again from the same inputs and dL/dy = scale * (dz - k2 - xhat * k3) is stored directly: y and the (pooled: a quarter
+// of the size) upstream gradients are read twice, the full-resolution gradient is written ONCE and never read
+// (5.5 -> 4 full-tensor passes; and dz is never rounded to the storage type on its way into the formula).
+template <typename T, bool POOL, int PASS = 0>
 __global__ __launch_bounds__(BN_THREADS) void bn_act_pool_bwd_kernel(const BnBwdPoolArgs a) {
   constexpr int VEC = Traits<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) char dyn[];
@@ -257,9 +263,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_pool_bwd_kernel(const BnBwd
   for (int i = 0; i < VEC; ++i) s[0][i] = s[1][i] = 0.f;
   if (m.active) {
     const int v = m.cv;
-    float sc[VEC], sh[VEC], mu[VEC], is[VEC];
+    float sc[VEC], sh[VEC], mu[VEC], is[VEC], k2[VEC], k3[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { sc[i] = a.scale[v * VEC + i]; sh[i] = a.shift[v * VEC + i]; mu[i] = a.mean[v * VEC + i]; is[i] = a.invstd[v * VEC + i]; }
+    for (int i = 0; i < VEC; ++i) {
+      sc[i] = a.scale[v * VEC + i]; sh[i] = a.shift[v * VEC + i]; mu[i] = a.mean[v * VEC + i]; is[i] = a.invstd[v * VEC + i];
+      k2[i] = PASS == 2 ? a.coef[v * VEC + i] : 0.f; k3[i] = PASS == 2 ? a.coef[a.C + v * VEC + i] : 0.f;
+    }
     const long b = (long)blockIdx.x * a.chunk, e = min(NO, b + a.chunk);
     for (long op = b + m.row; op < e; op += m.rows) {
       float g[VEC];
@@ -297,32 +306,43 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_pool_bwd_kernel(const BnBwd
             if (z > best) { best = z; arg = k; }
           }
           const float d = best > 0.f ? g[i] : 0.f;
+          if constexpr (PASS == 2) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) dz[k][i] = k == arg ? d : 0.f;
-          float ya = yv[0][i];
+            for (int k = 0; k < 4; ++k) dz[k][i] = sc[i] * ((k == arg ? d : 0.f) - k2[i] - (yv[k][i] - mu[i]) * is[i] * k3[i]);
+          } else {
 #pragma unroll
-          for (int k = 1; k < 4; ++k) ya = k == arg ? yv[k][i] : ya;
-          s[0][i] += d;
-          s[1][i] = fmaf(d, (ya - mu[i]) * is[i], s[1][i]);
+            for (int k = 0; k < 4; ++k) dz[k][i] = k == arg ? d : 0.f;
+            float ya = yv[0][i];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) ya = k == arg ? yv[k][i] : ya;
+            s[0][i] += d;
+            s[1][i] = fmaf(d, (ya - mu[i]) * is[i], s[1][i]);
+          }
         }
+        if constexpr (PASS != 1) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          *reinterpret_cast<uint4*>(a.dz + (ip + (k >> 1) * a.W + (k & 1)) * a.dz_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(dz[k]);
+          for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<uint4*>(a.dz + (ip + (k >> 1) * a.W + (k & 1)) * a.dz_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(dz[k]);
+        }
       } else {
         float yv[VEC], dz[VEC];
         Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.y + (size_t)op * a.y_stride * sizeof(T) + (size_t)v * 16), yv);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           const float d = fmaf(yv[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
-          dz[i] = d;
-          s[0][i] += d;
-          s[1][i] = fmaf(d, (yv[i] - mu[i]) * is[i], s[1][i]);
+          if constexpr (PASS == 2) {
+            dz[i] = sc[i] * (d - k2[i] - (yv[i] - mu[i]) * is[i] * k3[i]);
+          } else {
+            dz[i] = d;
+            s[0][i] += d;
+            s[1][i] = fmaf(d, (yv[i] - mu[i]) * is[i], s[1][i]);
+          }
         }
-        *reinterpret_cast<uint4*>(a.dz + (size_t)op * a.dz_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(dz);
+        if constexpr (PASS != 1) *reinterpret_cast<uint4*>(a.dz + (size_t)op * a.dz_stride * sizeof(T) + (size_t)v * 16) = Vec16<T>::pack(dz);
       }
     }
   }
-  block_fold<VEC, 2>(s, m, CV, a.C, reinterpret_cast<float*>(dyn), a.partial);
+  if constexpr (PASS != 2) block_fold<VEC, 2>(s, m, CV, a.C, reinterpret_cast<float*>(dyn), a.partial);
 }
 
 // ---- forward: BN + ReLU (+ bilinear 2x) + skip ---------------------------------------------------------------------------
@@ -936,10 +956,18 @@ extern "C" int mdie_bn_act_pool_bwd(const mdie_bn_pool_bwd_desc* d, void* stream
   a.partial = reinterpret_cast<float*>(d->workspace);
   a.chunk = p.chunk;
   const size_t lds = (size_t)p.rows * 2 * d->C * sizeof(float);
-#define MDIE_BN_BWD(T, P) hipLaunchKernelGGL((bn_act_pool_bwd_kernel<T, P>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a)
-  MDIE_SWITCH_T(d->dtype, if (d->pool) MDIE_BN_BWD(T, true); else MDIE_BN_BWD(T, false));
+#define MDIE_BN_BWD(T, P, PASS) hipLaunchKernelGGL((bn_act_pool_bwd_kernel<T, P, PASS>), dim3(p.blocks), dim3(BN_THREADS), (PASS) == 2 ? 0 : lds, s, a)
+  if (!d->two_pass) {
+    MDIE_SWITCH_T(d->dtype, if (d->pool) MDIE_BN_BWD(T, true, 0); else MDIE_BN_BWD(T, false, 0));
+    return bn_bwd_finish("mdie_bn_act_pool_bwd", p.blocks, d->C, d->c_real, d->C, 0, (double)d->B * d->H * d->W, a.partial, d->dgamma, d->dbeta, d->coef, s);
+  }
+  MDIE_SWITCH_T(d->dtype, if (d->pool) MDIE_BN_BWD(T, true, 1); else MDIE_BN_BWD(T, false, 1));
+  if (int e = bn_bwd_finish("mdie_bn_act_pool_bwd", p.blocks, d->C, d->c_real, d->C, 0, (double)d->B * d->H * d->W, a.partial, d->dgamma, d->dbeta, d->coef, s)) return e;
+  a.coef = d->coef;
+  MDIE_SWITCH_T(d->dtype, if (d->pool) MDIE_BN_BWD(T, true, 2); else MDIE_BN_BWD(T, false, 2));
 #undef MDIE_BN_BWD
-  return bn_bwd_finish("mdie_bn_act_pool_bwd", p.blocks, d->C, d->c_real, d->C, 0, (double)d->B * d->H * d->W, a.partial, d->dgamma, d->dbeta, d->coef, s);
+  MDIE_LAUNCH_CHECK("mdie_bn_act_pool_bwd");
+  return MDIE_OK;
 }
 
 extern "C" int mdie_bn_act_up_add_fwd(int dtype, int B, int H, int W, int C, const void* y, int y_stride, const float* scale, const float* shift, int up,

@@ -61,7 +61,7 @@ class BnPoolBwdDesc(C.Structure):
                 ("d_out", C.c_void_p), ("d_out_stride", C.c_int), ("d_drop", C.c_void_p), ("d_drop_stride", C.c_int),
                 ("p", C.c_float), ("seed", C.c_uint), ("seed_dev", C.c_void_p), ("dz", C.c_void_p), ("dz_stride", C.c_int),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("coef", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("two_pass", C.c_int)]
 
 
 class BnUpBwdDesc(C.Structure):

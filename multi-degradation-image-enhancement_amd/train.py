@@ -104,9 +104,9 @@ class _PackPlan:
 
 _PLAN = None     # the plan of the network whose step is running (forward_train sets it; backward runs inside the same step)
 
-# The bias of a convolution that feeds a BatchNorm has an exactly-zero gradient (the batch mean absorbs it): 28 of the 35
+# The bias of a convolution that feeds a BatchNorm has an exactly-zero gradient (the batch mean absorbs it): 24 of the 35
 # convolutions.  Autograd still wants a tensor per parameter; they are slices of ONE zero-filled arena per step (one fill
-# launch instead of 28 -- each slice belongs to one parameter, so in-place users of .grad -- GradScaler.unscale_, gradient
+# launch instead of 24 -- each slice belongs to one parameter, so in-place users of .grad -- GradScaler.unscale_, gradient
 # clipping -- see ordinary separate tensors).
 _ZERO_ARENA = None   # [tensor, next free element]
 
@@ -335,8 +335,8 @@ class _ConvBnFn(torch.autograd.Function):
         d.dz, d.dz_stride = dz.data_ptr(), cout
         d.dgamma, d.dbeta, d.coef = dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), nws
+        d.two_pass = 1                                         # dz receives dL/dy itself (no mdie_bn_bwd_apply pass over it)
         L.check(L.lib.mdie_bn_act_pool_bwd(C.byref(d), _sp(dev)), "mdie_bn_act_pool_bwd")
-        _bn_apply_inplace(dt, y, dz, k, mv[0], coef)          # dz is now dL/dy
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _empty(dt, B, cin_st, H, W, dev)

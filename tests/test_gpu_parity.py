@@ -2005,3 +2005,185 @@ def test_small_and_ragged_extents_against_oracle(E, net, shape):
         yh = net(x.cuda())
     assert rel_to_max(yb, ref) <= BF16_TOL          # measured <= 2.4e-3
     assert rel_to_max(yh, ref) <= F16_OUT_TOL
+
+
+# ---- round 3: the entry points the faster training step added ---------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("C_new,off,C_fold,c_real,split,gap", [(64, 0, 64, 64, 64, 0), (16, 32, 48, 35, 3, 13), (16, 0, 16, 3, 3, 13)])
+def test_bn_stats_fold_equals_stats_then_fold(E, L, precision, C_new, off, C_fold, c_real, split, gap):
+    """mdie_bn_stats_fold (statistics pass + ONE final/fold launch) against mdie_bn_stats followed by mdie_bn_fold: bit-identical
+    mean / var / scale / shift / invstd / running statistics, for a plain BatchNorm, for a DenseBlock layer whose new map joins
+    earlier ones (statistics already in place), and with the final_dense channel gap."""
+    import ctypes as C
+    dt = E.dtype_id(precision)
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(2, C_new, 12, 20, generator=g) * 1.7 + 0.3).cuda().to(TORCH_DT[precision]).contiguous(memory_format=torch.channels_last)
+    N = 2 * 12 * 20
+    gamma, beta = torch.randn(c_real, generator=g).cuda(), torch.randn(c_real, generator=g).cuda()
+    old = torch.rand(2, C_fold, generator=g).cuda() + 0.1                 # statistics of the earlier maps (mean, var)
+    sp = torch.cuda.current_stream().cuda_stream
+
+    def run(fused):
+        mv = old.clone()
+        rm, rv = torch.zeros(c_real, device="cuda"), torch.ones(c_real, device="cuda")
+        k = torch.full((3, C_fold), 7.0, device="cuda")
+        nws = L.lib.mdie_bn_workspace_bytes(C_new)
+        ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+        if fused:
+            d = L.BnStatsFoldDesc()
+            d.dtype, d.N, d.x, d.C, d.stride = dt, N, x.data_ptr(), C_new, C_new
+            d.mean, d.var = mv[0, off:].data_ptr(), mv[1, off:].data_ptr()
+            d.workspace, d.workspace_bytes = ws.data_ptr(), nws
+            d.C_fold, d.C_real, d.split, d.gap = C_fold, c_real, split, gap
+            d.fold_mean, d.fold_var, d.gamma, d.beta, d.eps, d.momentum = mv[0].data_ptr(), mv[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1
+            d.running_mean, d.running_var = rm.data_ptr(), rv.data_ptr()
+            d.scale, d.shift, d.invstd = k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr()
+            L.check(L.lib.mdie_bn_stats_fold(C.byref(d), sp), "mdie_bn_stats_fold")
+        else:
+            L.check(L.lib.mdie_bn_stats(dt, N, x.data_ptr(), C_new, C_new, mv[0, off:].data_ptr(), mv[1, off:].data_ptr(), ws.data_ptr(), nws, sp), "mdie_bn_stats")
+            L.check(L.lib.mdie_bn_fold(C_fold, c_real, split, gap, mv[0].data_ptr(), mv[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, N,
+                                       rm.data_ptr(), rv.data_ptr(), k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr(), sp), "mdie_bn_fold")
+        torch.cuda.synchronize()
+        return mv, rm, rv, k
+
+    for a, b in zip(run(True), run(False)):
+        assert torch.equal(a, b)
+    mv = run(True)[0]
+    ref = x.float().permute(1, 0, 2, 3).reshape(C_new, -1)
+    assert rel_to_max(mv[0, off:off + C_new], ref.mean(1)) <= 1e-5 and rel_to_max(mv[1, off:off + C_new], ref.var(1, unbiased=False)) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_bn_stats_fold_rejects_bad_arguments(L):
+    import ctypes as C
+    d = L.BnStatsFoldDesc()
+    assert L.lib.mdie_bn_stats_fold(None, None) == -1
+    x = torch.zeros(1, 16, 8, 8, device="cuda")
+    mv, k = torch.zeros(2, 32, device="cuda"), torch.zeros(3, 32, device="cuda")
+    ws = torch.empty(L.lib.mdie_bn_workspace_bytes(16), dtype=torch.uint8, device="cuda")
+    d.dtype, d.N, d.x, d.C, d.stride = L.F32, 64, x.data_ptr(), 16, 16
+    d.mean, d.var, d.workspace, d.workspace_bytes = mv[0, 24:].data_ptr(), mv[1, 24:].data_ptr(), ws.data_ptr(), ws.numel()
+    d.C_fold, d.C_real, d.split, d.gap = 32, 32, 32, 0
+    d.fold_mean, d.fold_var, d.gamma, d.beta = mv[0].data_ptr(), mv[1].data_ptr(), k[0].data_ptr(), k[1].data_ptr()
+    d.scale, d.shift, d.invstd = k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr()
+    assert L.lib.mdie_bn_stats_fold(C.byref(d), None) == -1 and b"inside the fold range" in L.lib.mdie_last_error()   # 24 + 16 > 32
+    d.mean, d.var, d.workspace_bytes = mv[0, 16:].data_ptr(), mv[1, 16:].data_ptr(), 16
+    assert L.lib.mdie_bn_stats_fold(C.byref(d), None) == -3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("ks", [3, 1])
+def test_pack_job_places_real_channels_inside_stored_ones(E, L, precision, ks):
+    """mdie_pack_conv_weight_job with an input-channel gap (forward form) and an output-channel gap (input-gradient form) against the
+    pack of the explicitly zero-padded weight (what train.py built with torch.cat every step before): byte-identical; and the batch
+    entry over both jobs gives the same bytes."""
+    import ctypes as C
+    dt = E.dtype_id(precision)
+    g = torch.Generator().manual_seed(5)
+    cout, real_c, gap, extra = 16, 3, 13, 32
+    cin_real, cin_st = real_c + extra, real_c + gap + extra
+    w = torch.randn(cout, cin_real, ks, ks, generator=g).cuda()
+    wpad = torch.cat((w[:, :real_c], w.new_zeros(cout, gap, ks, ks), w[:, real_c:]), 1).contiguous()
+    sp = torch.cuda.current_stream().cuda_stream
+
+    def job(src, transposed, co, ci, co_st, ci_st, split, gp, osplit, ogap):
+        dst = torch.zeros(L.lib.mdie_conv_weight_bytes(dt, ks, ci_st, co_st), dtype=torch.uint8, device="cuda")
+        return L.PackJob(src.data_ptr(), dst.data_ptr(), ks, transposed, co, ci, co_st, ci_st, split, gp, osplit, ogap), dst
+
+    def run(j):
+        L.check(L.lib.mdie_pack_conv_weight_job(dt, C.byref(j[0]), sp), "mdie_pack_conv_weight_job")
+        torch.cuda.synchronize()
+        return j[1]
+
+    fwd = run(job(w, 0, cout, cin_real, cout, cin_st, real_c, gap, cout, 0))
+    fwd_ref = run(job(wpad, 0, cout, cin_st, cout, cin_st, cin_st, 0, cout, 0))
+    assert torch.equal(fwd, fwd_ref) and fwd.any()
+    # input-gradient form: the dgrad convolution's OUTPUT channels are the layer's stored input channels
+    dg = run(job(w, 1, cin_real, cout, cin_st, cout, cout, 0, real_c, gap))
+    dg_ref = run(job(wpad, 1, cin_st, cout, cin_st, cout, cout, 0, cin_st, 0))
+    assert torch.equal(dg, dg_ref) and dg.any()
+    j1, j2 = job(w, 0, cout, cin_real, cout, cin_st, real_c, gap, cout, 0), job(w, 1, cin_real, cout, cin_st, cout, cout, 0, real_c, gap)
+    table = torch.frombuffer(bytearray(bytes(j1[0]) + bytes(j2[0])), dtype=torch.uint8).cuda()
+    L.check(L.lib.mdie_pack_conv_weights_batch(dt, table.data_ptr(), 2, sp), "mdie_pack_conv_weights_batch")
+    torch.cuda.synchronize()
+    assert torch.equal(j1[1], fwd_ref) and torch.equal(j2[1], dg_ref)
+    bad = job(w, 0, cout, cin_real, cout, cin_st - 16, real_c, gap, cout, 0)[0]
+    assert L.lib.mdie_pack_conv_weight_job(dt, C.byref(bad), sp) == -1
+
+
+@pytest.mark.gpu
+def test_zero_bias_gradients_are_separate_slices_of_one_arena(E):
+    """train._zero_grad_vec: the 24 exactly-zero bias gradients of a step are slices of one zero-filled tensor -- distinct memory per
+    parameter (an in-place user of .grad such as GradScaler.unscale_ or gradient clipping must not touch a neighbour), all zero, and a
+    request past the arena's end falls back to its own tensor."""
+    import mdie_amd.train as T
+    net, _ = _train_net()
+    net = net.cuda().train()
+    x = torch.rand(2, 3, 32, 32, device="cuda")
+    net.zero_grad(set_to_none=True)
+    net(x).mean().backward()
+    zero = [(n, p) for n, p in net.named_parameters() if n.endswith("bias") and p.grad is not None and p.dim() == 1 and not p.grad.any()]
+    assert len(zero) == 24          # 4 encoder convolutions + 4 x 4 dense layers + 4 decoder stages: every bias that meets a BatchNorm
+    spans = sorted((p.grad.data_ptr(), p.grad.data_ptr() + 4 * p.grad.numel()) for _, p in zero)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+    zero[0][1].grad.add_(1.0)
+    assert all(not p.grad.any() for _, p in zero[1:])
+    T._new_zero_arena(x.device, n=8)
+    a, b = T._zero_grad_vec(8, x.device), T._zero_grad_vec(8, x.device)
+    assert a.data_ptr() != b.data_ptr() and not a.any() and not b.any() and b.numel() == 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("pool,p", [(True, 0.2), (True, 0.0), (False, 0.2)])
+def test_pool_bwd_two_pass_equals_masked_gradient_then_apply(E, L, precision, pool, p):
+    """mdie_bn_act_pool_bwd with two_pass = 1 (sums-only pass, fold, a pass that stores dL/dy directly) against the original form
+    (masked gradient dz stored, mdie_bn_bwd_apply over it): same dgamma / dbeta / coef bit for bit (the sums never saw the stored
+    dz), and dL/dy equal up to the one rounding of dz to the storage type that the two-pass form no longer makes."""
+    import ctypes as C
+    dt = E.dtype_id(precision)
+    td = TORCH_DT[precision]
+    g = torch.Generator().manual_seed(21)
+    B, H, W, Cc = 2, 12, 20, 64
+    cl = lambda t: t.cuda().to(td).contiguous(memory_format=torch.channels_last)
+    y = cl(torch.randn(B, Cc, H, W, generator=g))
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    d_o, d_t = cl(torch.randn(B, Cc, Ho, Wo, generator=g)), cl(torch.randn(B, Cc, Ho, Wo, generator=g))
+    mean, var = y.float().mean((0, 2, 3)), y.float().var((0, 2, 3), unbiased=False)
+    gamma, beta = torch.rand(Cc, generator=g).cuda() + 0.5, torch.randn(Cc, generator=g).cuda() * 0.1
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    sp = torch.cuda.current_stream().cuda_stream
+
+    def run(two_pass):
+        dz = torch.full_like(y, 3.0)
+        dgb, coef = torch.zeros(2, Cc, device="cuda"), torch.zeros(2, Cc, device="cuda")
+        ws = torch.empty(L.lib.mdie_bn_workspace_bytes(Cc), dtype=torch.uint8, device="cuda")
+        d = L.BnPoolBwdDesc()
+        d.dtype, d.B, d.H, d.W, d.C, d.c_real = dt, B, H, W, Cc, Cc
+        d.y, d.y_stride = y.data_ptr(), Cc
+        d.scale, d.shift, d.mean, d.invstd, d.pool = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), int(pool)
+        d.d_out, d.d_out_stride, d.d_drop, d.d_drop_stride = d_o.data_ptr(), Cc, d_t.data_ptr(), Cc
+        d.p, d.seed, d.seed_dev = p, 1234, None
+        d.dz, d.dz_stride = dz.data_ptr(), Cc
+        d.dgamma, d.dbeta, d.coef = dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr()
+        d.workspace, d.workspace_bytes, d.two_pass = ws.data_ptr(), ws.numel(), two_pass
+        L.check(L.lib.mdie_bn_act_pool_bwd(C.byref(d), sp), "mdie_bn_act_pool_bwd")
+        if not two_pass:
+            a = L.BnBwdDesc()
+            a.dtype, a.N, a.nseg = dt, B * H * W, 1
+            a.x[0], a.g[0] = L.Seg(y.data_ptr(), Cc, Cc), L.Seg(dz.data_ptr(), Cc, Cc)
+            a.accumulate, a.da, a.da_stride = 0, dz.data_ptr(), Cc
+            a.mean, a.invstd, a.scale, a.shift, a.relu, a.coef = mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0, coef.data_ptr()
+            L.check(L.lib.mdie_bn_bwd_apply(C.byref(a), sp), "mdie_bn_bwd_apply")
+        torch.cuda.synchronize()
+        return dz.float(), dgb, coef
+
+    dz2, dgb2, coef2 = run(1)
+    dz0, dgb0, coef0 = run(0)
+    assert torch.equal(dgb2, dgb0) and torch.equal(coef2, coef0)
+    assert rel_to_max(dz2, dz0) <= {"fp32": 1e-6, "fp16": 2e-3, "bf16": 1.6e-2}[precision]
+    assert float(dz2.abs().max()) > 0.1
