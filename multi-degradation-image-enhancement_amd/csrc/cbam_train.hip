@@ -16,7 +16,7 @@
 namespace mdie {
 
 constexpr int CT_THREADS = 256;
-constexpr int CT_MAX_SLABS = 16;
+constexpr int CT_MAX_SLABS = 64;   // x B workgroups in the pooling pass (16 left half the CUs of an 8-image step idle: 1.4 TB/s)
 constexpr int CT_MIN_SLAB = 128;
 constexpr int CT_TS = 16, CT_PW = CT_TS + 6;
 
@@ -106,10 +106,13 @@ __global__ __launch_bounds__(CT_THREADS) void cbt_gate_kernel(const CbtArgs a) {
   for (int c = tid; c < a.C; c += CT_THREADS) {
     float s = 0.f, m = -INFINITY;
     int ii = 0x7fffffff;
+#pragma unroll 8
     for (int k = 0; k < a.nslab; ++k) {
       const size_t o = ((size_t)img * a.nslab + k) * a.C + c;
+      const float pm = a.pmax[o];
+      const int pi = a.pidx[o];
       s += a.psum[o];
-      if (a.pmax[o] > m || (a.pmax[o] == m && a.pidx[o] < ii)) { m = a.pmax[o]; ii = a.pidx[o]; }
+      if (pm > m || (pm == m && pi < ii)) { m = pm; ii = pi; }
     }
     avg[c] = s * inv; mx[c] = m;
     a.pooled[((size_t)img * 2 + 0) * a.C + c] = s * inv;
@@ -117,11 +120,18 @@ __global__ __launch_bounds__(CT_THREADS) void cbt_gate_kernel(const CbtArgs a) {
     a.amax_idx[(size_t)img * a.C + c] = ii;
   }
   __syncthreads();
-  for (int j = tid; j < Hd; j += CT_THREADS) {
-    float sa = a.b1[j], sm = a.b1[j];
-    const float* w = a.w1 + (size_t)j * a.C;
-    for (int c = 0; c < a.C; ++c) { sa = fmaf(w[c], avg[c], sa); sm = fmaf(w[c], mx[c], sm); }
-    hid[j] = fmaxf(sa, 0.f) + fmaxf(sm, 0.f);
+  {
+    // hidden unit j over LPJ = 256 / Hd lanes (8 .. 64: C = 512 .. 64), each a strided run of channels: consecutive lanes read
+    // consecutive weights (one thread per unit walked its whole row alone: 512 dependent, uncoalesced steps -- 39 us at C = 512)
+    const int LPJ = Hd >= 4 ? CT_THREADS / Hd : 64, j = tid / LPJ, q = tid - j * LPJ;   // (C < 64: whole waves past unit Hd - 1 idle)
+    if (j < Hd) {
+      float sa = 0.f, sm = 0.f;
+      const float* w = a.w1 + (size_t)j * a.C;
+#pragma unroll 4
+      for (int c = q; c < a.C; c += LPJ) { sa = fmaf(w[c], avg[c], sa); sm = fmaf(w[c], mx[c], sm); }
+      for (int d = LPJ >> 1; d > 0; d >>= 1) { sa += __shfl_xor(sa, d); sm += __shfl_xor(sm, d); }
+      if (q == 0) hid[j] = fmaxf(sa + a.b1[j], 0.f) + fmaxf(sm + a.b1[j], 0.f);
+    }
   }
   __syncthreads();
   for (int c = tid; c < a.C; c += CT_THREADS) {

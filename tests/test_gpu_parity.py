@@ -1796,7 +1796,7 @@ _ORACLE_TRAIN_STEP = {}
                                                                      # 1x1 maps at the deep end: BatchNorm over TWO samples normalises to exactly +-1, the true gradient
                                                                      # through it is ~0 and what is left is summation-order noise -> direction only loosely pinned there
                                                                      ("fp32", (2, 8, 8), 0.95, 0.9999, 2e-4),
-                                                                     ("bf16", (2, 64, 64), 0.87, 0.98, 3e-2),     # measured: worst 0.8934-0.8966, median 0.9870
+                                                                     ("bf16", (2, 64, 64), 0.87, 0.98, 4e-2),     # measured: worst 0.8934-0.9176, median 0.9870, output 2.9e-2 .. 3.1e-2 (moves with the fp32 summation ORDER of the CBAM gate's hidden layer: 128-sample BatchNorms downstream)
                                                                      # fp16 = the reference's own autocast dtype: gradients need its GradScaler (models/model.py:31,164)
                                                                      ("fp16", (2, 64, 64), 0.986, 0.9975, 8e-3),      # measured: worst 0.9931, median 0.99874, output 3.9e-3
                                                                      # 256x256: the kernel selection of BASELINE configs[2] (512x512, B=8/GPU) -- B=2: encoder.conv2 has 2*8*4*2 = 128
