@@ -18,6 +18,7 @@ namespace mdie {
 constexpr int CT_THREADS = 256;
 constexpr int CT_MAX_SLABS = 64;   // x B workgroups in the pooling pass (16 left half the CUs of an 8-image step idle: 1.4 TB/s)
 constexpr int CT_MIN_SLAB = 128;
+constexpr int CT_MAX_GX = 256;     // x B workgroups in the per-pixel passes (64: two workgroups per CU at B = 8, 2.6 TB/s)
 constexpr int CT_TS = 16, CT_PW = CT_TS + 6;
 
 struct CbtArgs {
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(CT_THREADS) void cbt_gate_bwd_kernel(const CbtArgs 
   float* pg = a.pgrad + (size_t)img * (2 * (size_t)Hd * C + Hd + C);
   for (int c = tid; c < C; c += CT_THREADS) {
     float dg = 0.f;
+#pragma unroll 8
     for (int k = 0; k < a.gx; ++k) dg += a.partC[((size_t)img * a.gx + k) * C + c];
     const float g = a.gate[(size_t)img * C + c];
     datt[c] = dg * g * (1.f - g);
@@ -564,7 +566,7 @@ static size_t ct256(size_t v) { return (v + 255) & ~(size_t)255; }
 static int ct_nslab(int H, int W) { const int n = cdiv(H * W, CT_MIN_SLAB); return n < CT_MAX_SLABS ? n : CT_MAX_SLABS; }
 static int ct_gx(int H, int W, int groups) {
   int gx = cdiv(H * W, groups * 4);
-  if (gx > 64) gx = 64;
+  if (gx > CT_MAX_GX) gx = CT_MAX_GX;
   return gx < 1 ? 1 : gx;
 }
 
@@ -572,14 +574,14 @@ struct CtWs { size_t psum, pmax, pidx, part2, part98, partC, pgrad, dn, dcomp, d
 static CtWs ct_ws(int B, int H, int W, int C) {
   CtWs w{};
   const size_t tiles = (size_t)cdiv(W, CT_TS) * cdiv(H, CT_TS);
-  const size_t n2 = (size_t)B * (tiles > 64 ? tiles : 64);
+  const size_t n2 = (size_t)B * (tiles > CT_MAX_GX ? tiles : CT_MAX_GX);
   size_t o = 0;
   w.psum = o; o += ct256((size_t)B * CT_MAX_SLABS * C * 4);
   w.pmax = o; o += ct256((size_t)B * CT_MAX_SLABS * C * 4);
   w.pidx = o; o += ct256((size_t)B * CT_MAX_SLABS * C * 4);
   w.part2 = o; o += ct256(n2 * 2 * 4);
   w.part98 = o; o += ct256((size_t)B * tiles * 98 * 4);
-  w.partC = o; o += ct256((size_t)B * 64 * C * 4);
+  w.partC = o; o += ct256((size_t)B * CT_MAX_GX * C * 4);
   w.pgrad = o; o += ct256((size_t)B * (2 * (size_t)(C / 16) * C + C / 16 + C) * 4);
   w.dn = o; o += ct256((size_t)B * H * W * 4);
   w.dcomp = o; o += ct256((size_t)B * H * W * 2 * 4);
