@@ -104,21 +104,42 @@ __global__ __launch_bounds__(CT_THREADS) void cbt_gate_kernel(const CbtArgs a) {
   float* mx = avg + a.C;
   float* hid = mx + a.C;      // [Hd]
   const float inv = 1.0f / (float)(a.H * a.W);
-  for (int c = tid; c < a.C; c += CT_THREADS) {
-    float s = 0.f, m = -INFINITY;
-    int ii = 0x7fffffff;
-#pragma unroll 8
-    for (int k = 0; k < a.nslab; ++k) {
-      const size_t o = ((size_t)img * a.nslab + k) * a.C + c;
-      const float pm = a.pmax[o];
-      const int pi = a.pidx[o];
-      s += a.psum[o];
-      if (pm > m || (pm == m && pi < ii)) { m = pm; ii = pi; }
+  {
+    // fold the slabs: channel c by 256 / C threads (C < 256), each a strided share of the slabs, combined in slab order through LDS
+    // (one thread per channel left 3/4 of the block idle at C = 64 and walked 64 slabs alone)
+    const int parts = a.C < CT_THREADS ? CT_THREADS / a.C : 1;
+    float* fs = hid + Hd;                 // [parts][C] sums, maxima, indices
+    float* fm = fs + parts * a.C;
+    int* fi = reinterpret_cast<int*>(fm + parts * a.C);
+    for (int u = tid; u < parts * a.C; u += CT_THREADS) {
+      const int c = u % a.C, part = u / a.C;
+      float s = 0.f, m = -INFINITY;
+      int ii = 0x7fffffff;
+#pragma unroll 4
+      for (int k = part; k < a.nslab; k += parts) {
+        const size_t o = ((size_t)img * a.nslab + k) * a.C + c;
+        const float pm = a.pmax[o];
+        const int pi = a.pidx[o];
+        s += a.psum[o];
+        if (pm > m || (pm == m && pi < ii)) { m = pm; ii = pi; }
+      }
+      fs[u] = s; fm[u] = m; fi[u] = ii;
     }
-    avg[c] = s * inv; mx[c] = m;
-    a.pooled[((size_t)img * 2 + 0) * a.C + c] = s * inv;
-    a.pooled[((size_t)img * 2 + 1) * a.C + c] = m;
-    a.amax_idx[(size_t)img * a.C + c] = ii;
+    __syncthreads();
+    for (int c = tid; c < a.C; c += CT_THREADS) {
+      float s = 0.f, m = -INFINITY;
+      int ii = 0x7fffffff;
+      for (int part = 0; part < parts; ++part) {
+        const float pm = fm[part * a.C + c];
+        const int pi = fi[part * a.C + c];
+        s += fs[part * a.C + c];
+        if (pm > m || (pm == m && pi < ii)) { m = pm; ii = pi; }
+      }
+      avg[c] = s * inv; mx[c] = m;
+      a.pooled[((size_t)img * 2 + 0) * a.C + c] = s * inv;
+      a.pooled[((size_t)img * 2 + 1) * a.C + c] = m;
+      a.amax_idx[(size_t)img * a.C + c] = ii;
+    }
   }
   __syncthreads();
   {
@@ -481,26 +502,30 @@ __global__ __launch_bounds__(CT_THREADS) void cbt_gate_bwd_kernel(const CbtArgs 
   }
   __syncthreads();
   {
-    // hidden unit j is split over `parts` threads, each a contiguous run of channels (all loads in flight at once)
-    const int parts = CT_THREADS / Hd, run = C / parts > 0 ? C / parts : 1;
-    const int j = tid / parts, q = tid - j * parts;
-    float sa = 0.f, sm = 0.f, dh = 0.f;
-    if (j < Hd && q * run < C) {
-      const int c0 = q * run;
-      const float* w = a.w1 + (size_t)j * C + c0;
-      for (int i = 0; i < run; ++i) {
-        sa = fmaf(w[i], avg[c0 + i], sa); sm = fmaf(w[i], mx[c0 + i], sm);
-        dh = fmaf(a.w2[(size_t)(c0 + i) * Hd + j], datt[c0 + i], dh);
-      }
+    // forward pre-activations of hidden unit j: LPJ lanes walk row j of W1 together (consecutive lanes, consecutive weights), as in
+    // cbt_gate_kernel; dh[j] = sum_c W2[c][j] datt[c]: W2 is read in its memory order (thread t keeps unit t % Hd and channels
+    // t / Hd + k * 256 / Hd), the per-thread sums are folded per unit in a fixed order.  (Both were contiguous runs per thread --
+    // every load instruction touched 64 cache lines: 20 - 58 us per launch on 8 workgroups.)
+    const int LPJ = Hd >= 4 ? CT_THREADS / Hd : 64, j = tid / LPJ, q = tid - j * LPJ;
+    if (j < Hd) {
+      float sa = 0.f, sm = 0.f;
+      const float* w = a.w1 + (size_t)j * C;
+#pragma unroll 4
+      for (int c = q; c < C; c += LPJ) { sa = fmaf(w[c], avg[c], sa); sm = fmaf(w[c], mx[c], sm); }
+      for (int d = LPJ >> 1; d > 0; d >>= 1) { sa += __shfl_xor(sa, d); sm += __shfl_xor(sm, d); }
+      if (q == 0) { pa[j] = sa + a.b1[j]; pm[j] = sm + a.b1[j]; }
     }
-    part[tid] = sa; part[CT_THREADS + tid] = sm; part[2 * CT_THREADS + tid] = dh;
+    const int j2 = tid % Hd, cstep = CT_THREADS / Hd;
+    float dh = 0.f;
+#pragma unroll 4
+    for (int c = tid / Hd; c < C; c += cstep) dh = fmaf(a.w2[(size_t)c * Hd + j2], datt[c], dh);
+    part[tid] = dh;
     __syncthreads();
     if (tid < Hd) {
-      float ta = a.b1[tid], tm = a.b1[tid], th = 0.f;
-      for (int k = 0; k < parts; ++k) { ta += part[tid * parts + k]; tm += part[CT_THREADS + tid * parts + k]; th += part[2 * CT_THREADS + tid * parts + k]; }
-      pa[tid] = ta; pm[tid] = tm;
-      dpa[tid] = ta > 0.f ? th : 0.f;
-      dpm[tid] = tm > 0.f ? th : 0.f;
+      float th = 0.f;
+      for (int k = 0; k < cstep; ++k) th += part[tid + Hd * k];
+      dpa[tid] = pa[tid] > 0.f ? th : 0.f;
+      dpm[tid] = pm[tid] > 0.f ? th : 0.f;
       pg[2 * (size_t)Hd * C + tid] = dpa[tid] + dpm[tid];                      // db1
     }
   }
@@ -566,7 +591,8 @@ static size_t ct256(size_t v) { return (v + 255) & ~(size_t)255; }
 static int ct_nslab(int H, int W) { const int n = cdiv(H * W, CT_MIN_SLAB); return n < CT_MAX_SLABS ? n : CT_MAX_SLABS; }
 static int ct_gx(int H, int W, int groups) {
   int gx = cdiv(H * W, groups * 4);
-  if (gx > CT_MAX_GX) gx = CT_MAX_GX;
+  const int cap = 16 * groups < CT_MAX_GX ? 16 * groups : CT_MAX_GX;   // wide tensors (C >= 256: 4 / 8 pixel groups per block) are small maps: fewer
+  if (gx > cap) gx = cap;                                             // partials for cbt_gate_bwd_kernel's one block per image to fold
   return gx < 1 ? 1 : gx;
 }
 
@@ -627,7 +653,7 @@ static int ct_forward(const mdie_cbam_train_desc* d, CbtArgs& a, hipStream_t s) 
   const int gx = ct_gx(d->H, d->W, groups);
   const int tiles = cdiv(d->W, CT_TS) * cdiv(d->H, CT_TS);
   hipLaunchKernelGGL((cbt_pool_kernel<T>), dim3(a.nslab, d->B), dim3(CT_THREADS), (size_t)3 * rows * d->C * 4, s, a);
-  hipLaunchKernelGGL(cbt_gate_kernel, dim3(d->B), dim3(CT_THREADS), (size_t)(2 * d->C + d->C / 16) * 4, s, a);
+  hipLaunchKernelGGL(cbt_gate_kernel, dim3(d->B), dim3(CT_THREADS), (size_t)(2 * d->C + d->C / 16 + 3 * (d->C > CT_THREADS ? d->C : CT_THREADS)) * 4, s, a);
   if (NV == 1) hipLaunchKernelGGL((cbt_chanpool_kernel<T, 1>), dim3(gx, d->B), dim3(CT_THREADS), 0, s, a, LPP);
   else hipLaunchKernelGGL((cbt_chanpool_kernel<T, 2>), dim3(gx, d->B), dim3(CT_THREADS), 0, s, a, LPP);
   hipLaunchKernelGGL(cbt_conv7_kernel, dim3(tiles, d->B), dim3(CT_THREADS), 0, s, a);

@@ -287,17 +287,25 @@ struct LossFinal {
 // one block: ordered double-precision sums of the partials -> values[0..nterms-1], values[nterms] = weighted total
 __global__ __launch_bounds__(LS_THREADS) void loss_final_kernel(LossFinal f, const float* pw_part, const float* spart, const float* gpart,
                                                                 float* values) {
-  __shared__ double red[5][LS_THREADS];
+  __shared__ double red[5][LS_THREADS / 64];
   double s[5] = {0, 0, 0, 0, 0};
   for (int i = threadIdx.x; i < f.n_pw; i += LS_THREADS) { s[0] += pw_part[i * 3]; s[1] += pw_part[i * 3 + 1]; s[2] += pw_part[i * 3 + 2]; }
-  for (int i = threadIdx.x; i < f.n_ssim; i += LS_THREADS) s[3] += spart[i];
+#pragma unroll 8
+  for (int i = threadIdx.x; i < f.n_ssim; i += LS_THREADS) s[3] += spart[i];     // (one partial per 16x16 tile and plane: 24 k at 8 x 512 x 512)
+#pragma unroll 8
   for (int i = threadIdx.x; i < f.n_sobel; i += LS_THREADS) s[4] += gpart[i];
-  for (int k = 0; k < 5; ++k) red[k][threadIdx.x] = s[k];
+  // fixed-shape tree: lanes of a wave by shuffles, then the waves in order (thread 0 alone walked 5 x 256 LDS values: 33 us)
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s[k] += __shfl_xor(s[k], d);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
+  }
   __syncthreads();
   if (threadIdx.x != 0) return;
   for (int k = 0; k < 5; ++k) {
     double t = 0.0;
-    for (int i = 0; i < LS_THREADS; ++i) t += red[k][i];
+    for (int i = 0; i < LS_THREADS / 64; ++i) t += red[k][i];
     s[k] = t;
   }
   double total = 0.0;
