@@ -195,8 +195,71 @@ def _pad_vec(v, n):
     return v if v.numel() == n else F.pad(v, (0, n - v.numel()))
 
 
-def _wgrad(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre=None, split=None, gap=0):
+# Weight gradients on a stream of their own.  Nothing in backward waits for a dW -- the chain is input gradient -> BatchNorm
+# backward -> input gradient -- and that chain is full of kernels that leave the GPU nearly idle (the *_final folds, the gates,
+# the 32x32 / 64x64 layers): the weight-gradient kernels (1.8 ms of an 8.4 ms step) run under them.  Fork: the side stream waits for
+# the main stream at the point of the call (dy and every input are complete in main-stream order); join: ONE wait of the main
+# stream for the side stream when backward ends (an autograd-engine callback queued from the first call of each backward), so
+# the optimizer, the GradScaler, a gradient exchange that runs after backward -- everything that reads .grad -- comes after.
+# Not taken when something reads .grad DURING backward: a parameter that already holds a gradient (accumulation adds in place
+# on the main stream) or GradBuckets' per-parameter hooks.  And only where it pays (measured, bf16, B = 8, same box): eager 512x512
+# 8.69 -> 8.11 ms; as a hipGraph 8.71 -> 8.73 (the replay gains nothing from the second branch) and 256x256 3.85 -> 4.21 as a graph,
+# 7.06 -> 8.87 eager (host-bound: the stream switches and record_stream calls cost more than the overlap returns) -- so: eager steps
+# of at least WGRAD_STREAM_MIN_PIXELS input pixels (the size from which Model.train_step stops capturing), never under capture.
+WGRAD_STREAM = __import__("os").environ.get("MDIE_TRAIN_WGRAD_STREAM", "1") == "1"
+WGRAD_STREAM_MIN_PIXELS = 8 * 384 * 384
+_wgrad_side_this_step = False  # forward_train decides per step
+_WGRAD_SIDE = {}
+_wgrad_hooks_active = 0        # GradBuckets with hooks registered
+_wgrad_join_queued = set()     # devices whose join callback is queued in the running backward
+
+
+def _wgrad_side_stream(dev):
+    st = _WGRAD_SIDE.get(dev)
+    if st is None:
+        st = _WGRAD_SIDE[dev] = torch.cuda.Stream(dev)
+    return st
+
+
+def _queue_wgrad_join(dev, main):
+    """`main`: the stream backward runs on, taken inside a Function.backward (the engine has set it to the forward's stream there).
+    The callback itself may run on an autograd worker thread whose current stream is the device's default one -- under graph
+    capture that is NOT the capturing stream -- so the stream to join is fixed here, not looked up there."""
+    if dev in _wgrad_join_queued:
+        return
+    _wgrad_join_queued.add(dev)
+
+    def join():
+        _wgrad_join_queued.discard(dev)
+        main.wait_stream(_wgrad_side_stream(dev))
+
+    torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
+def join_weight_gradients(dev):
+    """make the current stream wait for weight gradients still running on the side stream (idempotent; backward's own callback
+    has normally done it already)"""
+    st = _WGRAD_SIDE.get(torch.device(dev) if not isinstance(dev, torch.device) else dev)
+    if st is not None:
+        torch.cuda.current_stream(dev).wait_stream(st)
+
+
+def _wgrad(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre=None, split=None, gap=0, param=None):
     """dW in the parameter's layout from the convolution's input segments and dy (stored cout_st channels)."""
+    dev = dy.device
+    if _wgrad_side_this_step and WGRAD_STREAM and _wgrad_hooks_active == 0 and param is not None and param.grad is None:
+        main, side = torch.cuda.current_stream(dev), _wgrad_side_stream(dev)
+        side.wait_stream(main)
+        _queue_wgrad_join(dev, main)
+        with torch.cuda.stream(side):
+            dw = _wgrad_launch(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre, split, gap)
+        for t in list(segs) + [dy] + (list(pre) if pre is not None else []):
+            t.record_stream(side)          # allocated on the main stream, read on the side stream
+        return dw
+    return _wgrad_launch(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre, split, gap)
+
+
+def _wgrad_launch(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre, split, gap):
     B, _, H, W = dy.shape
     dev = dy.device
     cin_st = sum(s.shape[1] for s in segs)
@@ -303,6 +366,7 @@ class _ConvBnFn(torch.autograd.Function):
         ctx.save_for_backward(x, w32, y, k, mv)
         ctx.set_materialize_grads(False)
         ctx.meta = (dt, pool, p, seed, cin, cout, need_o, need_t)
+        ctx.wparam = weight
         ctx.seed_dev = seed_dev
         outs = tuple(v for v in (o, t) if v is not None)
         return outs if len(outs) > 1 else outs[0]
@@ -341,7 +405,7 @@ class _ConvBnFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _empty(dt, B, cin_st, H, W, dev)
             _conv_raw(dt, [dz], _pack(dt, w32, 3, True, cin, cout, cin_st, cout), _zeros(cin_st, dev), 3, cin_st, dx)
-        dw = _wgrad(dt, [x], dz, w32.shape, 3, False, cin, cout, cout)
+        dw = _wgrad(dt, [x], dz, w32.shape, 3, False, cin, cout, cout, param=ctx.wparam)
         return dx, dw, _zero_grad_vec(cout, dev), dgb[0], dgb[1], None, None, None, None, None, None, None, None
 
 
@@ -386,6 +450,7 @@ class _DenseFn(torch.autograd.Function):
             weights.append(w)
         ctx.save_for_backward(x, mv, *grow, *consts, *weights, *([y] if sigmoid else []))
         ctx.meta = (dt, real_c, sigmoid, c0)
+        ctx.wparams = [params[4 * l + 2] for l in range(5)]
         return y if sigmoid else out
 
     @staticmethod
@@ -437,7 +502,8 @@ class _DenseFn(torch.autograd.Function):
             planar = not acc32
             da = torch.empty(cin_st // 16, N, 16, dtype=td, device=dev) if planar else _empty(dt, B, cin_st, H, W, dev)
             _conv_raw(dt, [dy], _pack(dt, w, ks, True, cin_real, cout, cin_st, cout_st, out_split=real_c, out_gap=gap), _zeros(cin_st, dev), ks, cin_st, da, planar=planar)
-            grads[4 * l + 2] = _wgrad(dt, segs, dy, (cout, cin_real, ks, ks), ks, False, cin_real, cout, cout_st, pre=(k[0], k[1]), split=real_c, gap=gap)
+            grads[4 * l + 2] = _wgrad(dt, segs, dy, (cout, cin_real, ks, ks), ks, False, cin_real, cout, cout_st, pre=(k[0], k[1]), split=real_c, gap=gap,
+                                      param=ctx.wparams[l])
             # BatchNorm + ReLU backward: per-channel sums of this layer ...
             dgb = torch.empty(2, cin_real, dtype=torch.float32, device=dev)
             coef = torch.empty(2, cin_st, dtype=torch.float32, device=dev)
@@ -516,6 +582,7 @@ class _DeconvFn(torch.autograd.Function):
                                              out.data_ptr(), cout_st, _sp(dev)), "mdie_bn_act_up_add_fwd")
         ctx.save_for_backward(x, w32, y, k, mv)
         ctx.meta = (dt, up, cin, cout, cout_st)
+        ctx.wparam = weight
         return out
 
     @staticmethod
@@ -550,7 +617,7 @@ class _DeconvFn(torch.autograd.Function):
         dx = _empty(dt, B, cin, H, W, dev)
         # input gradient of a transposed convolution = plain convolution with the un-flipped kernel, in/out swapped
         _conv_raw(dt, [dz], _pack(dt, w32, 3, False, cin, cout, cin, cout_st), _zeros(cin, dev), 3, cin, dx)
-        dw = _wgrad(dt, [x], dz, w32.shape, 3, True, cin, cout, cout_st)
+        dw = _wgrad(dt, [x], dz, w32.shape, 3, True, cin, cout, cout_st, param=ctx.wparam)
         return dx, dw, _zero_grad_vec(cout, dev), dgb[0], dgb[1], (d_out if ctx.needs_input_grad[5] else None), None, None, None
 
 
@@ -570,6 +637,7 @@ class _ConvFn(torch.autograd.Function):
         _conv_raw(dtype, list(segs), _pack(dtype, w32, ks, transposed, cout, cin), _f32(bias), ks, cout, out)
         ctx.save_for_backward(w32, *segs)
         ctx.meta = (dtype, transposed, ks, cout, cin)
+        ctx.wparam = weight
         return out
 
     @staticmethod
@@ -582,7 +650,7 @@ class _ConvFn(torch.autograd.Function):
         # input gradient: the same convolution with the in/out-swapped, flipped kernel
         dx = _empty(dtype, B, cin, H, W, dev)
         _conv_raw(dtype, [dy], _pack(dtype, w32, ks, not transposed, cin, cout), _zeros(cin, dev), ks, cin, dx)
-        dw = _wgrad(dtype, list(segs), dy, w32.shape, ks, transposed, cin, cout, cout)
+        dw = _wgrad(dtype, list(segs), dy, w32.shape, ks, transposed, cin, cout, cout, param=ctx.wparam)
         db = dy.float().sum(dim=(0, 2, 3))
         grads, c0 = [], 0
         for s in segs:
@@ -720,6 +788,8 @@ def forward_train(net, x, precision="fp32", dropout_p=0.2):
     _PLAN.run(x.device)
     _new_zero_arena(x.device)
     B, ch, H, W = x.shape
+    global _wgrad_side_this_step
+    _wgrad_side_this_step = WGRAD_STREAM and B * H * W >= WGRAD_STREAM_MIN_PIXELS and not torch.cuda.is_current_stream_capturing()
     if ch != 3 or H % 8 or W % 8:
         raise L.MdieError(f"forward_train: input must be [B,3,H,W] with H, W multiples of 8, got {tuple(x.shape)}")
     xin = _empty(dt, B, 16, H, W, x.device)
@@ -784,6 +854,7 @@ class CapturedStep:
         def fwd_bwd():
             total, values = losses(net(self.x), self.t)
             (scale_fn(total) if scale_fn is not None else total).backward()
+            join_weight_gradients(dev)
             return values
 
         targets = list(net.buffers())           # what a training-mode forward advances besides the parameters
@@ -868,6 +939,8 @@ class GradBuckets:
         self._pending = [len(b) for b in self.buckets]
         self._work = [None] * len(self.buckets)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in self.buckets for p in b]
+        global _wgrad_hooks_active
+        _wgrad_hooks_active += 1      # the hooks read .grad during backward: weight gradients stay on the main stream (_wgrad)
 
     def _on_grad(self, p):
         bi, off = self._where[p]
@@ -909,5 +982,8 @@ class GradBuckets:
         self.finish()
 
     def remove(self):
+        global _wgrad_hooks_active
+        if self._hooks:
+            _wgrad_hooks_active = max(0, _wgrad_hooks_active - 1)
         for h in self._hooks:
             h.remove()

@@ -2187,3 +2187,41 @@ def test_pool_bwd_two_pass_equals_masked_gradient_then_apply(E, L, precision, po
     assert torch.equal(dgb2, dgb0) and torch.equal(coef2, coef0)
     assert rel_to_max(dz2, dz0) <= {"fp32": 1e-6, "fp16": 2e-3, "bf16": 1.6e-2}[precision]
     assert float(dz2.abs().max()) > 0.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,shape", [("bf16", (4, 64, 64)), ("fp16", (2, 128, 128)), ("bf16", (2, 256, 256)), ("bf16", (8, 512, 512))])
+def test_side_stream_weight_gradients_equal_main_stream(E, precision, shape, monkeypatch):
+    """train.WGRAD_STREAM: weight gradients launched on a stream of their own (forked at the call, joined once when backward ends)
+    against the same three optimizer steps with everything on one stream: losses, parameters and buffers bit-identical -- any
+    difference is a race (a dW read before its kernel finished, an input overwritten or recycled while the side stream read it)."""
+    import mdie_amd.train as T
+    from models.cdan import CDAN
+    from oracle import params as P
+    sd = P.make_state_dict(42)
+    batches = [tuple(v.cuda() for v in P.lowlight_batch(5 + i, *shape)) for i in range(3)]
+
+    monkeypatch.setattr(T, "WGRAD_STREAM_MIN_PIXELS", 0)       # (the small shapes too: by default only steps >= 8 x 384 x 384 pixels fork)
+
+    def run(side):
+        monkeypatch.setattr(T, "WGRAD_STREAM", side)
+        torch.manual_seed(123)
+        net = CDAN(precision=precision)
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+        losses = []
+        for x, t in batches:
+            opt.zero_grad(set_to_none=True)
+            loss = torch.sqrt((net(x) - t) ** 2 + 1e-6).mean()
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        return losses, [p.detach().clone() for p in net.parameters()], [b.clone() for b in net.buffers()]
+
+    a, b = run(True), run(False)
+    assert all(torch.equal(u, v) for u, v in zip(a[0], b[0]))
+    bad = [n for (n, _), u, v in zip(CDAN().named_parameters(), a[1], b[1]) if not torch.equal(u, v)]
+    assert not bad, f"parameters differ: {bad[:6]}"
+    assert all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
