@@ -420,7 +420,7 @@ class Model:
         # One hipGraph per batch shape (train.CapturedStep; MDIE_TRAIN_GRAPH=0 turns it off): forward + loss + backward, and the
         # Adam step too when nothing has to happen between backward and step (no gradient exchange, no GradScaler check).
         # (auto: only while a step is launch-bound -- measured on MI355X, bf16, B = 8, round 3: 256x256 6.2 -> 3.8 ms per step as a
-        #  graph; 512x512 8.39 eager, 8.38 as a graph: GPU-bound either way, ~400 graph nodes)
+        #  graph; 512x512 7.9 eager -- weight gradients overlap the backward chain on a side stream there, train._wgrad -- 8.4 as a graph)
         mode = os.environ.get("MDIE_TRAIN_GRAPH", "auto") if self.device.type == "cuda" else "0"
         want_graph = (lambda x: mode == "1" or (mode == "auto" and x.shape[0] * x.shape[2] * x.shape[3] <= 8 * 384 * 384))
         whole = mode != "0" and not distributed and not scaler.is_enabled()      # the Adam step rides in the graph too
