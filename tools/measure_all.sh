@@ -46,4 +46,5 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 cd "$ROOT"
 python tools/traffic_from_pmc.py "$OUT/pmc" "$OUT/traffic_bf16_b32_256.json" > "$OUT/traffic_summary.txt" 2>&1
 python tools/mfma_busy_from_pmc.py "$OUT/pmc_mfma" "$OUT/mfma_busy.txt" > /dev/null 2>&1
+python tools/train_timeline.py "$OUT/train_stats" "$OUT/train_timeline.txt" > /dev/null 2>&1
 echo "done: $(ls "$OUT" | wc -l) files"
