@@ -113,6 +113,8 @@ def source_sha16():
         t = re.sub(r"//[^\n]*", "", t)
         t = re.sub(r"\s+", " ", t)
         h.update(os.path.basename(f).encode() + b"\0" + t.encode())
+    with open(os.path.join(pk, "Makefile"), encoding="utf-8") as fh:      # the compiler flags are part of the code (lines that are not comments)
+        h.update(b"Makefile\0" + " ".join(l.strip() for l in fh if l.strip() and not l.lstrip().startswith("#")).encode())
     return h.hexdigest()[:16]
 
 

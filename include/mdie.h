@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 19
+#define MDIE_ABI_VERSION 20
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1,
        MDIE_F16 = 2 /* IEEE half: the reference's mixed-precision dtype (torch.cuda.amp.autocast, models/model.py:15,159) */ };
@@ -122,7 +122,22 @@ typedef struct {
                               out[(n / 16) * out_group_stride + p * out_stride + n % 16] (out_stride >= 16; plain epilogue only: no activation,
                               pooling, residual) -- the layout mdie_bn_bwd_reduce / mdie_bn_bwd_apply_multi take `da` in (da_plane), so that
                               one feature segment of several layers' input gradients is a set of dense streams */
+  const struct mdie_bn_reduce_fuse* bnred;   /* optional, with out_group_stride only: see below */
 } mdie_conv_desc;
+
+/* The BatchNorm-ReLU backward SUMS fused into the input-gradient convolution of a DenseBlock layer (training).  The convolution's
+ * output `da` is the gradient w.r.t. relu(bn(x)) where x = cat(x segments) (models/cdan.py:35-46); BatchNorm backward needs
+ *   sum dz  and  sum dz * xhat   per channel,   dz = da * [x * scale + shift > 0]
+ * over the whole batch before anything can be applied -- a pass of its own over da and x (mdie_bn_bwd_reduce: 0.7 ms of an 8 ms
+ * step).  With `bnred` the convolution reads x at the pixels it has just produced and leaves, per tile, sum dz and sum dz * x in
+ * partial[slab][2][cout] (mdie_conv_bnred_slabs() slabs); mdie_bn_bwd_finish folds the slabs and forms
+ * sum dz * xhat = invstd * (sum dz * x - mean * sum dz): da is written once and read once (by mdie_bn_bwd_apply_multi). */
+typedef struct mdie_bn_reduce_fuse {
+  int nseg; mdie_seg x[MDIE_MAX_SEG];   /* the layer's input, stored channels: together exactly `cout` of the convolution */
+  const float* scale; const float* shift;   /* [cout] of that layer's BatchNorm (mdie_bn_fold) */
+  float* partial; size_t partial_bytes;     /* >= mdie_conv_bnred_slabs * 2 * cout floats */
+} mdie_bn_reduce_fuse;
+int mdie_conv_bnred_slabs(int B, int H, int W, int cout);
 
 int mdie_conv_fwd(const mdie_conv_desc* d, void* stream);
 /* tile edge (8 or 16) mdie_conv_fwd picks for this shape: pool_partial has ceil(H/t) * ceil(W/t) slabs per image */
@@ -525,6 +540,16 @@ typedef struct {
 } mdie_bn_bwd_desc;
 int mdie_bn_bwd_reduce(const mdie_bn_bwd_desc* d, void* stream);
 int mdie_bn_bwd_apply(const mdie_bn_bwd_desc* d, void* stream);
+/* mdie_bn_bwd_reduce's second half alone, for sums an input-gradient convolution left (mdie_conv_desc.bnred: per slab, sum dz and
+ * sum dz * x): folds the slabs in order and writes dgamma, dbeta (real-channel layout: c_real / split / gap) and coef [2][C]. */
+typedef struct {
+  int C; long N;                          /* stored channels, pixels */
+  const float* partial; int n_partial;    /* [n_partial][2][C] */
+  const float* mean; const float* invstd; /* [C] */
+  int c_real, split, gap;
+  float* dgamma; float* dbeta; float* coef;
+} mdie_bn_bwd_finish_desc;
+int mdie_bn_bwd_finish(const mdie_bn_bwd_finish_desc* d, void* stream);
 /* The same backward for a tensor that SEVERAL BatchNorm layers normalise -- the input of a DenseBlock, which each of its four
  * layers and its transition see through cat(features) (models/cdan.py:35,38) -- in ONE pass:
  *     g = sum_j scale_j * (da_j * [x * scale_j + shift_j > 0] - coef_j[0] - xhat * coef_j[1])      (written, rounded once)

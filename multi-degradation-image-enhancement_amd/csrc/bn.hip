@@ -553,6 +553,31 @@ __global__ __launch_bounds__(64) void bn_bwd_final_kernel(int nblk, int C_st, in
   }
 }
 
+// the same fold for partial sums a CONVOLUTION left (mdie_conv_desc.bnred): slab sums of dz and of dz * x (raw x: the convolution's
+// epilogue holds no mean / invstd), so  sum dz * xhat = invstd * (sum dz * x - mean * sum dz).  One 256-thread block per stored
+// channel (up to B * tiles slabs: 8 k at 8 x 512 x 512), lanes by shuffles, the four waves in order.
+__global__ __launch_bounds__(256) void bn_bwd_final_raw_kernel(int nblk, int C_st, int C_real, int split, int gap, double n, const float* partial, const float* mean,
+                                                              const float* invstd, float* dgamma, float* dbeta, float* coef) {
+  __shared__ double red[2][4];
+  const int cs = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+  for (int b = threadIdx.x; b < nblk; b += 256) { s1 += partial[((size_t)b * 2 + 0) * C_st + cs]; s2 += partial[((size_t)b * 2 + 1) * C_st + cs]; }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    s2 = (double)invstd[cs] * (s2 - (double)mean[cs] * s1);
+    coef[cs] = (float)(s1 / n);
+    coef[C_st + cs] = (float)(s2 / n);
+    const int c = real_channel(cs, split, gap, C_real);
+    if (c >= 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+  }
+}
+
 // thread = (channel vector, pixel row) with the channel fixed for the whole kernel: the six per-channel constants
 // live in registers and the pixel loop is pure streaming (da, x in; g in/out)
 template <typename T>
@@ -1054,6 +1079,18 @@ extern "C" int mdie_bn_bwd_reduce(const mdie_bn_bwd_desc* d, void* stream) {
   const size_t lds = (size_t)p.rows * 2 * a.C * sizeof(float);
   MDIE_SWITCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(p.blocks), dim3(BN_THREADS), lds, s, a));
   return bn_bwd_finish("mdie_bn_bwd_reduce", p.blocks, a.C, d->c_real, d->split, d->gap, (double)a.N, a.partial, d->dgamma, d->dbeta, d->coef, s);
+}
+
+extern "C" int mdie_bn_bwd_finish(const mdie_bn_bwd_finish_desc* d, void* stream) {
+  MDIE_REQUIRE(d != nullptr, "mdie_bn_bwd_finish: null descriptor");
+  MDIE_REQUIRE(d->C > 0 && d->C % 16 == 0 && d->N > 0 && d->n_partial > 0, "mdie_bn_bwd_finish: C %d, N %ld, %d slabs", d->C, d->N, d->n_partial);
+  MDIE_REQUIRE(d->partial && d->mean && d->invstd && d->dgamma && d->dbeta && d->coef, "mdie_bn_bwd_finish: null pointer");
+  MDIE_REQUIRE(d->c_real > 0 && d->gap >= 0 && d->split >= 0 && d->C >= d->c_real + (d->split < d->c_real ? d->gap : 0), "mdie_bn_bwd_finish: %d stored channels cannot hold %d real + gap %d",
+               d->C, d->c_real, d->gap);
+  hipLaunchKernelGGL(bn_bwd_final_raw_kernel, dim3(d->C), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d->n_partial, d->C, d->c_real, d->split, d->gap, (double)d->N,
+                     d->partial, d->mean, d->invstd, d->dgamma, d->dbeta, d->coef);
+  MDIE_LAUNCH_CHECK("mdie_bn_bwd_finish");
+  return MDIE_OK;
 }
 
 extern "C" int mdie_bn_bwd_apply(const mdie_bn_bwd_desc* d, void* stream) {

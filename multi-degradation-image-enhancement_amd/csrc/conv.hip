@@ -580,6 +580,7 @@ static void fill_epi(EpiArgs& e, int H, int W, const float* sc, const float* sh,
 
 }  // namespace mdie
 extern "C" int mdie_conv_tile(int B, int H, int W, int cout);
+extern "C" int mdie_conv_bnred_slabs(int B, int H, int W, int cout);
 namespace mdie {
 
 template <typename T>
@@ -606,12 +607,27 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   a.weight = reinterpret_cast<const char*>(d->weight);
   fill_epi(a.e, d->H, d->W, d->post_scale, d->post_shift, d->act, d->pool, d->residual, d->res_stride, d->out, d->out_stride, d->out_nchw3);
   a.pool_partial = d->pool_partial;
-  if (conv_wide_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr)) return launch_conv_wide(Traits<T>::DT, a, stream);
   if (d->out_group_stride != 0 && d->out_group_stride != 16) {   // one plane per 16 output channels: conv_planar.hip
     MDIE_REQUIRE(!d->tr, "mdie_conv_fwd: out_group_stride and tr exclude each other");
     a.e.out_gs = d->out_group_stride;
+    if (const mdie_bn_reduce_fuse* r = d->bnred) {   // + the BatchNorm-ReLU backward sums of the tensor this output is the gradient of
+      MDIE_REQUIRE(r->nseg >= 1 && r->nseg <= MDIE_MAX_SEG && r->scale && r->shift && r->partial, "mdie_conv_fwd: bnred: null / nseg %d", r->nseg);
+      int bc = 0;
+      for (int k = 0; k < r->nseg; ++k) {
+        MDIE_REQUIRE(r->x[k].ptr && r->x[k].channels > 0 && r->x[k].channels % 16 == 0 && r->x[k].stride >= r->x[k].channels && r->x[k].stride % Traits<T>::VEC == 0 &&
+                         ((uintptr_t)r->x[k].ptr & 15) == 0,
+                     "mdie_conv_fwd: bnred: x segment %d (whole 16-channel groups, 16-byte aligned)", k);
+        a.e.bx[k].ptr = reinterpret_cast<const char*>(r->x[k].ptr); a.e.bx[k].ch_begin = bc; bc += r->x[k].channels; a.e.bx[k].ch_end = bc; a.e.bx[k].stride = r->x[k].stride;
+      }
+      MDIE_REQUIRE(bc == d->cout, "mdie_conv_fwd: bnred: x holds %d channels, the gradient %d", bc, d->cout);
+      const size_t need = (size_t)mdie_conv_bnred_slabs(d->B, d->H, d->W, d->cout) * 2 * d->cout * sizeof(float);
+      if (r->partial_bytes < need) { set_error("mdie_conv_fwd: bnred: partial %zu < %zu bytes", r->partial_bytes, need); return MDIE_ENOSPC; }
+      a.e.bx_nseg = r->nseg; a.e.b_scale = r->scale; a.e.b_shift = r->shift; a.e.b_partial = r->partial;
+    }
     return launch_conv_planar(Traits<T>::DT, a, d->ksize, stream);
   }
+  MDIE_REQUIRE(!d->bnred, "mdie_conv_fwd: bnred rides on the planar output (out_group_stride)");
+  if (conv_wide_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr)) return launch_conv_wide(Traits<T>::DT, a, stream);
   if (d->tr) {   // the block's transition folded into this layer: conv_thin_kernel only (csrc/conv_thin.hip)
     MDIE_REQUIRE(conv_thin_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr, true),
                  "mdie_conv_fwd: tr needs a 16-bit 3x3 layer with pre-activation, 16 outputs, <= 56 stored input channels and H, W multiples of 16");
@@ -812,6 +828,12 @@ extern "C" int mdie_conv_tile(int B, int H, int W, int cout) {
   // element of the bottleneck CBAM's output).  Maps with an edge of 8 or less take 8x8 tiles, everything else 16x16.
   (void)B; (void)cout;
   return (H <= 8 || W <= 8) ? 8 : 16;
+}
+
+extern "C" int mdie_conv_bnred_slabs(int B, int H, int W, int cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || cout <= 0 || cout % 16 != 0) return 0;
+  const int t = mdie::conv_planar_tile(B, H, W, cout);
+  return B * mdie::cdiv(H, t) * mdie::cdiv(W, t);
 }
 
 extern "C" int mdie_conv_first_fwd(const mdie_conv_first_desc* d, void* stream) {

@@ -27,6 +27,13 @@ struct EpiArgs {
   int out_stride;
   float* nchw3;  // optional fp32 NCHW [B,3,Ho,Wo] destination for output channels 0..2
   long out_gs;   // PLANAR kernels only: elements between consecutive 16-channel groups of the output (mdie_conv_desc.out_group_stride)
+  // BNRED kernels only (mdie_conv_desc.bnred): the tensor x whose gradient this convolution's output is, per stored output
+  // channel the constants of the BatchNorm + ReLU that was applied to it, and where the per-tile sums go
+  SegDev bx[MDIE_MAX_SEG];
+  int bx_nseg;
+  const float* b_scale;
+  const float* b_shift;
+  float* b_partial;   // [B * tiles per image][2][cout]: sum of dz, sum of dz * x   (dz = output * [x * scale + shift > 0])
 };
 
 struct ConvArgs {
@@ -247,6 +254,83 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiArgs& e, const float4 (
   }
 }
 
+// PLANAR + BNRED epilogue (conv_planar.hip): store the plain output one plane per 16 channels AND accumulate, per output channel,
+//   s1 += dz,  s2 += dz * x      with dz = stored output * [x * b_scale + b_shift > 0]
+// -- the two sums of the BatchNorm-ReLU backward of the tensor x this output is the gradient of (sum dz * xhat follows in the
+// finishing kernel as invstd * (s2 - mean * s1): no per-channel mean / invstd in registers here).  x is read at the lane's
+// pixel and 4 channels: 8 (16-bit) / 16 (fp32) bytes per subtile and channel group, every byte of a line used across the wave.
+// Channel-group outer, subtile inner: one group's constants and sums are live at a time (BN = 64 would hold 64 registers otherwise).
+template <typename T, int NCS, int NPS, int TILE>
+__device__ __forceinline__ void conv_epilogue_bnred(const EpiArgs& e, const float4 (&esc)[NCS], const float4 (&esh)[NCS], f32x4 (&acc)[NCS][NPS], int img, int y0,
+                                                    int x0, int n0, int ps_base, int lq, int lp, float* red, int wave, int BN) {
+  using TS = TileStep<TILE, NPS>;
+  int ty0, tx0;
+  tile_pixel<TILE>(ps_base, lp, ty0, tx0);
+  const int gy0 = y0 + ty0, gx0 = x0 + tx0;
+  const size_t pix0 = ((size_t)img * e.H + gy0) * e.W + gx0;
+  const ptrdiff_t ogs = (ptrdiff_t)e.out_gs;
+  T* const orow0 = reinterpret_cast<T*>(e.out) + pix0 * e.out_stride + (ptrdiff_t)(n0 >> 4) * ogs + lq * 4;
+#pragma unroll
+  for (int cs = 0; cs < NCS; ++cs) {
+    const int c16 = n0 + cs * 16;                                   // wave-uniform: first stored channel of this group
+    const T* xb = nullptr; int xs = 0;
+#pragma unroll
+    for (int k = 0; k < MDIE_MAX_SEG; ++k)
+      if (k < e.bx_nseg && c16 >= e.bx[k].ch_begin && c16 < e.bx[k].ch_end) {
+        xb = reinterpret_cast<const T*>(e.bx[k].ptr) + (c16 - e.bx[k].ch_begin) + lq * 4; xs = e.bx[k].stride;
+      }
+    const float4 bsc = *reinterpret_cast<const float4*>(e.b_scale + c16 + lq * 4), bsh = *reinterpret_cast<const float4*>(e.b_shift + c16 + lq * 4);
+    const float bs[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, bh[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
+    const float sc[4] = {esc[cs].x, esc[cs].y, esc[cs].z, esc[cs].w}, sh[4] = {esh[cs].x, esh[cs].y, esh[cs].z, esh[cs].w};
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float xv[NPS][4];
+    bool inside[NPS];
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {                              // all of the group's x loads first (in flight together)
+      const int gy = gy0 + TS::dy(ps), gx = gx0 + TS::dx(ps);
+      inside[ps] = gy < e.H && gx < e.W;
+      const size_t pix = inside[ps] ? pix0 + (size_t)TS::dy(ps) * e.W + TS::dx(ps) : pix0 - (size_t)ty0 * e.W - tx0;   // (outside: the tile's first pixel, not used)
+      if constexpr (sizeof(T) == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + pix * xs);
+        xv[ps][0] = v.x; xv[ps][1] = v.y; xv[ps][2] = v.z; xv[ps][3] = v.w;
+      } else {
+        const uint2 v = *reinterpret_cast<const uint2*>(xb + pix * xs);
+        xv[ps][0] = Half<T>::lo(v.x); xv[ps][1] = Half<T>::hi(v.x); xv[ps][2] = Half<T>::lo(v.y); xv[ps][3] = Half<T>::hi(v.y);
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int dpix = TS::dy(ps) * e.W + TS::dx(ps);               // wave-uniform
+      T* orow = orow0 + (ptrdiff_t)dpix * e.out_stride + cs * ogs;
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaf(acc[cs][ps][i], sc[i], sh[i]);
+      if constexpr (sizeof(T) == 4) {
+        if (inside[ps]) *reinterpret_cast<float4*>(orow) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        const uint2 pk = make_uint2(Half<T>::pack(v[0], v[1]), Half<T>::pack(v[2], v[3]));
+        if (inside[ps]) *reinterpret_cast<uint2*>(orow) = pk;
+        v[0] = Half<T>::lo(pk.x); v[1] = Half<T>::hi(pk.x); v[2] = Half<T>::lo(pk.y); v[3] = Half<T>::hi(pk.y);   // the STORED values: what a pass over `out` would read
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dz = (inside[ps] && fmaf(xv[ps][i], bs[i], bh[i]) > 0.f) ? v[i] : 0.f;
+        s1[i] += dz;
+        s2[i] = fmaf(dz, xv[ps][i], s2[i]);
+      }
+    }
+    // over the 16 pixel lanes of the row group (same lq = same 4 channels); lane lp == 0 of each group writes the wave's sums
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int d = 8; d > 0; d >>= 1) { s1[i] += __shfl_xor(s1[i], d); s2[i] += __shfl_xor(s2[i], d); }
+    if (lp == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { red[(wave * 2 + 0) * BN + cs * 16 + lq * 4 + i] = s1[i]; red[(wave * 2 + 1) * BN + cs * 16 + lq * 4 + i] = s2[i]; }
+    }
+  }
+}
+
 // runtime -> compile-time dispatch (act and pool are launch-uniform, so this is one scalar branch)
 template <typename T, int NCS, int NPS, int TILE>
 __device__ __forceinline__ void conv_epilogue(const EpiArgs& e, const float4 (&esc)[NCS], const float4 (&esh)[NCS],
@@ -275,5 +359,6 @@ int launch_conv_thin(int dtype, const ConvArgs& a, hipStream_t stream, const mdi
 // conv_planar.hip: conv_kernel with the output written one plane per 16 channels (no activation, pooling, residual): the input
 // gradients of the DenseBlock layers in training
 int launch_conv_planar(int dtype, ConvArgs& a, int ksize, hipStream_t stream);
+int conv_planar_tile(int B, int H, int W, int cout);
 
 }  // namespace mdie

@@ -30,9 +30,10 @@ constexpr int conv_min_waves(int BN, int TILE) { return BN == 16 ? 4 : (TILE == 
 // that is not a load, an LDS access or an MFMA is kept off the hot path: 3-D grid instead of index
 // division, incremental patch coordinates, remainder staging iterations under a wave-uniform branch,
 // epilogue constants prefetched at kernel entry.
-template <typename T, int KS, int BN, int TILE, bool STATS = false, bool PLANAR = false>
+template <typename T, int KS, int BN, int TILE, bool STATS = false, bool PLANAR = false, bool BNRED = false>
 __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_kernel(const ConvArgs a) {
   static_assert(!(PLANAR && STATS), "planar output is the plain epilogue");
+  static_assert(!BNRED || PLANAR, "the BatchNorm-backward sums ride on the planar epilogue");
   using G = ConvGeom<KS, BN, TILE>;
 #ifdef EXP_STAMPS
   unsigned long long* dbg = (a.e.res_stride == -12345) ? reinterpret_cast<unsigned long long*>(const_cast<char*>(a.e.residual)) : nullptr;
@@ -291,7 +292,21 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
   if (dbg) { e2.residual = nullptr; e2.res_stride = 0; }
   conv_epilogue<T, NCS, NPS, TILE>(e2, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp);
 #else
-  if constexpr (PLANAR) {   // (no activation, no pooling, no residual: checked by the host)
+  if constexpr (PLANAR && BNRED) {
+    // the patch image is dead once every wave is past its last MFMA: the 4 waves' channel sums meet there, then one thread per
+    // channel folds them in wave order and writes this tile's slab (fixed order: bit-reproducible)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);           // [wave][2][BN]
+    conv_epilogue_bnred<T, NCS, NPS, TILE>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp, red, wave, BN);
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int k = tid / BN, ch = tid - k * BN;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < CONV_THREADS / 64; ++w) t += red[(w * 2 + k) * BN + ch];
+      a.e.b_partial[(((size_t)img * tpi + trem) * 2 + k) * a.cout + n0 + ch] = t;
+    }
+  } else if constexpr (PLANAR) {   // (no activation, no pooling, no residual: checked by the host)
     conv_epilogue_t<T, NCS, NPS, TILE, MDIE_ACT_NONE, false, false, true>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp);
   } else if constexpr (!STATS) {
     conv_epilogue<T, NCS, NPS, TILE>(a.e, esc, esh, acc, img, y0, x0, n0, wave * NPS, lq, lp);

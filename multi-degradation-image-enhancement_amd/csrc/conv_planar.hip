@@ -16,18 +16,31 @@
 
 namespace mdie {
 
-template <typename T, int KS, int BN, int TILE>
-static int launch_planar_t(ConvArgs& a, hipStream_t stream) {
+template <typename T, int KS, int BN, int TILE, bool BNRED>
+static int launch_planar_k(ConvArgs& a, hipStream_t stream) {
   using G = ConvGeom<KS, BN, TILE>;
   a.tiles_x = cdiv(a.W, TILE); a.tiles_y = cdiv(a.H, TILE);
   const dim3 grid(8, a.n_tiles, cdiv(a.tiles_x * a.tiles_y * a.B, 8));
   static LdsOptIn opt;
-  if (!opt.ensure(reinterpret_cast<const void*>(&conv_kernel<T, KS, BN, TILE, false, true>), G::BUF_BYTES + 8 * 1024)) return MDIE_ELAUNCH;
+  if (!opt.ensure(reinterpret_cast<const void*>(&conv_kernel<T, KS, BN, TILE, false, true, BNRED>), G::BUF_BYTES + 8 * 1024)) return MDIE_ELAUNCH;
   TimedLaunch tl(KS == 3 ? MDIE_K_CONV3 : MDIE_K_CONV1);
   const size_t lds = G::BUF_BYTES + 2 * BN * sizeof(float) + (a.pre_scale ? (size_t)2 * a.nchunk * Traits<T>::KC * sizeof(float) : 0);
-  hipLaunchKernelGGL((conv_kernel<T, KS, BN, TILE, false, true>), grid, dim3(CONV_THREADS), lds, stream, a);
+  hipLaunchKernelGGL((conv_kernel<T, KS, BN, TILE, false, true, BNRED>), grid, dim3(CONV_THREADS), lds, stream, a);
   MDIE_LAUNCH_CHECK("mdie_conv_fwd");
   return MDIE_OK;
+}
+
+template <typename T, int KS, int BN, int TILE>
+static int launch_planar_t(ConvArgs& a, hipStream_t stream) {
+  static_assert(ConvGeom<KS, BN, TILE>::BUF_BYTES >= (CONV_THREADS / 64) * 2 * BN * (int)sizeof(float), "the wave sums of the BNRED epilogue fit the dead patch image");
+  return a.e.b_partial ? launch_planar_k<T, KS, BN, TILE, true>(a, stream) : launch_planar_k<T, KS, BN, TILE, false>(a, stream);
+}
+
+// the tile edge launch_planar_dt picks: mdie_conv_bnred_slabs (conv.hip) sizes the partial sums with it
+int conv_planar_tile(int B, int H, int W, int cout) {
+  const int bn = (cout % 64 == 0) ? 64 : 16;
+  const long wgs16 = (long)cdiv(H, 16) * cdiv(W, 16) * B * (cout / bn);
+  return wgs16 < SMALL_GRID_WGS ? 8 : 16;
 }
 
 template <typename T>

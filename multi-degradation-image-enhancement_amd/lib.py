@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 19
+ABI_VERSION = 20
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 FWD_SERIAL = 2
@@ -38,13 +38,23 @@ class TrFuse(C.Structure):
                 ("act", C.c_int), ("out_nchw3", C.c_void_p)]
 
 
+class BnReduceFuse(C.Structure):
+    _fields_ = [("nseg", C.c_int), ("x", Seg * MAX_SEG), ("scale", C.c_void_p), ("shift", C.c_void_p), ("partial", C.c_void_p), ("partial_bytes", C.c_size_t)]
+
+
+class BnBwdFinishDesc(C.Structure):
+    _fields_ = [("C", C.c_int), ("N", C.c_long), ("partial", C.c_void_p), ("n_partial", C.c_int), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("c_real", C.c_int), ("split", C.c_int), ("gap", C.c_int), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("coef", C.c_void_p)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("ksize", C.c_int),
                 ("nseg", C.c_int), ("inp", Seg * MAX_SEG), ("cin", C.c_int), ("cout", C.c_int),
                 ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("weight", C.c_void_p),
                 ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int), ("pool", C.c_int),
                 ("residual", C.c_void_p), ("res_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int),
-                ("out_nchw3", C.c_void_p), ("pool_partial", C.c_void_p), ("tr", C.POINTER(TrFuse)), ("out_group_stride", C.c_long)]
+                ("out_nchw3", C.c_void_p), ("pool_partial", C.c_void_p), ("tr", C.POINTER(TrFuse)), ("out_group_stride", C.c_long),
+                ("bnred", C.POINTER(BnReduceFuse))]
 
 
 class WgradDesc(C.Structure):
@@ -182,6 +192,8 @@ SIGNATURES = {
     "mdie_pack_conv_weight_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p]),
     "mdie_pack_conv_weights_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mdie_conv_bnred_slabs": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mdie_bn_bwd_finish": (C.c_int, [C.POINTER(BnBwdFinishDesc), C.c_void_p]),
     "mdie_bn_stats_fold": (C.c_int, [C.POINTER(BnStatsFoldDesc), C.c_void_p]),
     "mdie_pack_conv_weight_job": (C.c_int, [C.c_int, C.POINTER(PackJob), C.c_void_p]),
     "mdie_conv_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -36,6 +36,7 @@ EPS = 1e-5
 # the rounding of the FORWARD activations (fp16, 8x finer, gives 0.9987 / 0.993 with the same five bf16-style roundings), while
 # the fp32 traffic costs 6 % of a 512x512 step (11.57 vs 10.88 ms, B = 8).
 ACC32 = __import__("os").environ.get("MDIE_TRAIN_ACC32", "0") == "1"
+BN_REDUCE_IN_DGRAD = __import__("os").environ.get("MDIE_TRAIN_BNRED", "1") == "1"   # the DenseBlock layers' BatchNorm-backward sums from the input-gradient convolution's epilogue
 
 
 def _cl(t):
@@ -165,7 +166,7 @@ def _zeros(n, dev):
     return _ZEROS[key]
 
 
-def _conv_raw(dt, segs, packed, bias_st, ks, cout_st, out, pre=None, act=L.ACT_NONE, out_nchw3=None, planar=False):
+def _conv_raw(dt, segs, packed, bias_st, ks, cout_st, out, pre=None, act=L.ACT_NONE, out_nchw3=None, planar=False, bnred=None):
     """out = act(conv_k(relu(cat(segs) * pre_scale + pre_shift)?) + bias); out: NHWC view with >= cout_st channels, or
     (planar) a [cout_st / 16, B*H*W, 16] tensor: one plane per 16 output channels (mdie_conv_desc.out_group_stride)."""
     B, _, H, W = segs[0].shape
@@ -187,6 +188,15 @@ def _conv_raw(dt, segs, packed, bias_st, ks, cout_st, out, pre=None, act=L.ACT_N
     else:
         d.out, d.out_stride = out.data_ptr(), out.stride(3)
     d.out_nchw3 = out_nchw3.data_ptr() if out_nchw3 is not None else None
+    if bnred is not None:     # (x segments, scale, shift, partial): the BatchNorm-ReLU backward sums of x ride on this input-gradient convolution
+        xsegs, bsc, bsh, partial = bnred
+        r = L.BnReduceFuse()
+        r.nseg = len(xsegs)
+        for i, s in enumerate(xsegs):
+            ptr, c, st = _nhwc(s)
+            r.x[i] = L.Seg(ptr, c, st)
+        r.scale, r.shift, r.partial, r.partial_bytes = bsc.data_ptr(), bsh.data_ptr(), partial.data_ptr(), partial.numel() * 4
+        d.bnred = C.pointer(r)
     L.check(L.lib.mdie_conv_fwd(C.byref(d), _sp(out.device)), "mdie_conv_fwd")
 
 
@@ -500,38 +510,54 @@ class _DenseFn(torch.autograd.Function):
                 grads[4 * l + 3] = _zero_grad_vec(16, dev)
             # gradient w.r.t. the activated input a = relu(bn(cat(segs)))
             planar = not acc32
+            fuse = planar and BN_REDUCE_IN_DGRAD
             da = torch.empty(cin_st // 16, N, 16, dtype=td, device=dev) if planar else _empty(dt, B, cin_st, H, W, dev)
-            _conv_raw(dt, [dy], _pack(dt, w, ks, True, cin_real, cout, cin_st, cout_st, out_split=real_c, out_gap=gap), _zeros(cin_st, dev), ks, cin_st, da, planar=planar)
+            dgb = torch.empty(2, cin_real, dtype=torch.float32, device=dev)
+            coef = torch.empty(2, cin_st, dtype=torch.float32, device=dev)
+            if fuse:    # the BatchNorm-ReLU backward sums come out of the input-gradient convolution's epilogue (mdie_conv_desc.bnred)
+                nslab = L.lib.mdie_conv_bnred_slabs(B, H, W, cin_st)
+                partial = torch.empty(nslab, 2, cin_st, dtype=torch.float32, device=dev)
+                bnred = (segs, k[0], k[1], partial)
+            else:
+                bnred = None
+            _conv_raw(dt, [dy], _pack(dt, w, ks, True, cin_real, cout, cin_st, cout_st, out_split=real_c, out_gap=gap), _zeros(cin_st, dev), ks, cin_st, da, planar=planar,
+                      bnred=bnred)
             grads[4 * l + 2] = _wgrad(dt, segs, dy, (cout, cin_real, ks, ks), ks, False, cin_real, cout, cout_st, pre=(k[0], k[1]), split=real_c, gap=gap,
                                       param=ctx.wparams[l])
             # BatchNorm + ReLU backward: per-channel sums of this layer ...
-            dgb = torch.empty(2, cin_real, dtype=torch.float32, device=dev)
-            coef = torch.empty(2, cin_st, dtype=torch.float32, device=dev)
-            nws = L.lib.mdie_bn_workspace_bytes(cin_st)
-            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
             d = L.BnBwdDesc()
-            d.dtype, d.N, d.nseg = dt, N, len(segs)
-            for i, (sgm, g) in enumerate(zip(segs, gsegs)):
-                ptr, c, st = _nhwc(sgm)
-                d.x[i] = L.Seg(ptr, c, st)
-                ptr, c, st = _nhwc(g)
-                d.g[i] = L.Seg(ptr, c, st)
-            d.accumulate = 0 if l == 4 else 31
-            if acc32:
-                ptr, c, st = _nhwc(sx)
-                d.acc32[0], d.final_from[0] = L.Seg(ptr, c, st), (0 if l == 0 else c0)        # x: layer 0 is its last consumer
-                for j in range(l):
-                    ptr, c, st = _nhwc(sg[j])
-                    d.acc32[1 + j], d.final_from[1 + j] = L.Seg(ptr, c, st), (0 if j == l - 1 else 16)   # growth map l-1: this layer is its last consumer
-            if planar:
-                d.da, d.da_stride, d.da_plane = da.data_ptr(), 16, N * 16
+            if fuse:
+                f = L.BnBwdFinishDesc()
+                f.C, f.N, f.partial, f.n_partial = cin_st, N, partial.data_ptr(), nslab
+                f.mean, f.invstd = mv[0].data_ptr(), k[2].data_ptr()
+                f.c_real, f.split, f.gap = cin_real, real_c, gap
+                f.dgamma, f.dbeta, f.coef = dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr()
+                L.check(L.lib.mdie_bn_bwd_finish(C.byref(f), _sp(dev)), "mdie_bn_bwd_finish")
             else:
-                d.da, d.da_stride = da.data_ptr(), cin_st
-            d.mean, d.invstd, d.scale, d.shift, d.relu = mv[0].data_ptr(), k[2].data_ptr(), k[0].data_ptr(), k[1].data_ptr(), 1
-            d.c_real, d.split, d.gap = cin_real, real_c, gap
-            d.dgamma, d.dbeta, d.coef = dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr()
-            d.workspace, d.workspace_bytes = ws.data_ptr(), nws
-            L.check(L.lib.mdie_bn_bwd_reduce(C.byref(d), _sp(dev)), "mdie_bn_bwd_reduce")
+                nws = L.lib.mdie_bn_workspace_bytes(cin_st)
+                ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+                d.dtype, d.N, d.nseg = dt, N, len(segs)
+                for i, (sgm, g) in enumerate(zip(segs, gsegs)):
+                    ptr, c, st = _nhwc(sgm)
+                    d.x[i] = L.Seg(ptr, c, st)
+                    ptr, c, st = _nhwc(g)
+                    d.g[i] = L.Seg(ptr, c, st)
+                d.accumulate = 0 if l == 4 else 31
+                if acc32:
+                    ptr, c, st = _nhwc(sx)
+                    d.acc32[0], d.final_from[0] = L.Seg(ptr, c, st), (0 if l == 0 else c0)        # x: layer 0 is its last consumer
+                    for j in range(l):
+                        ptr, c, st = _nhwc(sg[j])
+                        d.acc32[1 + j], d.final_from[1 + j] = L.Seg(ptr, c, st), (0 if j == l - 1 else 16)   # growth map l-1: this layer is its last consumer
+                if planar:
+                    d.da, d.da_stride, d.da_plane = da.data_ptr(), 16, N * 16
+                else:
+                    d.da, d.da_stride = da.data_ptr(), cin_st
+                d.mean, d.invstd, d.scale, d.shift, d.relu = mv[0].data_ptr(), k[2].data_ptr(), k[0].data_ptr(), k[1].data_ptr(), 1
+                d.c_real, d.split, d.gap = cin_real, real_c, gap
+                d.dgamma, d.dbeta, d.coef = dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr()
+                d.workspace, d.workspace_bytes = ws.data_ptr(), nws
+                L.check(L.lib.mdie_bn_bwd_reduce(C.byref(d), _sp(dev)), "mdie_bn_bwd_reduce")
             grads[4 * l], grads[4 * l + 1] = dgb[0], dgb[1]
             if acc32:   # (fp32 running sums: the layer-by-layer form)
                 L.check(L.lib.mdie_bn_bwd_apply(C.byref(d), _sp(dev)), "mdie_bn_bwd_apply")
@@ -704,6 +730,9 @@ def deconv_stage(dt, cv, bn, x, skip, up):
     return _DeconvFn.apply(x, cv.weight, cv.bias, bn.weight, bn.bias, skip, bn, dt, up)
 
 
+_DEBUG_POISON = None     # tools/dbg_bnred.py: byte value the CBAM workspaces are filled with (None: left as allocated)
+
+
 class _CbamFn(torch.autograd.Function):
     """CBAM.forward (models/cbam.py:91-95) in training mode, optionally times `mul` (the `out *= dense_k` that follows it)."""
 
@@ -721,6 +750,8 @@ class _CbamFn(torch.autograd.Function):
         d.running_mean, d.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
         nws = L.lib.mdie_cbam_train_workspace_bytes(B, H, W, Cc)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        if _DEBUG_POISON is not None:
+            ws.fill_(_DEBUG_POISON)
         d.workspace, d.workspace_bytes = ws.data_ptr(), nws
         L.check(L.lib.mdie_cbam_train_fwd(C.byref(d), _sp(dev)), "mdie_cbam_train_fwd")
         ctx.save_for_backward(x, mul, gate, amax, pooled, comp, smap, bnc, *params)
@@ -760,6 +791,8 @@ class _CbamFn(torch.autograd.Function):
         d.dw1, d.db1, d.dw2, d.db2, d.dw7, d.dgamma, d.dbeta = [g.data_ptr() for g in grads]
         nws = L.lib.mdie_cbam_train_workspace_bytes(B, H, W, Cc)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        if _DEBUG_POISON is not None:
+            ws.fill_(_DEBUG_POISON)
         d.workspace, d.workspace_bytes = ws.data_ptr(), nws
         L.check(L.lib.mdie_cbam_train_bwd(C.byref(d), _sp(dev)), "mdie_cbam_train_bwd")
         return (dx, dmul, *grads, None, None)

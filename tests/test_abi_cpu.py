@@ -177,15 +177,18 @@ def test_custom_torch_ops_are_registered_and_have_no_cpu_kernel():
 
 
 def test_shipped_code_objects_pass_the_isa_guard():
-    """tools/isa_guard.py on the library the tests load: no kernel that issues MFMAs reads a VGPR pair through the
-    op_sel / op_sel_hi modifiers of a packed-f32 instruction (the combination that produced wrong lanes 48..63 in round 2,
-    DESIGN.md section 4 finding 6), and no kernel of the library spills registers to scratch."""
+    """tools/isa_guard.py on the library the tests load: NO kernel reads a VGPR pair through the op_sel / op_sel_hi modifiers of a
+    packed-f32 instruction -- the form that returned wrong values with MFMAs in flight on the CU, inside one kernel in round 2 and
+    across kernels (MFMA-free CBAM backward next to the weight-gradient kernels on a second stream) in round 3, DESIGN.md section 4
+    finding 6 -- and no kernel of the library spills registers to scratch."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import isa_guard
     rows = isa_guard.audit(L.LIB_PATH)
     assert len(rows) > 100 and sum(1 for r in rows if r["mfma"]) > 50, "disassembly found too few kernels: the audit itself is broken"
-    assert any(r["pk_sel"] for r in rows if not r["mfma"]), "the audit no longer recognises the op_sel forms it exists to find"
+    assert sum(r["pk"] for r in rows) > 100, "the audit no longer sees packed-f32 instructions at all (the convolutions' plain packed epilogues)"
+    assert isa_guard.vgpr_swizzle("v_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[8:9] op_sel:[0,1,1] op_sel_hi:[1,0,0]"), "the audit no longer recognises the forms it exists to find"
+    assert not isa_guard.vgpr_swizzle("v_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[8:9]") and not isa_guard.vgpr_swizzle("v_pk_mul_f32 v[2:3], v[4:5], 1.0 op_sel_hi:[1,0]")
     bad = isa_guard.violations(rows)
     assert not bad, [(r["pretty"], r["pk_sel"][:2]) for r in bad]
     spills = [r["pretty"] for r in rows if r["scratch"]]

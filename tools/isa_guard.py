@@ -10,14 +10,17 @@ a register pair feeds both results, or the halves are exchanged), scratch instru
 Why.  Round 2 found `v_pk_fma_f32 ... op_sel:[0,1,1]` / `op_sel_hi:[1,0,0]` returning wrong values in lanes 48..63 in the
 epilogue of conv_first_pool_kernel -- a kernel that also issues MFMAs -- while another kernel shared the CU; the ISA of the
 failing and the passing build is under profiles/r03_pkfma_*.txt and the analysis in DESIGN.md section 4 (finding 6): every
-documented MFMA -> VALU wait-state rule is met with margin in both builds, so the mechanism is NOT explained, and the
-library treats the combination as unsafe.  The rule this tool enforces (tests/test_abi_cpu.py runs it on every build):
+documented MFMA -> VALU wait-state rule is met with margin in both builds, so the mechanism is NOT explained.  Round 3 then saw
+the same thing ACROSS kernels: the MFMA-free backward kernels of cbam_train.hip (10-49 such forms each), bit-reproducible on
+one stream, gave different gradients in one training step out of three once the weight-gradient MFMA kernels ran beside them on
+a second stream -- and never (0 of 12 rounds, tools/race_hunt_train.py) once that file was built without packed f32.  The rule
+this tool enforces (tests/test_abi_cpu.py runs it on every build) is therefore library-wide:
 
-    a kernel that issues v_mfma must not contain a packed-f32 instruction that reads a VGPR pair through op_sel / op_sel_hi,
+    no kernel contains a packed-f32 instruction that reads a VGPR pair through op_sel / op_sel_hi,
 
-so that a compiler upgrade, an SLP-vectoriser decision or a new epilogue cannot bring the form back unnoticed.  Kernels
-without MFMAs (CBAM, BatchNorm, loss, post-processing) may keep it: they pass the two-engines-in-flight stress test
-(tests/test_gpu_parity.py::test_engines_in_flight_on_different_inputs) and the audit lists them so the fact is on record.
+so that a compiler upgrade, an SLP-vectoriser decision or a new epilogue cannot bring the form back unnoticed.  The MFMA files
+(conv*.hip) keep plain packed f32 (distinct register pairs, no swizzle) in their epilogues and pre-activations; every other
+file is built with the packed-f32 feature off (csrc/Makefile, NOPK).
 """
 import os
 import re
@@ -101,7 +104,7 @@ def audit(so_path):
 
 
 def violations(rows):
-    return [r for r in rows if r["mfma"] > 0 and r["pk_sel"]]
+    return [r for r in rows if r["pk_sel"]]
 
 
 def main(argv):
@@ -115,13 +118,11 @@ def main(argv):
             if r["mfma"] or r["pk"] or r["scratch"]:
                 print(f"{r['mfma']:6d} {r['pk']:5d} {len(r['pk_sel']):5d} {r['scratch']:5d}  {r['pretty'][:150]}")
     bad = violations(rows)
-    with_sel = [r for r in rows if r["pk_sel"] and not r["mfma"]]
-    print(f"{len(rows)} kernels; {sum(1 for r in rows if r['mfma'])} issue MFMAs; packed-f32 op_sel forms: "
-          f"{sum(len(r['pk_sel']) for r in with_sel)} in {len(with_sel)} MFMA-free kernels, "
-          f"{sum(len(r['pk_sel']) for r in bad)} in {len(bad)} MFMA kernels; "
+    print(f"{len(rows)} kernels; {sum(1 for r in rows if r['mfma'])} issue MFMAs; {sum(r['pk'] for r in rows)} packed-f32 instructions in "
+          f"{sum(1 for r in rows if r['pk'])} kernels, of which read a VGPR pair through op_sel / op_sel_hi: {sum(len(r['pk_sel']) for r in bad)} in {len(bad)} kernels; "
           f"kernels touching scratch: {sum(1 for r in rows if r['scratch'])}")
     for r in bad:
-        print(f"VIOLATION: {r['pretty'][:160]}: {r['mfma']} v_mfma and {len(r['pk_sel'])} packed-f32 op_sel forms, e.g. {r['pk_sel'][0]}")
+        print(f"VIOLATION: {r['pretty'][:160]}: {len(r['pk_sel'])} packed-f32 op_sel forms ({r['mfma']} v_mfma), e.g. {r['pk_sel'][0]}")
     return 1 if bad else 0
 
 
