@@ -2225,3 +2225,106 @@ def test_side_stream_weight_gradients_equal_main_stream(E, precision, shape, mon
     bad = [n for (n, _), u, v in zip(CDAN().named_parameters(), a[1], b[1]) if not torch.equal(u, v)]
     assert not bad, f"parameters differ: {bad[:6]}"
     assert all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("ks,cout,hw,segc", [(3, 80, (20, 24), (16, 16, 16, 16, 16)), (1, 64, (16, 16), (64,)), (3, 48, (40, 36), (16, 32))])
+def test_input_gradient_convolution_with_fused_batchnorm_backward_sums(E, L, precision, ks, cout, hw, segc):
+    """mdie_conv_desc.bnred: the planar input-gradient convolution that also leaves the per-slab sums of dz and dz * x, folded by
+    mdie_bn_bwd_finish -- against the same convolution followed by mdie_bn_bwd_reduce over its output: `da` bit-identical, dgamma /
+    dbeta / coef equal to summation-order accuracy (both see the STORED da and x; only sum(dz * xhat) is formed as
+    invstd * (sum(dz * x) - mean * sum(dz)) in double instead of term by term).  Shapes: 5 segments with ragged 16x16 tiles and BN = 16
+    output tiles, a 1x1 with a 64-wide tile, 8x8-tile territory."""
+    import ctypes as C
+    dt, td = E.dtype_id(precision), TORCH_DT[precision]
+    g = torch.Generator().manual_seed(31)
+    B, (H, W), cin = 2, hw, 16
+    N = B * H * W
+    cl = lambda t: t.cuda().to(td).contiguous(memory_format=torch.channels_last)
+    dy = cl(torch.randn(B, cin, H, W, generator=g))
+    xs = [cl(torch.randn(B, c, H, W, generator=g) * 1.3 + 0.2) for c in segc]
+    w = torch.randn(cout, cin, ks, ks, generator=g) * 0.2
+    packed = E.pack_conv_weight(w, dt).cuda()
+    ones, zeros = torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda")
+    xcat = torch.cat([t.float() for t in xs], 1)
+    mean, var = xcat.mean((0, 2, 3)), xcat.var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    gamma, beta = torch.rand(cout, generator=g).cuda() + 0.5, torch.randn(cout, generator=g).cuda() * 0.3
+    scale = (gamma * invstd).contiguous()
+    shift = (beta - mean * scale).contiguous()
+    sp = torch.cuda.current_stream().cuda_stream
+
+    def conv(bnred):
+        da = torch.full((cout // 16, N, 16), 3.0, dtype=td, device="cuda")
+        d = L.ConvDesc()
+        d.dtype, d.B, d.H, d.W, d.ksize, d.nseg = dt, B, H, W, ks, 1
+        d.inp[0] = L.Seg(dy.data_ptr(), cin, cin)
+        d.cin, d.cout = cin, cout
+        d.weight, d.post_scale, d.post_shift = packed.data_ptr(), ones.data_ptr(), zeros.data_ptr()
+        d.act, d.pool, d.out, d.out_stride, d.out_group_stride = 0, 0, da.data_ptr(), 16, da.stride(0)
+        partial = None
+        if bnred:
+            nslab = L.lib.mdie_conv_bnred_slabs(B, H, W, cout)
+            partial = torch.full((nslab, 2, cout), float("nan"), device="cuda")
+            r = L.BnReduceFuse()
+            r.nseg = len(xs)
+            for i, t in enumerate(xs):
+                r.x[i] = L.Seg(t.data_ptr(), t.shape[1], t.shape[1])
+            r.scale, r.shift, r.partial, r.partial_bytes = scale.data_ptr(), shift.data_ptr(), partial.data_ptr(), partial.numel() * 4
+            d.bnred = C.pointer(r)
+        L.check(L.lib.mdie_conv_fwd(C.byref(d), sp), "mdie_conv_fwd")
+        return da, partial
+
+    da0, _ = conv(False)
+    dgb0, coef0 = torch.zeros(2, cout, device="cuda"), torch.zeros(2, cout, device="cuda")
+    ws = torch.empty(L.lib.mdie_bn_workspace_bytes(cout), dtype=torch.uint8, device="cuda")
+    b = L.BnBwdDesc()
+    b.dtype, b.N, b.nseg = dt, N, len(xs)
+    for i, t in enumerate(xs):
+        b.x[i] = L.Seg(t.data_ptr(), t.shape[1], t.shape[1])
+    b.da, b.da_stride, b.da_plane = da0.data_ptr(), 16, N * 16
+    b.mean, b.invstd, b.scale, b.shift, b.relu = mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), 1
+    b.c_real, b.split, b.gap = cout, cout, 0
+    b.dgamma, b.dbeta, b.coef = dgb0[0].data_ptr(), dgb0[1].data_ptr(), coef0.data_ptr()
+    b.workspace, b.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(L.lib.mdie_bn_bwd_reduce(C.byref(b), sp), "mdie_bn_bwd_reduce")
+
+    da1, partial = conv(True)
+    dgb1, coef1 = torch.zeros(2, cout, device="cuda"), torch.zeros(2, cout, device="cuda")
+    f = L.BnBwdFinishDesc()
+    f.C, f.N, f.partial, f.n_partial = cout, N, partial.data_ptr(), partial.shape[0]
+    f.mean, f.invstd, f.c_real, f.split, f.gap = mean.data_ptr(), invstd.data_ptr(), cout, cout, 0
+    f.dgamma, f.dbeta, f.coef = dgb1[0].data_ptr(), dgb1[1].data_ptr(), coef1.data_ptr()
+    L.check(L.lib.mdie_bn_bwd_finish(C.byref(f), sp), "mdie_bn_bwd_finish")
+    torch.cuda.synchronize()
+    assert torch.equal(da0, da1) and not torch.isnan(partial).any()
+    tol = 2e-5 if precision == "fp32" else 1e-4
+    assert rel_to_max(dgb1, dgb0) <= tol and rel_to_max(coef1, coef0) <= tol and float(dgb0.abs().max()) > 1.0
+    # refusals: without the planar output; a partial buffer one slab short; x that does not cover the output channels
+    bad = L.ConvDesc()
+    C.memmove(C.byref(bad), C.byref(L.ConvDesc()), C.sizeof(L.ConvDesc))
+    r = L.BnReduceFuse()
+    r.nseg, r.scale, r.shift, r.partial, r.partial_bytes = 1, scale.data_ptr(), shift.data_ptr(), partial.data_ptr(), partial.numel() * 4 - 4 * 2 * cout
+    r.x[0] = L.Seg(xs[0].data_ptr(), xs[0].shape[1], xs[0].shape[1])
+    for mode in ("not planar", "short", "channels"):
+        d = L.ConvDesc()
+        d.dtype, d.B, d.H, d.W, d.ksize, d.nseg = dt, B, H, W, ks, 1
+        d.inp[0] = L.Seg(dy.data_ptr(), cin, cin)
+        d.cin, d.cout = cin, cout
+        d.weight, d.post_scale, d.post_shift = packed.data_ptr(), ones.data_ptr(), zeros.data_ptr()
+        d.out, d.out_stride, d.out_group_stride = da1.data_ptr(), 16, (0 if mode == "not planar" else da1.stride(0))
+        rr = L.BnReduceFuse()
+        C.memmove(C.byref(rr), C.byref(r), C.sizeof(L.BnReduceFuse))
+        if mode != "channels":
+            rr.nseg = len(xs)
+            for i, t in enumerate(xs):
+                rr.x[i] = L.Seg(t.data_ptr(), t.shape[1], t.shape[1])
+        if mode == "channels" or mode == "not planar":
+            rr.partial_bytes = partial.numel() * 4
+        if mode == "channels" and len(xs) == 1:
+            rr.x[0] = L.Seg(xs[0].data_ptr(), 16, xs[0].shape[1])
+        d.bnred = C.pointer(rr)
+        rc = L.lib.mdie_conv_fwd(C.byref(d), sp)
+        assert rc == (-3 if mode == "short" else -1), (mode, rc, L.lib.mdie_last_error())
+    torch.cuda.synchronize()
