@@ -2220,11 +2220,16 @@ def test_side_stream_weight_gradients_equal_main_stream(E, precision, shape, mon
         torch.cuda.synchronize()
         return losses, [p.detach().clone() for p in net.parameters()], [b.clone() for b in net.buffers()]
 
-    a, b = run(True), run(False)
-    assert all(torch.equal(u, v) for u, v in zip(a[0], b[0]))
-    bad = [n for (n, _), u, v in zip(CDAN().named_parameters(), a[1], b[1]) if not torch.equal(u, v)]
-    assert not bad, f"parameters differ: {bad[:6]}"
-    assert all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
+    b = run(False)
+    names = [n for n, _ in CDAN().named_parameters()]
+    # the largest shape several times: what this test first caught -- swizzled packed-f32 forms in the MFMA-free CBAM backward kernels
+    # going wrong next to the side stream's MFMA kernels (finding 6) -- showed in one round out of three
+    for _ in range(5 if shape[1] >= 512 else 1):
+        a = run(True)
+        assert all(torch.equal(u, v) for u, v in zip(a[0], b[0]))
+        bad = [n for n, u, v in zip(names, a[1], b[1]) if not torch.equal(u, v)]
+        assert not bad, f"parameters differ: {bad[:6]}"
+        assert all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
 
 
 @pytest.mark.gpu
