@@ -2333,3 +2333,35 @@ def test_input_gradient_convolution_with_fused_batchnorm_backward_sums(E, L, pre
         rc = L.lib.mdie_conv_fwd(C.byref(d), sp)
         assert rc == (-3 if mode == "short" else -1), (mode, rc, L.lib.mdie_last_error())
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_bn_stats_fold_from_partial_sums(L):
+    """mdie_bn_stats_fold with x = NULL: the caller supplies per-slab channel sums and sums of squares [n][2][C] (what a producer's
+    epilogue would leave); one launch folds them (double precision, slab order) and applies the fold."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(3)
+    Cc, n, per = 32, 37, 50
+    y = (torch.randn(n, per, Cc, generator=g) * 2.0 + 0.7).cuda()
+    partial = torch.stack((y.sum(1), (y * y).sum(1)), 1).contiguous()           # [n][2][C]
+    mv, k = torch.zeros(2, Cc, device="cuda"), torch.zeros(3, Cc, device="cuda")
+    gamma, beta = torch.rand(Cc, generator=g).cuda() + 0.5, torch.randn(Cc, generator=g).cuda()
+    rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    d = L.BnStatsFoldDesc()
+    d.dtype, d.N, d.x, d.C, d.stride = L.F32, n * per, None, Cc, Cc
+    d.mean, d.var = mv[0].data_ptr(), mv[1].data_ptr()
+    d.workspace, d.workspace_bytes, d.n_partial = partial.data_ptr(), partial.numel() * 4, n
+    d.C_fold, d.C_real, d.split, d.gap = Cc, Cc, Cc, 0
+    d.fold_mean, d.fold_var, d.gamma, d.beta, d.eps, d.momentum = mv[0].data_ptr(), mv[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1
+    d.running_mean, d.running_var = rm.data_ptr(), rv.data_ptr()
+    d.scale, d.shift, d.invstd = k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr()
+    L.check(L.lib.mdie_bn_stats_fold(C.byref(d), torch.cuda.current_stream().cuda_stream), "mdie_bn_stats_fold")
+    torch.cuda.synchronize()
+    flat = y.reshape(-1, Cc).double()
+    mean, var = flat.mean(0), flat.var(0, unbiased=False)
+    assert rel_to_max(mv[0], mean.float()) <= 1e-6 and rel_to_max(mv[1], var.float()) <= 1e-5
+    inv = 1.0 / torch.sqrt(var + 1e-5)
+    assert rel_to_max(k[0], (gamma.double() * inv).float()) <= 1e-5 and rel_to_max(k[1], (beta.double() - mean * gamma.double() * inv).float()) <= 1e-5
+    assert rel_to_max(rm, (0.1 * mean).float()) <= 1e-5
+    d.workspace_bytes = 16
+    assert L.lib.mdie_bn_stats_fold(C.byref(d), None) == -1
