@@ -597,9 +597,14 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     f.out = c.ws + P.o[0].off; f.out_stride = P.o[0].C;
     RUN(mdie_conv_first_fwd(&f, stream));
   }
-  RUN(side_dense(0, h1, w1));
+  // WHERE the side branches start (round 3, same-box sweep over fork points, eager launches, B = 32 at 256x256): forking each block
+  // as soon as its input exists (dense1 after conv1, dense2 after conv2, dense3 after conv3) puts all three next to conv2 / conv3 /
+  // conv4 -- the MFMA-bound layers of the main chain ran 1.3-2x their serial time with the HBM-bound dense kernels taking CUs and LDS
+  // from them (profiles/r03y_infer_timeline_graph.txt), while the decoder's first half (gates, small maps) left the chip idle.
+  // dense3 is needed first (cbam1) and stays where it was; dense1 and dense2 start after conv4 and run beside the bottleneck CBAM,
+  // dec.conv1 and the decoder's small kernels: 30.2 k -> 31.0 k images/s (+2.6 %; all three after conv4 +2.3 %, only dense1 late
+  // +2.2 %, all after the bottleneck +1 %, all three in line on ONE side stream -2 %; stream priorities: nothing).
   RUN(run_conv(c, CV_E2, h1, w1, {P.o[0]}, P.o[1], MDIE_ACT_RELU, 1, nullptr));
-  RUN(side_dense(1, h2, w2));
   RUN(run_conv(c, CV_E3, h2, w2, {P.o[1]}, P.o[2], MDIE_ACT_RELU, 1, nullptr));
   RUN(side_dense(2, h3, w3));
   // the two CBAMs at the deep end pool tensors a 64-wide convolution has just written: that convolution emits the
@@ -610,6 +615,8 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   const int slabs_e = cdiv(h3, te) * cdiv(w3, te), slabs_d = cdiv(h3, td) * cdiv(w3, td);
   const bool fuse_e = slabs_e <= MDIE_POOL_SLABS_MAX, fuse_d = slabs_d <= MDIE_POOL_SLABS_MAX;
   RUN(run_conv(c, CV_E4, h3, w3, {P.o[2]}, P.e, MDIE_ACT_RELU, 0, nullptr, nullptr, fuse_e ? pool_buf : nullptr));
+  RUN(side_dense(1, h2, w2));
+  RUN(side_dense(0, h1, w1));
   // bottleneck, models/cdan.py:173
   RUN(run_cbam_stage(c, P, CB_BOTT, h3, w3, P.e, nullptr, P.bott, fuse_e ? slabs_e : 0));
   // Decoder.forward, models/cdan.py:126-159
