@@ -23,7 +23,15 @@ def dtype_id(name):
         raise ValueError(f"unknown precision {name!r}; use 'fp32', 'bf16' or 'fp16'") from None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr(device):
+    """the current stream of `device` as a hipStream_t (torch's raw-stream getter: 0.2 us instead of the 4 us a Stream object costs --
+    an eager training step asks ~700 times)"""
+    if _raw_stream is not None:
+        idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+        return C.c_void_p(_raw_stream(torch.cuda.current_device() if idx is None else idx))
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -689,8 +689,31 @@ def conv(dtype, weight, bias, segs, transposed=False):
     return _ConvFn.apply(dtype, transposed, weight, bias, *[_cl(s) for s in segs])
 
 
+def _step_tensors(net):
+    """(the num_batches_tracked buffers, the 4-D fp32 parameters) of `net`, found once: walking the module tree costs 0.7 ms of an
+    8 ms step.  Valid while the first and last of each list are still the tensors the modules hold (load_state_dict copies in
+    place and keeps them; .to() / a re-wrap replaces them -- then the lists are rebuilt)."""
+    c = net.__dict__.get("_mdie_step_tensors")
+    if c is not None:
+        bufs, convs, probes = c
+        if all(getattr(m, n, None) is t for m, n, t in probes):
+            return bufs, convs
+    bufs, convs, probes = [], [], []
+    for m in net.modules():
+        for n, b in m._buffers.items():
+            if n == "num_batches_tracked" and b is not None:
+                bufs.append(b)
+                probes.append((m, n, b))
+        for n, p in m._parameters.items():
+            if p is not None and p.dim() == 4 and p.dtype == torch.float32 and p.is_contiguous():
+                convs.append(p)
+                probes.append((m, n, p))
+    net.__dict__["_mdie_step_tensors"] = (bufs, convs, probes)
+    return bufs, convs
+
+
 def _tick(net):
-    bufs = [buf for name, buf in net.named_buffers() if name.endswith("num_batches_tracked")]
+    bufs = _step_tensors(net)[0]
     if bufs:
         torch._foreach_add_(bufs, 1)        # (one or two launches instead of 32)
 
@@ -814,7 +837,7 @@ def forward_train(net, x, precision="fp32", dropout_p=0.2):
     global _PLAN
     plans = net.__dict__.setdefault("_mdie_pack_plans", {})
     _PLAN = plans.get(dt) or plans.setdefault(dt, _PackPlan(dt))
-    ptrs = frozenset(p.data_ptr() for p in net.parameters() if p.dim() == 4 and p.dtype == torch.float32 and p.is_contiguous())
+    ptrs = frozenset(p.data_ptr() for p in _step_tensors(net)[1])
     if ptrs != _PLAN.param_ptrs:        # parameters moved (load_state_dict keeps them; .to() / a new optimizer wrapper may not): start over
         plans[dt] = _PLAN = _PackPlan(dt)
         _PLAN.param_ptrs = ptrs
