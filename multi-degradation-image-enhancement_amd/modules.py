@@ -54,11 +54,26 @@ def _fingerprint(module):
     """Changes whenever a parameter or buffer may have changed: tensor versions (eager updates bump them) plus the
     module's own counter, which everything that rewrites parameters WITHOUT bumping versions advances -- a replayed
     hipGraph with the optimizer step inside (train.CapturedStep) -- and which every train() -> eval() transition
-    advances too, so an evaluation never runs on weights packed before the last training phase."""
-    v = getattr(module, "_mdie_epoch", 0)
-    for t in module.parameters():
-        v += t._version
-    for t in module.buffers():
+    advances too, so an evaluation never runs on weights packed before the last training phase.
+
+    The tensors are found once: walking the module tree through parameters() / buffers() cost 0.5 ms per forward -- half the
+    GPU time of a batch-32 step, which made `net(x)` 7 % slower than the engine it wraps.  The cached list is re-validated by
+    identity against the dicts the modules hold (a re-registered parameter or buffer rebuilds it)."""
+    c = module.__dict__.get("_mdie_fp_cache")
+    if c is not None:
+        for d, n, t in c:
+            if d.get(n) is not t:
+                c = None
+                break
+    if c is None:
+        c = []
+        for m in module.modules():
+            c.extend((m._parameters, n, t) for n, t in m._parameters.items() if t is not None)
+            c.extend((m._buffers, n, t) for n, t in m._buffers.items() if t is not None)
+        module.__dict__["_mdie_fp_cache"] = c
+        module.__dict__["_mdie_fp_gen"] = module.__dict__.get("_mdie_fp_gen", 0) + 1      # a different SET of tensors is a change too
+    v = getattr(module, "_mdie_epoch", 0) + (module.__dict__.get("_mdie_fp_gen", 0) << 40)
+    for _, _, t in c:
         v += t._version
     return v
 

@@ -157,3 +157,31 @@ def test_workers_and_epochs_draw_different_augmentations(tmp_path):
     loader = torch.utils.data.DataLoader(ds, batch_size=1, num_workers=2)
     epochs = [torch.cat([x for x, _ in loader]) for _ in range(3)]
     assert not (torch.equal(epochs[0], epochs[1]) and torch.equal(epochs[1], epochs[2]))   # (was: every epoch identical)
+
+
+def test_module_fingerprint_sees_every_kind_of_change():
+    """modules._fingerprint (decides when the eval engine repacks its weights): in-place parameter and buffer updates, the
+    module's own epoch counter (graph replays that rewrite weights without bumping versions), and a re-registered tensor --
+    the tensor list is cached on the module (the tree walk cost 0.5 ms per forward) and must notice a changed SET too."""
+    import torch
+    from models.cdan import CDAN
+    from mdie_amd import modules as M
+    net = CDAN()
+    a = M._fingerprint(net)
+    assert M._fingerprint(net) == a
+    with torch.no_grad():
+        net.encoder.conv1.conv.weight.add_(1.0)
+    b = M._fingerprint(net)
+    assert b != a
+    net.encoder.conv1.bn.running_mean.zero_()
+    c = M._fingerprint(net)
+    assert c not in (a, b)
+    net._mdie_epoch += 1
+    d = M._fingerprint(net)
+    assert d not in (a, b, c)
+    w = net.decoder.conv4.weight
+    net.decoder.conv4.weight = torch.nn.Parameter(w.detach().clone())          # same values, same version count, other tensor
+    e = M._fingerprint(net)
+    assert e not in (a, b, c, d) and M._fingerprint(net) == e
+    net.load_state_dict(CDAN().state_dict())                                    # copies in place: versions move
+    assert M._fingerprint(net) != e
