@@ -30,6 +30,7 @@ cp("tail_fold_ab_fp16.txt", "tail_fold_ab_fp16.txt")
 cp("layers_bf16_general_tail.txt", "layers_bf16_general_tail.txt")
 cp("batch_independence_probe.txt", "batch_independence_probe.txt")
 cp("train_timeline.txt", "train_timeline_bf16_b8_512.txt")
+cp("infer_timeline.txt", "infer_timeline_bf16_b32.txt")
 with open(os.path.join(dst, f"{pre}_configs.txt"), "w") as f:
     f.write("# BASELINE configs[2] (training step shape), [3] (routed, 9 weight sets) and [4] (1024x1024, its stated dtype fp16), plus the\n"
             "# PCIe-inclusive and batches-in-flight serving rates: output lines of tools/bench_train.py, bench_configs.py, bench_e2e.py,\n"

@@ -47,4 +47,5 @@ cd "$ROOT"
 python tools/traffic_from_pmc.py "$OUT/pmc" "$OUT/traffic_bf16_b32_256.json" > "$OUT/traffic_summary.txt" 2>&1
 python tools/mfma_busy_from_pmc.py "$OUT/pmc_mfma" "$OUT/mfma_busy.txt" > /dev/null 2>&1
 python tools/train_timeline.py "$OUT/train_stats" "$OUT/train_timeline.txt" > /dev/null 2>&1
+python tools/infer_timeline.py "$OUT/stats" "$OUT/infer_timeline.txt" > /dev/null 2>&1
 echo "done: $(ls "$OUT" | wc -l) files"
