@@ -185,3 +185,34 @@ def test_module_fingerprint_sees_every_kind_of_change():
     assert e not in (a, b, c, d) and M._fingerprint(net) == e
     net.load_state_dict(CDAN().state_dict())                                    # copies in place: versions move
     assert M._fingerprint(net) != e
+
+
+def test_timeline_tools_parse_a_rocprofv3_kernel_trace(tmp_path):
+    """tools/train_timeline.py and tools/infer_timeline.py on a hand-made rocprofv3 kernel trace (the column set of rocprofv3 1.x):
+    steps are cut at their marker kernels, launch order, queue and overlap come out."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tmp_path / "run" / "host"
+    d.mkdir(parents=True)
+    hdr = '"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name","Correlation_Id","Start_Timestamp","End_Timestamp","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Workgroup_Size_X","Workgroup_Size_Y","Workgroup_Size_Z","Grid_Size_X","Grid_Size_Y","Grid_Size_Z"\n'
+    rows, t, n = [], 1000, 0
+
+    def k(name, q, start, dur):
+        nonlocal n
+        n += 1
+        rows.append(f'"KERNEL_DISPATCH","Agent 2",{q},0,1,{n},1,"{name}",{n},{start},{start + dur},0,0,64,0,32,256,1,1,2048,1,1\n')
+
+    for step in range(12):
+        base = t + step * 100000
+        k("void mdie::nchw3_to_nhwc16_kernel<bf16>(int)", 1, base, 2000)                       # training marker
+        k("_ZN4mdie22conv_first_pool_kernelIDF16bLb1EEEvNS_9FirstArgsE", 1, base + 3000, 30000)      # inference marker
+        k("_ZN4mdie16conv_wide_kernelIDF16bLi1ELb1ELb0ELi4EEEvNS_8WideArgsE", 1, base + 33000, 60000)
+        k("_ZN4mdie11conv_kernelIDF16bLi3ELi16ELi16ELb0ELb0EEEvNS_8ConvArgsE", 2, base + 40000, 20000)   # a side-queue kernel under the wide one
+    (d / "1_kernel_trace.csv").write_text(hdr + "".join(rows))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "train_timeline.py"), str(tmp_path / "run")], capture_output=True, text=True, check=True).stdout
+    assert "4 kernels" in out and "conv_wide_kernel" in out and "nchw3_to_nhwc16_kernel" in out
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "infer_timeline.py"), str(tmp_path / "run")], capture_output=True, text=True, check=True).stdout
+    assert "on 2 queues" in out
+    wide = [l for l in out.splitlines() if "conv_wide_kernel" in l and "|" in l][0]
+    assert wide.split("|")[1].strip().startswith("conv_kernel")              # the overlap column names the side-queue kernel
