@@ -221,7 +221,7 @@ WGRAD_STREAM_MIN_PIXELS = 8 * 384 * 384
 _wgrad_side_this_step = False  # forward_train decides per step
 _WGRAD_SIDE = {}
 _wgrad_hooks_active = 0        # GradBuckets with hooks registered
-_wgrad_join_queued = set()     # devices whose join callback is queued in the running backward
+_wgrad_join_task = {}          # device -> id of the autograd graph task (= one backward) whose join callback is queued
 
 
 def _wgrad_side_stream(dev):
@@ -235,12 +235,12 @@ def _queue_wgrad_join(dev, main):
     """`main`: the stream backward runs on, taken inside a Function.backward (the engine has set it to the forward's stream there).
     The callback itself may run on an autograd worker thread whose current stream is the device's default one -- under graph
     capture that is NOT the capturing stream -- so the stream to join is fixed here, not looked up there."""
-    if dev in _wgrad_join_queued:
-        return
-    _wgrad_join_queued.add(dev)
+    task = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else None
+    if task is not None and task >= 0 and _wgrad_join_task.get(dev) == task:
+        return                       # this backward already has its join (keyed by the task, so a backward that died half way leaves nothing behind)
+    _wgrad_join_task[dev] = task
 
     def join():
-        _wgrad_join_queued.discard(dev)
         main.wait_stream(_wgrad_side_stream(dev))
 
     torch.autograd.Variable._execution_engine.queue_callback(join)
