@@ -2365,3 +2365,42 @@ def test_bn_stats_fold_from_partial_sums(L):
     assert rel_to_max(rm, (0.1 * mean).float()) <= 1e-5
     d.workspace_bytes = 16
     assert L.lib.mdie_bn_stats_fold(C.byref(d), None) == -1
+
+
+@pytest.mark.gpu
+def test_side_stream_join_survives_a_backward_that_raised(E, monkeypatch):
+    """A backward that dies after weight gradients were forked to the side stream never runs its join callback.  The next backward must
+    still join (the callback is keyed by the autograd graph task, not by a flag the dead one left set): its optimizer step is compared
+    bit for bit with the single-stream schedule."""
+    import mdie_amd.train as T
+    from models.cdan import CDAN
+    from oracle import params as P
+    monkeypatch.setattr(T, "WGRAD_STREAM_MIN_PIXELS", 0)
+    sd = P.make_state_dict(42)
+    x, t = (v.cuda() for v in P.lowlight_batch(9, 4, 128, 128))
+
+    def boom(g):            # a hook on the FIRST layer's weight: fires at the very end of backward, after every weight gradient was launched
+        raise RuntimeError("boom")
+
+    def run(side):
+        monkeypatch.setattr(T, "WGRAD_STREAM", side)
+        torch.manual_seed(5)
+        net = CDAN(precision="bf16")
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+        h = net.encoder.conv1.conv.weight.register_hook(boom)
+        with pytest.raises(RuntimeError, match="boom"):
+            torch.sqrt((net(x) - t) ** 2 + 1e-6).mean().backward()
+        h.remove()
+        torch.cuda.synchronize()
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            loss = torch.sqrt((net(x) - t) ** 2 + 1e-6).mean()
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), [p.detach().clone() for p in net.parameters()]
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and all(torch.equal(u, v) for u, v in zip(a[1], b[1]))
