@@ -212,7 +212,7 @@ def _pad_vec(v, n):
 # stream for the side stream when backward ends (an autograd-engine callback queued from the first call of each backward), so
 # the optimizer, the GradScaler, a gradient exchange that runs after backward -- everything that reads .grad -- comes after.
 # Not taken when something reads .grad DURING backward: a parameter that already holds a gradient (accumulation adds in place
-# on the main stream) or GradBuckets' per-parameter hooks.  And only where it pays (measured, bf16, B = 8, same box): eager 512x512
+# on the main stream), a parameter with a tensor / post-accumulate hook of its own, or GradBuckets' per-parameter hooks.  And only where it pays (measured, bf16, B = 8, same box): eager 512x512
 # 8.69 -> 8.11 ms; as a hipGraph 8.71 -> 8.73 (the replay gains nothing from the second branch) and 256x256 3.85 -> 4.21 as a graph,
 # 7.06 -> 8.87 eager (host-bound: the stream switches and record_stream calls cost more than the overlap returns) -- so: eager steps
 # of at least WGRAD_STREAM_MIN_PIXELS input pixels (the size from which Model.train_step stops capturing), never under capture.
@@ -257,7 +257,8 @@ def join_weight_gradients(dev):
 def _wgrad(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre=None, split=None, gap=0, param=None):
     """dW in the parameter's layout from the convolution's input segments and dy (stored cout_st channels)."""
     dev = dy.device
-    if _wgrad_side_this_step and WGRAD_STREAM and _wgrad_hooks_active == 0 and param is not None and param.grad is None:
+    if (_wgrad_side_this_step and WGRAD_STREAM and _wgrad_hooks_active == 0 and param is not None and param.grad is None
+            and not getattr(param, "_backward_hooks", None) and not getattr(param, "_post_accumulate_grad_hooks", None)):   # a hook would read the gradient during backward
         main, side = torch.cuda.current_stream(dev), _wgrad_side_stream(dev)
         side.wait_stream(main)
         _queue_wgrad_join(dev, main)
