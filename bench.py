@@ -29,42 +29,6 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}
 
 
-def kind_model(B, H, W, esz):
-    """Split of the fused-schedule algorithmic model per kernel kind:
-    kind -> (bytes, flops).  Sums to mdie_cdan_algorithmic_bytes / mdie_cdan_flops."""
-    P = float(H * W)
-    by = {k: [0.0, 0.0] for k in ("conv3x3", "conv1x1", "cbam", "upsample_add", "layout")}
-
-    def conv(kind, cin, cout, pin, pout, k):
-        by[kind][0] += (cin * pin + cout * pout) * esz
-        by[kind][1] += 2.0 * cin * cout * k * k * pin
-
-    def dense(c, p):
-        for i in range(4):
-            conv("conv3x3", c + 16 * i, 16, p, p, 3)
-        conv("conv1x1", c + 64, c, p, p, 1)
-
-    def cbam(c, p, mul):
-        by["cbam"][0] += (3 * c * p + (c * p if mul else 0) + 4 * p) * esz
-        by["cbam"][1] += 4.0 * 2 * c * (c // 16)  # two MLP layers on two pooled vectors (+ 7x7: 2*98*p)
-        by["cbam"][1] += 2.0 * 98 * p
-
-    def up(c, plo):
-        by["upsample_add"][0] += 9 * c * plo * esz
-
-    conv("conv3x3", 3, 64, P, P / 4, 3); dense(64, P / 4)
-    conv("conv3x3", 64, 128, P / 4, P / 16, 3); dense(128, P / 16)
-    conv("conv3x3", 128, 256, P / 16, P / 64, 3); dense(256, P / 64)
-    conv("conv3x3", 256, 512, P / 64, P / 64, 3)
-    cbam(512, P / 64, False)
-    conv("conv3x3", 512, 256, P / 64, P / 64, 3); by["conv3x3"][0] += 256 * P / 64 * esz; cbam(256, P / 64, True)
-    conv("conv3x3", 256, 128, P / 64, P / 64, 3); up(128, P / 64); cbam(128, P / 16, True)
-    conv("conv3x3", 128, 64, P / 16, P / 16, 3); up(64, P / 16); cbam(64, P / 4, True)
-    conv("conv3x3", 64, 3, P / 4, P / 4, 3); up(3, P / 4)
-    dense(3, P)
-    return {k: (v[0] * B, v[1] * B) for k, v in by.items()}
-
-
 def cpu_baseline(sd, x_cpu, seconds_budget=16.0):
     """The oracle (a port of the reference's PyTorch CPU path) on this host's cores: the whole batch of the GPU run
     (B = 32 at 256x256, 1 warm-up + timed forwards, median) on every core this process may use, plus a
@@ -249,16 +213,21 @@ def main():
         # ---- roofline: per-launch HIP events on the launch stream (instrumented mode, eager) ------------------
         prof = {}
         if rank == 0:
+            # every launch reports its kind and ITS share of the SURVEY 8d model (mdie_launch_info, from the engine's own launch
+            # list): a kind's bytes are the bytes of launches that exist (the folded 1x1 transition of decoder.final_dense is
+            # booked with the four 3x3 launches that do its work)
             reps = 5
             for _ in range(reps):
                 _, extras = eng.forward(x, out=y, profile=True)
-                for kind, ms in extras["launches"]:
+                for (kind, ms), (_, by, fl) in zip(extras["launches"], extras["launch_info"]):
                     k = "cbam" if kind.startswith("cbam") else kind
-                    prof.setdefault(k, [0, 0.0])
-                    prof[k][0] += 1
-                    prof[k][1] += ms
+                    p_ = prof.setdefault(k, [0, 0.0, 0.0, 0.0])
+                    p_[0] += 1
+                    p_[1] += ms
+                    p_[2] += by
+                    p_[3] += fl
             for k in prof:
-                prof[k] = (prof[k][0] // reps, prof[k][1] / reps)
+                prof[k] = (prof[k][0] // reps, prof[k][1] / reps, prof[k][2] / reps, prof[k][3] / reps)
 
     if rank != 0:
         if dist is not None:
@@ -270,11 +239,11 @@ def main():
     esz = 4 if args.precision == "fp32" else 2
     alg_bytes = L.lib.mdie_cdan_algorithmic_bytes(B, S, S, esz)
     flops = L.lib.mdie_cdan_flops(B, S, S)
-    model = kind_model(B, S, S, esz)
     kernel_ms = sum(v[1] for v in prof.values())
+    model_bytes = sum(v[2] for v in prof.values())
+    assert abs(model_bytes - alg_bytes) <= 1e-6 * alg_bytes, f"per-launch model {model_bytes} != mdie_cdan_algorithmic_bytes {alg_bytes}"
     per_kernel = {}
-    for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
-        b, f = model.get(k, (0.0, 0.0))
+    for k, (n, ms, b, f) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
         per_kernel[k] = {"launches": n, "ms": round(ms, 4), "alg_GB": round(b / 1e9, 4), "GBps": round(b / ms / 1e6, 1) if ms else None,
                          "hbm_frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4) if ms else None,
                          "TFLOPs": round(f / ms / 1e9, 1) if ms and f else None}
@@ -293,7 +262,10 @@ def main():
             traffic_note = (f"{os.path.basename(tfile)} was measured on kernel source {tj.get('kernel_source_sha16')}, this tree is {source_sha16()}: "
                             f"stale, not reported (was {tj.get('hbm_bytes_per_step')})")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic, "traffic_source": traffic_note,
+                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                # the same bytes over the timed step itself (side branches overlapped, launch gaps included) instead of the serial kernel time
+                "frac_step": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": traffic_note,
                 "kernel": "cdan_forward (all launches of one step)", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_step": alg_bytes, "flops_per_step": flops,
                 "mfma_frac": round(flops / (kernel_ms * 1e-3) / 1e12 / MFMA_PEAK_TF[args.precision], 4) if kernel_ms else None,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 20
+#define MDIE_ABI_VERSION 21
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1,
        MDIE_F16 = 2 /* IEEE half: the reference's mixed-precision dtype (torch.cuda.amp.autocast, models/model.py:15,159) */ };
@@ -381,7 +381,15 @@ void mdie_aux_destroy(void* aux);
  * taps (optional, host array of MDIE_TAP_COUNT) is filled with workspace views.
  * launch_ms (optional, host array of capacity max_launches) turns on the instrumented mode:
  * a hipEvent pair around every kernel launch, synchronised at the end (NOT capturable);
- * n_launches receives the count, launch_kind[i] an MDIE_K* id. */
+ * n_launches receives the count, launch_kind[i] an MDIE_K* id; launch_info (optional, capacity max_launches) receives, per
+ * launch, the layer it belongs to and ITS share of the fused-schedule model of SURVEY.md section 8d (the shares of one forward
+ * sum to mdie_cdan_algorithmic_bytes / mdie_cdan_flops: a transition folded into its producers is booked with them). */
+typedef struct {
+  char label[40];          /* e.g. "enc.conv2+pool", "dense3.l1", "cbam2.spatial*d2", "final.l3+tr+sigmoid" */
+  double alg_bytes;        /* algorithmic HBM bytes of this launch (activations + the parameters it reads) */
+  double flops;            /* 2 * MAC */
+} mdie_launch_info;
+
 typedef struct {
   int dtype;
   int B, H, W;
@@ -393,6 +401,7 @@ typedef struct {
   int flags;                /* MDIE_FWD_* bits */
   void* aux;                /* mdie_aux_create handle or NULL; used only when `stream` is not capturing (see above) */
   float* launch_ms; int* launch_kind; int max_launches; int* n_launches;
+  mdie_launch_info* launch_info;
 } mdie_cdan_fwd_desc;
 
 enum { MDIE_FWD_FUSED_TAIL = 1 /* run upsample + final_dense + sigmoid as ONE launch (mdie_tail_fwd) instead of 7 */,
@@ -562,7 +571,7 @@ typedef struct {
   const void* x; int x_stride;
   void* g; int g_stride;
   const float* mean; const float* invstd;
-  int nlayer;                                 /* 2..5 */
+  int nlayer;                                 /* 1..5 */
   const void* da[5]; int da_stride[5];
   const float* scale[5]; const float* shift[5]; const float* coef[5]; int coef_stride[5];
   long da_plane[5];                           /* 0, or the plane stride of da[j] (one plane per 16 channels, as mdie_bn_bwd_desc.da_plane);

@@ -224,6 +224,7 @@ struct LaunchTimer {
   hipStream_t stream = nullptr;
   hipEvent_t* ev = nullptr;  // 2 * cap events
   int* kind = nullptr;
+  mdie_launch_info* info = nullptr;   // optional: labels + model shares, filled by the engine after each call (engine.hip: note)
   int cap = 0, n = 0;
   bool on() const { return ev != nullptr; }
   void begin(int k) {

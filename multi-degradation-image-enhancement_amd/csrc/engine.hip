@@ -399,6 +399,57 @@ struct Aux {
   hipEvent_t fork[3], join[3];
 };
 
+// Instrumented mode only (mdie_cdan_fwd_desc.launch_info): which layer a launch belongs to and its share of the fused-schedule
+// model of SURVEY.md 8d -- elements per image as mdie_cdan_algorithmic_bytes counts them, plus the parameters the launch reads
+// (the model's "weights once per batch" term, 3 585 663 elements, split over the launches that read them).  A call's launches
+// are [from, timer->n); the share goes to the first of them unless a caller splits it (CBAM stages).
+struct Notes {
+  LaunchTimer* lt = nullptr;
+  double esz = 2, Bn = 1;
+  int dtype = MDIE_BF16;
+  int mark() const { return lt ? lt->n : 0; }
+  bool on() const { return lt && lt->info; }
+  void put(int i, const char* label, double elems, double params, double flops) const {
+    if (!on() || i >= lt->n || i >= lt->cap) return;
+    mdie_launch_info& li = lt->info[i];
+    snprintf(li.label, sizeof li.label, "%s", label);
+    li.alg_bytes = (elems * Bn + params) * esz;
+    li.flops = flops * Bn;
+  }
+  void note(int from, const char* label, double elems, double params, double flops) const {
+    if (!on()) return;
+    for (int i = from; i < lt->n; ++i) put(i, label, i == from ? elems : 0.0, i == from ? params : 0.0, i == from ? flops : 0.0);
+  }
+  // one convolution: reads cin x pin, writes cout x pout (+ extra elements: a residual read), real channel counts
+  void conv(int from, const char* label, int id, double pin, double pout, double extra = 0.0) const {
+    if (!on()) return;
+    const ConvSpec& s = arch(dtype).conv[id];
+    const double params = (double)s.cin * s.cout * s.ks * s.ks + s.cout + 2.0 * (!s.bn_post.empty() ? s.cout : !s.bn_pre.empty() ? s.cin : 0);
+    note(from, label, s.cin * pin + s.cout * pout + extra, params, 2.0 * s.cin * s.cout * s.ks * s.ks * pin);
+  }
+  // a CBAM stage: 2 reads + 1 write of the tensor, the multiplicand, the 2-channel map both ways; the global pool rides on the
+  // producer (a standalone pool launch is traffic beyond the model: 0 bytes)
+  void cbam(int from, const char* name, int C, double p, bool mul, const char* mulname) const {
+    if (!on()) return;
+    const double mlp = 2.0 * C * (C / 16) + C / 16 + C;
+    bool gate_seen = false;
+    for (int i = from; i < lt->n && i < lt->cap; ++i) {
+      char label[40];
+      switch (lt->kind[i]) {
+        case MDIE_K_CBAM_POOL: snprintf(label, sizeof label, "%s.pool", name); put(i, label, 0, 0, 0); break;
+        case MDIE_K_CBAM_GATE: gate_seen = true; snprintf(label, sizeof label, "%s.gate", name); put(i, label, 0, mlp, 8.0 * C * (C / 16)); break;
+        case MDIE_K_CBAM_CHANPOOL:
+          snprintf(label, sizeof label, gate_seen ? "%s.chanpool" : "%s.gate+chanpool", name);
+          put(i, label, C * p + 2 * p, gate_seen ? 0 : mlp, gate_seen ? 0 : 8.0 * C * (C / 16));
+          break;
+        default:
+          snprintf(label, sizeof label, "%s.spatial%s%s", name, mul ? "*" : "", mul ? mulname : "");
+          put(i, label, (mul ? 3.0 : 2.0) * C * p + 2 * p, 100, 2.0 * 98 * p);
+      }
+    }
+  }
+};
+
 struct Ctx {
   int dtype, B;
   const char* params;
@@ -406,13 +457,15 @@ struct Ctx {
   BlobLayout L;
   hipStream_t stream;
   size_t esz;
+  const Notes* notes = nullptr;
 };
 
 static mdie_seg seg(const Ctx& c, const Buf& b) { return mdie_seg{c.ws + b.off, b.C, b.C}; }
 
-static int run_conv(const Ctx& c, int id, int H, int W, std::initializer_list<Buf> in, const Buf& out, int act, int pool,
+static int run_conv(const Ctx& c, const char* label, int id, int H, int W, std::initializer_list<Buf> in, const Buf& out, int act, int pool,
                     const Buf* residual, float* out_nchw3 = nullptr, float* pool_partial = nullptr, const mdie_tr_fuse* tr = nullptr) {
   const ConvSpec& s = arch(c.dtype).conv[id];
+  const int from = c.notes ? c.notes->mark() : 0;
   mdie_conv_desc d{};
   d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.ksize = s.ks;
   d.nseg = 0; d.cin = 0;
@@ -432,24 +485,35 @@ static int run_conv(const Ctx& c, int id, int H, int W, std::initializer_list<Bu
   d.out_nchw3 = out_nchw3;
   d.pool_partial = pool_partial;
   d.tr = tr;
-  return mdie_conv_fwd(&d, c.stream);
+  const int rc = mdie_conv_fwd(&d, c.stream);
+  if (c.notes && label && !tr) {
+    const double pin = (double)H * W;
+    c.notes->conv(from, label, id, pin, pool ? pin / 4 : pin, residual ? (double)s.cout * pin : 0.0);
+  }
+  return rc;
 }
 
 static int run_dense(const Ctx& c, int block, int H, int W, const Buf& base, const Buf* g, const Buf& out, int act,
                      float* out_nchw3 = nullptr, bool have_g0 = false) {
   const int id0 = CV_DENSE0 + block * 5;
+  static const char* const names[4][5] = {{"dense1.l0", "dense1.l1", "dense1.l2", "dense1.l3", "dense1.tr"},
+                                          {"dense2.l0", "dense2.l1", "dense2.l2", "dense2.l3", "dense2.tr"},
+                                          {"dense3.l0", "dense3.l1", "dense3.l2", "dense3.l3", "dense3.tr"},
+                                          {"final.l0", "final.l1", "final.l2", "final.l3", "final.tr+sigmoid->nchw"}};
+  const char* const* nm = names[block];
   int e;
-  if (!have_g0 && (e = run_conv(c, id0 + 0, H, W, {base}, g[0], MDIE_ACT_NONE, 0, nullptr))) return e;
-  if ((e = run_conv(c, id0 + 1, H, W, {base, g[0]}, g[1], MDIE_ACT_NONE, 0, nullptr))) return e;
-  if ((e = run_conv(c, id0 + 2, H, W, {base, g[0], g[1]}, g[2], MDIE_ACT_NONE, 0, nullptr))) return e;
-  if ((e = run_conv(c, id0 + 3, H, W, {base, g[0], g[1], g[2]}, g[3], MDIE_ACT_NONE, 0, nullptr))) return e;
-  return run_conv(c, id0 + 4, H, W, {base, g[0], g[1], g[2], g[3]}, out, act, 0, nullptr, out_nchw3);
+  if (!have_g0 && (e = run_conv(c, nm[0], id0 + 0, H, W, {base}, g[0], MDIE_ACT_NONE, 0, nullptr))) return e;
+  if ((e = run_conv(c, nm[1], id0 + 1, H, W, {base, g[0]}, g[1], MDIE_ACT_NONE, 0, nullptr))) return e;
+  if ((e = run_conv(c, nm[2], id0 + 2, H, W, {base, g[0], g[1]}, g[2], MDIE_ACT_NONE, 0, nullptr))) return e;
+  if ((e = run_conv(c, nm[3], id0 + 3, H, W, {base, g[0], g[1], g[2]}, g[3], MDIE_ACT_NONE, 0, nullptr))) return e;
+  return run_conv(c, nm[4], id0 + 4, H, W, {base, g[0], g[1], g[2], g[3]}, out, act, 0, nullptr, out_nchw3);
 }
 
 // pooled_slabs > 0: the producer of x already wrote that many pooling partials per image into the plan's pool buffer
 static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, const Buf& x, const Buf* mul, const Buf& out,
                           int pooled_slabs = 0) {
   const CbamBlob& o = c.L.cbam[id];
+  const int from = c.notes ? c.notes->mark() : 0;
   mdie_cbam_desc d{};
   d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.C = arch(c.dtype).cbam[id].C;
   d.x = c.ws + x.off; d.x_stride = x.C;
@@ -461,13 +525,21 @@ static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, con
   d.out = c.ws + out.off; d.out_stride = out.C;
   d.workspace = c.ws + P.cbam_ws; d.workspace_bytes = P.cbam_ws_bytes;
   if (pooled_slabs > 0) { d.pool_partial = reinterpret_cast<const float*>(c.ws + P.pool_ws); d.pool_slabs = pooled_slabs; }
-  return mdie_cbam_fwd(&d, c.stream);
+  const int rc = mdie_cbam_fwd(&d, c.stream);
+  if (c.notes) {
+    static const char* const names[4] = {"bott", "cbam1", "cbam2", "cbam3"}, * const muls[4] = {"", "d3", "d2", "d1"};
+    c.notes->cbam(from, names[id], d.C, (double)H * W, mul != nullptr, muls[id]);
+  }
+  return rc;
 }
 
-static int run_up(const Ctx& c, const Plan& P, int H, int W, const Buf& lo, const Buf& skip, const Buf& out) {
+static int run_up(const Ctx& c, const Plan& P, const char* label, int H, int W, const Buf& lo, const Buf& skip, const Buf& out) {
   // the upsampled + skip tensor feeds a CBAM: reduce it for the channel gate while writing it
-  return mdie_upsample2x_add_pool(c.dtype, c.B, H, W, lo.C, c.ws + lo.off, lo.C, c.ws + skip.off, skip.C, c.ws + out.off, out.C,
-                                  reinterpret_cast<float*>(c.ws + P.pool_ws), mdie_pool_slabs(2 * H, 2 * W), c.stream);
+  const int from = c.notes ? c.notes->mark() : 0;
+  const int rc = mdie_upsample2x_add_pool(c.dtype, c.B, H, W, lo.C, c.ws + lo.off, lo.C, c.ws + skip.off, skip.C, c.ws + out.off, out.C,
+                                          reinterpret_cast<float*>(c.ws + P.pool_ws), mdie_pool_slabs(2 * H, 2 * W), c.stream);
+  if (c.notes) c.notes->note(from, label, 9.0 * lo.C * H * W, 0, 0);      // read lo, read skip (4x), write the sum (4x)
+  return rc;
 }
 
 // Concurrency of the encoder DenseBlocks with the main path, in the two forms a caller's stream can be in:
@@ -562,6 +634,10 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   if (d->workspace_bytes < P.total) { set_error("mdie_cdan_forward: workspace %zu < %zu bytes", d->workspace_bytes, P.total); return MDIE_ENOSPC; }
   Ctx c{d->dtype, B, reinterpret_cast<const char*>(d->params), reinterpret_cast<char*>(d->workspace), blob_layout(d->dtype), stream,
         dtype_size(d->dtype)};
+  Notes notes;
+  notes.lt = current_timer(); notes.esz = (double)c.esz; notes.Bn = (double)B; notes.dtype = d->dtype;
+  if (notes.on()) c.notes = &notes;
+  const double PX = (double)H * W;
   const int h1 = H / 2, w1 = W / 2, h2 = H / 4, w2 = W / 4, h3 = H / 8, w3 = W / 8;
   int e;
 #define RUN(call) do { if ((e = (call))) return e; } while (0)
@@ -595,7 +671,9 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     f.post_shift = reinterpret_cast<const float*>(c.params + c.L.conv[CV_E1].post_shift);
     f.cout = 64; f.act = MDIE_ACT_RELU; f.pool = 1;
     f.out = c.ws + P.o[0].off; f.out_stride = P.o[0].C;
+    const int from = notes.mark();
     RUN(mdie_conv_first_fwd(&f, stream));
+    notes.conv(from, "enc.conv1+pool", CV_E1, PX, PX / 4);
   }
   // WHERE the side branches start (round 3, same-box sweep over fork points, eager launches, B = 32 at 256x256): forking each block
   // as soon as its input exists (dense1 after conv1, dense2 after conv2, dense3 after conv3) puts all three next to conv2 / conv3 /
@@ -604,8 +682,8 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   // dense3 is needed first (cbam1) and stays where it was; dense1 and dense2 start after conv4 and run beside the bottleneck CBAM,
   // dec.conv1 and the decoder's small kernels: 30.2 k -> 31.0 k images/s (+2.6 %; all three after conv4 +2.3 %, only dense1 late
   // +2.2 %, all after the bottleneck +1 %, all three in line on ONE side stream -2 %; stream priorities: nothing).
-  RUN(run_conv(c, CV_E2, h1, w1, {P.o[0]}, P.o[1], MDIE_ACT_RELU, 1, nullptr));
-  RUN(run_conv(c, CV_E3, h2, w2, {P.o[1]}, P.o[2], MDIE_ACT_RELU, 1, nullptr));
+  RUN(run_conv(c, "enc.conv2+pool", CV_E2, h1, w1, {P.o[0]}, P.o[1], MDIE_ACT_RELU, 1, nullptr));
+  RUN(run_conv(c, "enc.conv3+pool", CV_E3, h2, w2, {P.o[1]}, P.o[2], MDIE_ACT_RELU, 1, nullptr));
   RUN(side_dense(2, h3, w3));
   // the two CBAMs at the deep end pool tensors a 64-wide convolution has just written: that convolution emits the
   // per-tile channel sums / maxima itself (one slab per tile), unless the picture is so large that a gate would
@@ -614,24 +692,24 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   const int te = mdie_conv_tile(B, h3, w3, 512), td = mdie_conv_tile(B, h3, w3, 256);
   const int slabs_e = cdiv(h3, te) * cdiv(w3, te), slabs_d = cdiv(h3, td) * cdiv(w3, td);
   const bool fuse_e = slabs_e <= MDIE_POOL_SLABS_MAX, fuse_d = slabs_d <= MDIE_POOL_SLABS_MAX;
-  RUN(run_conv(c, CV_E4, h3, w3, {P.o[2]}, P.e, MDIE_ACT_RELU, 0, nullptr, nullptr, fuse_e ? pool_buf : nullptr));
+  RUN(run_conv(c, fuse_e ? "enc.conv4+pool-stats" : "enc.conv4", CV_E4, h3, w3, {P.o[2]}, P.e, MDIE_ACT_RELU, 0, nullptr, nullptr, fuse_e ? pool_buf : nullptr));
   RUN(side_dense(1, h2, w2));
   RUN(side_dense(0, h1, w1));
   // bottleneck, models/cdan.py:173
   RUN(run_cbam_stage(c, P, CB_BOTT, h3, w3, P.e, nullptr, P.bott, fuse_e ? slabs_e : 0));
   // Decoder.forward, models/cdan.py:126-159
-  RUN(run_conv(c, CV_D1, h3, w3, {P.bott}, P.t1, MDIE_ACT_RELU, 0, &P.o[2], nullptr, fuse_d ? pool_buf : nullptr));   // convT+BN+ReLU, + skip2
+  RUN(run_conv(c, fuse_d ? "dec.conv1+skip2+pool-stats" : "dec.conv1+skip2", CV_D1, h3, w3, {P.bott}, P.t1, MDIE_ACT_RELU, 0, &P.o[2], nullptr, fuse_d ? pool_buf : nullptr));   // convT+BN+ReLU, + skip2
   RUN(join_dense(2));
   RUN(run_cbam_stage(c, P, CB_1, h3, w3, P.t1, &P.d[2], P.u1, fuse_d ? slabs_d : 0));  // cbam1, *= dense3
-  RUN(run_conv(c, CV_D2, h3, w3, {P.u1}, P.t2lo, MDIE_ACT_RELU, 0, nullptr));
-  RUN(run_up(c, P, h3, w3, P.t2lo, P.o[1], P.t2));                                     // bilinear x2 + skip1
+  RUN(run_conv(c, "dec.conv2", CV_D2, h3, w3, {P.u1}, P.t2lo, MDIE_ACT_RELU, 0, nullptr));
+  RUN(run_up(c, P, "up2+skip1+pool", h3, w3, P.t2lo, P.o[1], P.t2));                    // bilinear x2 + skip1
   RUN(join_dense(1));
   RUN(run_cbam_stage(c, P, CB_2, h2, w2, P.t2, &P.d[1], P.u2, mdie_pool_slabs(h2, w2)));
-  RUN(run_conv(c, CV_D3, h2, w2, {P.u2}, P.t3lo, MDIE_ACT_RELU, 0, nullptr));
-  RUN(run_up(c, P, h2, w2, P.t3lo, P.o[0], P.t3));
+  RUN(run_conv(c, "dec.conv3", CV_D3, h2, w2, {P.u2}, P.t3lo, MDIE_ACT_RELU, 0, nullptr));
+  RUN(run_up(c, P, "up3+skip0+pool", h2, w2, P.t3lo, P.o[0], P.t3));
   RUN(join_dense(0));
   RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3, mdie_pool_slabs(h1, w1)));
-  RUN(run_conv(c, CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
+  RUN(run_conv(c, "dec.conv4", CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
   if (!(d->flags & MDIE_FWD_FUSED_TAIL)) {
     // bilinear x2 + x (x read from its fp32 NCHW planes), final_dense, sigmoid written straight to NCHW
     // upsample + x and final_dense layer 0 in one launch (csrc/updense0.hip); then layers 1..3 and the transition.
@@ -661,7 +739,17 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
       mdie_tr_fuse t0 = tr;
       t0.c0 = P.t4.C;                                       // g0 follows the base group in the transition's stored input
       if (fold_tr) u.tr = &t0;
+      const int from = notes.mark();
       RUN(mdie_up_add_dense0_fwd(&u, stream));
+      if (notes.on()) {
+        // upsample + x (read lo, read x, the sum written once as the block's base), layer 0 (reads the base, writes g0); folded: + the
+        // transition's terms of the base and of g0
+        const ConvSpec& l0 = arch(d->dtype).conv[id0];
+        const double up_el = 9.0 * 3 * PX / 4, l0_el = 3 * PX + 16 * PX, l0_par = 3.0 * 16 * 9 + 16 + 2 * 3, l0_fl = 2.0 * 3 * 16 * 9 * PX;
+        (void)l0;
+        if (fold_tr) notes.note(from, "up4+x+final.l0+tr", up_el + l0_el + (3 + 16) * PX, l0_par, l0_fl + 2.0 * (3 + 16) * 3 * PX);
+        else notes.note(from, "up4+x+final.l0", up_el + l0_el, l0_par, l0_fl);
+      }
     }
     if (fold_tr) {
       mdie_tr_fuse t1 = tr, t2 = tr, t3 = tr;
@@ -670,9 +758,22 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
       t3.post_scale = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + 4].post_scale);
       t3.post_shift = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + 4].post_shift);
       t3.act = MDIE_ACT_SIGMOID; t3.out_nchw3 = d->y;
-      RUN(run_conv(c, id0 + 1, H, W, {P.t4, P.fg[0]}, P.fg[1], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, &t1));
-      RUN(run_conv(c, id0 + 2, H, W, {P.t4, P.fg[0], P.fg[1]}, P.fg[2], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, &t2));
-      RUN(run_conv(c, id0 + 3, H, W, {P.t4, P.fg[0], P.fg[1], P.fg[2]}, P.fg[3], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, &t3));
+      // (the folded transition is booked with its producers: each reads its 16 new channels once more in the model's terms, the
+      //  last one writes the 3 outputs and carries the transition's parameters)
+      const double tr_par = 67.0 * 3 + 3 + 2 * 67;
+      for (int l = 1; l <= 3; ++l) {
+        const int from = notes.mark();
+        const mdie_tr_fuse* tl = l == 1 ? &t1 : l == 2 ? &t2 : &t3;
+        if (l == 1) RUN(run_conv(c, nullptr, id0 + 1, H, W, {P.t4, P.fg[0]}, P.fg[1], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, tl));
+        else if (l == 2) RUN(run_conv(c, nullptr, id0 + 2, H, W, {P.t4, P.fg[0], P.fg[1]}, P.fg[2], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, tl));
+        else RUN(run_conv(c, nullptr, id0 + 3, H, W, {P.t4, P.fg[0], P.fg[1], P.fg[2]}, P.fg[3], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, tl));
+        if (notes.on()) {
+          const double cin = 3 + 16.0 * l;
+          static const char* const nm[4] = {"", "final.l1+tr", "final.l2+tr", "final.l3+tr+sigmoid->nchw"};
+          notes.note(from, nm[l], cin * PX + 16 * PX + 16 * PX + (l == 3 ? 3 * PX : 0), cin * 16 * 9 + 16 + 2 * cin + (l == 3 ? tr_par : 0),
+                     2.0 * cin * 16 * 9 * PX + 2.0 * 16 * 3 * PX);
+        }
+      }
     } else {
       RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID, d->y, true));
     }
@@ -681,7 +782,13 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     t.dtype = d->dtype; t.B = B; t.H = H; t.W = W;
     t.lo = c.ws + P.t4lo.off; t.lo_stride = P.t4lo.C;
     t.x = d->x; t.y = d->y; t.params = c.params + c.L.tail;
+    const int from = notes.mark();
     RUN(mdie_tail_fwd(&t, stream));                                                 // all of the above, one launch
+    if (notes.on()) {   // booked with what the general chain moves and computes (the fused launch moves less)
+      double el = 9.0 * 3 * PX / 4 + (3 + 64) * PX + 3 * PX, par = 67.0 * 3 + 3 + 2 * 67, fl = 2.0 * 67 * 3 * PX;
+      for (int l = 0; l < 4; ++l) { const double cin = 3 + 16.0 * l; el += cin * PX + 16 * PX; par += cin * 16 * 9 + 16 + 2 * cin; fl += 2.0 * cin * 16 * 9 * PX; }
+      notes.note(from, "up4+x+final_dense+sigmoid (fused tail)", el, par, fl);
+    }
   }
 #undef RUN
   if (d->taps) {
@@ -737,7 +844,8 @@ extern "C" int mdie_cdan_forward(const mdie_cdan_fwd_desc* d, void* stream) {
   // instrumented mode: one event pair per launch (not capturable; synchronises at the end)
   MDIE_REQUIRE(d->launch_kind && d->n_launches && d->max_launches > 0, "mdie_cdan_forward: instrumentation buffers missing");
   LaunchTimer t;
-  t.stream = s; t.cap = d->max_launches; t.kind = d->launch_kind;
+  t.stream = s; t.cap = d->max_launches; t.kind = d->launch_kind; t.info = d->launch_info;
+  if (t.info) memset(t.info, 0, sizeof(mdie_launch_info) * (size_t)t.cap);
   std::vector<hipEvent_t> ev(2 * (size_t)t.cap);
   for (auto& x : ev) (void)hipEventCreate(&x);
   t.ev = ev.data();

@@ -132,8 +132,8 @@ class CdanEngine:
             d.taps = taps
         if profile:
             cap = 256
-            ms, kind, n = (C.c_float * cap)(), (C.c_int * cap)(), C.c_int(0)
-            d.launch_ms, d.launch_kind, d.max_launches, d.n_launches = ms, kind, cap, C.pointer(n)
+            ms, kind, n, info = (C.c_float * cap)(), (C.c_int * cap)(), C.c_int(0), (L.LaunchInfo * cap)()
+            d.launch_ms, d.launch_kind, d.max_launches, d.n_launches, d.launch_info = ms, kind, cap, C.pointer(n), info
         with torch.cuda.device(self.device):
             L.check(L.lib.mdie_cdan_forward(C.byref(d), _stream_ptr(self.device)), "mdie_cdan_forward")
         extras = {}
@@ -141,6 +141,8 @@ class CdanEngine:
             extras["taps"] = {name: self._read_tap(taps[i], B) for i, name in enumerate(L.TAP_NAMES) if taps[i].ptr}
         if profile:
             extras["launches"] = [(L.KERNEL_KINDS[kind[i]], float(ms[i])) for i in range(n.value)]
+            # per launch: the layer it belongs to and its share of the SURVEY 8d model (bytes, FLOPs) -- from the engine's own launch list
+            extras["launch_info"] = [(info[i].label.decode(), float(info[i].alg_bytes), float(info[i].flops)) for i in range(n.value)]
         return (y, extras) if extras else y
 
     def _read_tap(self, tap, B):

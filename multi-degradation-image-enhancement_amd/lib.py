@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 20
+ABI_VERSION = 21
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 FWD_SERIAL = 2
@@ -173,13 +173,17 @@ class Tap(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("channels", C.c_int), ("stride", C.c_int), ("H", C.c_int), ("W", C.c_int)]
 
 
+class LaunchInfo(C.Structure):
+    _fields_ = [("label", C.c_char * 40), ("alg_bytes", C.c_double), ("flops", C.c_double)]
+
+
 class CdanFwdDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("params", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("taps", C.POINTER(Tap)), ("flags", C.c_int), ("aux", C.c_void_p),
                 ("launch_ms", C.POINTER(C.c_float)), ("launch_kind", C.POINTER(C.c_int)),
-                ("max_launches", C.c_int), ("n_launches", C.POINTER(C.c_int))]
+                ("max_launches", C.c_int), ("n_launches", C.POINTER(C.c_int)), ("launch_info", C.POINTER(LaunchInfo))]
 
 
 # name -> (restype, argtypes); must list every function include/mdie.h declares

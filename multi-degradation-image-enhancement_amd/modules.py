@@ -109,9 +109,16 @@ class CDAN(nn.Module):
         eng = self._engines.get(key)
         fp = (_fingerprint(self), id(next(self.parameters())))
         if eng is None:
-            while len(self._engines) >= MAX_ENGINES:           # transient streams must not pin a workspace each forever
+            # transient streams must not pin a workspace each forever: the least recently used engine goes.  Its last forward may
+            # still be running: wait for THAT engine's stream (the key holds its handle), not for the device -- a device-wide
+            # synchronize per forward is what five round-robin streams would pay -- and never under capture, where any synchronize
+            # is illegal (there nothing is evicted: the cache grows by one engine and is trimmed by the next eager forward).
+            while len(self._engines) >= MAX_ENGINES and not torch.cuda.is_current_stream_capturing():
                 old = next(iter(self._engines))
-                torch.cuda.synchronize(device)                  # its last forward may still be running on its stream
+                try:
+                    torch.cuda.ExternalStream(old[2], device=device).synchronize()
+                except Exception:                               # (a stream its owner has destroyed since)
+                    torch.cuda.synchronize(device)
                 del self._engines[old], self._packed[old]
             eng = self._engines[key] = E.CdanEngine(device, self.precision)
             self._packed[key] = None
@@ -161,9 +168,18 @@ class CBAM(nn.Module):
             self.SpatialGate.spatial.bn.num_batches_tracked += 1
             y = T.cbam(dt, self, x.to(E.TORCH_DTYPE[dt]).contiguous(memory_format=torch.channels_last))
             return y.float().contiguous()
+        from . import ops  # noqa: F401  (registers torch.ops.mdie.*)
+        return torch.ops.mdie.cbam_forward(x, *self._eval_constants(x.device), dt, self.no_spatial)
+
+    def _eval_constants(self, dev):
+        """(w1, b1, w2, b2, w7, folded BatchNorm(1)) as fp32 device tensors, rebuilt only when a parameter or buffer has changed
+        (`_fingerprint`): a forward used to walk the state_dict, copy eight tensors and fold the BatchNorm on every call."""
+        fp = (_fingerprint(self), str(dev))
+        c = self.__dict__.get("_mdie_eval_consts")
+        if c is not None and c[0] == fp:
+            return c[1]
         sd = self.state_dict()
-        dev = x.device
-        f = lambda k: sd[k].to(dev, torch.float32).contiguous()
+        f = lambda k: sd[k].detach().to(dev, torch.float32).contiguous()
         if self.no_spatial:
             w7 = torch.zeros(98, device=dev)
             bn = torch.tensor([1.0, 0.0], device=dev)
@@ -172,6 +188,6 @@ class CBAM(nn.Module):
             p = "SpatialGate.spatial.bn."
             s = f(p + "weight") / torch.sqrt(f(p + "running_var") + 1e-5)
             bn = torch.cat((s, f(p + "bias") - f(p + "running_mean") * s))
-        from . import ops  # noqa: F401  (registers torch.ops.mdie.*)
-        return torch.ops.mdie.cbam_forward(x, f("ChannelGate.mlp.1.weight"), f("ChannelGate.mlp.1.bias"), f("ChannelGate.mlp.3.weight"),
-                                           f("ChannelGate.mlp.3.bias"), w7, bn, dt, self.no_spatial)
+        consts = (f("ChannelGate.mlp.1.weight"), f("ChannelGate.mlp.1.bias"), f("ChannelGate.mlp.3.weight"), f("ChannelGate.mlp.3.bias"), w7, bn)
+        self.__dict__["_mdie_eval_consts"] = (fp, consts)
+        return consts

@@ -79,6 +79,7 @@ class _PackPlan:
 
     def __init__(self, dt):
         self.dt, self.jobs, self.table, self.n_uploaded, self.filled, self.param_ptrs = dt, {}, None, 0, False, frozenset()
+        self.retired = []     # superseded job tables: a CapturedStep that recorded the batch launch replays with the OLD table's address
 
     def lookup(self, key):
         j = self.jobs.get(key)
@@ -96,6 +97,8 @@ class _PackPlan:
             arr = (L.PackJob * len(self.jobs))()
             for src, dst, i, args in self.jobs.values():
                 arr[i] = L.PackJob(src.data_ptr(), dst.data_ptr(), *args)
+            if self.table is not None:
+                self.retired.append(self.table)       # (a few hundred bytes each; freed with the plan) -- its jobs stay valid: jobs are only ever appended
             self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
             self.n_uploaded = len(self.jobs)
         if self.n_uploaded:
@@ -205,23 +208,32 @@ def _pad_vec(v, n):
     return v if v.numel() == n else F.pad(v, (0, n - v.numel()))
 
 
-# Weight gradients on a stream of their own.  Nothing in backward waits for a dW -- the chain is input gradient -> BatchNorm
-# backward -> input gradient -- and that chain is full of kernels that leave the GPU nearly idle (the *_final folds, the gates,
-# the 32x32 / 64x64 layers): the weight-gradient kernels (1.8 ms of an 8.4 ms step) run under them.  Fork: the side stream waits for
-# the main stream at the point of the call (dy and every input are complete in main-stream order); join: ONE wait of the main
-# stream for the side stream when backward ends (an autograd-engine callback queued from the first call of each backward), so
-# the optimizer, the GradScaler, a gradient exchange that runs after backward -- everything that reads .grad -- comes after.
-# Not taken when something reads .grad DURING backward: a parameter that already holds a gradient (accumulation adds in place
-# on the main stream), a parameter with a tensor / post-accumulate hook of its own, or GradBuckets' per-parameter hooks.  And only where it pays (measured, bf16, B = 8, same box): eager 512x512
-# 8.69 -> 8.11 ms; as a hipGraph 8.71 -> 8.73 (the replay gains nothing from the second branch) and 256x256 3.85 -> 4.21 as a graph,
-# 7.06 -> 8.87 eager (host-bound: the stream switches and record_stream calls cost more than the overlap returns) -- so: eager steps
-# of at least WGRAD_STREAM_MIN_PIXELS input pixels (the size from which Model.train_step stops capturing), never under capture.
-WGRAD_STREAM = __import__("os").environ.get("MDIE_TRAIN_WGRAD_STREAM", "1") == "1"
+# Weight gradients on a stream of their own -- OPT-IN (MDIE_TRAIN_WGRAD_STREAM=1), see the last paragraph.  Nothing in backward
+# waits for a dW -- the chain is input gradient -> BatchNorm backward -> input gradient -- and that chain is full of kernels that
+# leave the GPU nearly idle (the *_final folds, the gates, the 32x32 / 64x64 layers): the weight-gradient kernels (1.8 ms of an
+# 8.4 ms step) run under them.  Fork: the side stream waits for the main stream at the point of the call (dy and every input are
+# complete in main-stream order); join: ONE wait of the main stream for the side stream when backward ends (an autograd-engine
+# callback queued from the first call of each backward), so the optimizer, the GradScaler, a gradient exchange that runs after
+# backward -- everything that reads .grad -- comes after.
+# Not taken when something reads or combines the gradient DURING backward: a parameter that already holds a gradient (accumulation
+# adds in place on the main stream), a parameter with a tensor / post-accumulate hook of its own, GradBuckets' per-parameter hooks,
+# a parameter that has ALREADY received a side-stream dW in this backward (the network applied twice in one graph, weight sharing:
+# autograd sums the two on the main stream), or a backward that records a graph itself (create_graph=True: AccumulateGrad clones
+# instead of stealing).  And only where it pays (measured, bf16, B = 8, same box): eager 512x512 8.69 -> 8.11 ms; as a hipGraph
+# 8.71 -> 8.73 and 256x256 3.85 -> 4.21 as a graph, 7.06 -> 8.87 eager (host-bound) -- so: eager steps of at least
+# WGRAD_STREAM_MIN_PIXELS input pixels, never under capture.
+# WHY IT IS OFF BY DEFAULT (round 4).  In round 3 one box showed, in 4 of 12 rounds of three steps at 8x512x512, the bottleneck
+# CBAM's channel-gate MLP gradients (and what is downstream of them) differing from the single-stream schedule.  Those gradients
+# are computed entirely on the MAIN stream (cbt_bwd3 -> cbt_gate_bwd -> cbt_gate_final); the cause was not found: DESIGN.md
+# section 4 finding 6 lists what reading the kernels' ISA, the host-side fork and a hardware probe (tools/pkfma_probe.hip) exclude.
+# Until it is explained the default training schedule is the single stream.
+WGRAD_STREAM = __import__("os").environ.get("MDIE_TRAIN_WGRAD_STREAM", "0") == "1"
 WGRAD_STREAM_MIN_PIXELS = 8 * 384 * 384
 _wgrad_side_this_step = False  # forward_train decides per step
 _WGRAD_SIDE = {}
 _wgrad_hooks_active = 0        # GradBuckets with hooks registered
 _wgrad_join_task = {}          # device -> id of the autograd graph task (= one backward) whose join callback is queued
+_wgrad_seen = {}               # device -> (graph task id, ids of the parameters that have received a side-stream dW in it)
 
 
 def _wgrad_side_stream(dev):
@@ -231,11 +243,29 @@ def _wgrad_side_stream(dev):
     return st
 
 
+def _graph_task():
+    return torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else None
+
+
+def _first_sighting(dev, param):
+    """True the first time `param` asks for a side-stream dW inside the running backward (one autograd graph task)."""
+    task = _graph_task()
+    if task is None or task < 0:
+        return False               # not inside an engine-run backward (or a torch without the query): stay on the main stream
+    seen = _wgrad_seen.get(dev)
+    if seen is None or seen[0] != task:
+        seen = _wgrad_seen[dev] = (task, set())
+    if id(param) in seen[1]:
+        return False
+    seen[1].add(id(param))
+    return True
+
+
 def _queue_wgrad_join(dev, main):
     """`main`: the stream backward runs on, taken inside a Function.backward (the engine has set it to the forward's stream there).
     The callback itself may run on an autograd worker thread whose current stream is the device's default one -- under graph
     capture that is NOT the capturing stream -- so the stream to join is fixed here, not looked up there."""
-    task = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else None
+    task = _graph_task()
     if task is not None and task >= 0 and _wgrad_join_task.get(dev) == task:
         return                       # this backward already has its join (keyed by the task, so a backward that died half way leaves nothing behind)
     _wgrad_join_task[dev] = task
@@ -250,15 +280,17 @@ def join_weight_gradients(dev):
     """make the current stream wait for weight gradients still running on the side stream (idempotent; backward's own callback
     has normally done it already)"""
     st = _WGRAD_SIDE.get(torch.device(dev) if not isinstance(dev, torch.device) else dev)
-    if st is not None:
-        torch.cuda.current_stream(dev).wait_stream(st)
+    if st is not None and not torch.cuda.is_current_stream_capturing():    # (nothing is ever forked under capture; a capturing stream
+        torch.cuda.current_stream(dev).wait_stream(st)                      #  must not wait on an event of a stream outside the capture)
 
 
 def _wgrad(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre=None, split=None, gap=0, param=None):
     """dW in the parameter's layout from the convolution's input segments and dy (stored cout_st channels)."""
     dev = dy.device
     if (_wgrad_side_this_step and WGRAD_STREAM and _wgrad_hooks_active == 0 and param is not None and param.grad is None
-            and not getattr(param, "_backward_hooks", None) and not getattr(param, "_post_accumulate_grad_hooks", None)):   # a hook would read the gradient during backward
+            and not torch.is_grad_enabled()                                                                                   # create_graph: the gradient is cloned / differentiated on the main stream
+            and not getattr(param, "_backward_hooks", None) and not getattr(param, "_post_accumulate_grad_hooks", None)     # a hook would read the gradient during backward
+            and _first_sighting(dev, param)):                                                                                 # a second dW of one backward is summed with the first on the main stream
         main, side = torch.cuda.current_stream(dev), _wgrad_side_stream(dev)
         side.wait_stream(main)
         _queue_wgrad_join(dev, main)
@@ -267,6 +299,10 @@ def _wgrad(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre=None, 
         for t in list(segs) + [dy] + (list(pre) if pre is not None else []):
             t.record_stream(side)          # allocated on the main stream, read on the side stream
         return dw
+    if _wgrad_side_this_step and WGRAD_STREAM and param is not None and dev in _WGRAD_SIDE:
+        seen = _wgrad_seen.get(dev)
+        if seen is not None and seen[0] == _graph_task() and id(param) in seen[1]:
+            torch.cuda.current_stream(dev).wait_stream(_WGRAD_SIDE[dev])     # the first dW of this parameter may still be running: autograd adds the two next
     return _wgrad_launch(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre, split, gap)
 
 
@@ -754,7 +790,7 @@ def deconv_stage(dt, cv, bn, x, skip, up):
     return _DeconvFn.apply(x, cv.weight, cv.bias, bn.weight, bn.bias, skip, bn, dt, up)
 
 
-_DEBUG_POISON = None     # tools/dbg_bnred.py: byte value the CBAM workspaces are filled with (None: left as allocated)
+_DEBUG_POISON = None     # tools/race_hunt_train.py: byte value the CBAM workspaces are filled with (None: left as allocated)
 
 
 class _CbamFn(torch.autograd.Function):

@@ -11,14 +11,6 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 fused = os.environ.get("FUSED_TAIL", "0") == "1"
 general = os.environ.get("GENERAL_TAIL", "0") == "1"    # decoder.final_dense as the general chain (no transition folding)
-NAMES = ["enc.conv1+pool"] + [f"dense1.l{i}" for i in range(4)] + ["dense1.tr", "enc.conv2+pool"] + \
-        [f"dense2.l{i}" for i in range(4)] + ["dense2.tr", "enc.conv3+pool"] + [f"dense3.l{i}" for i in range(4)] + \
-        ["dense3.tr", "enc.conv4+pool-stats", "bott.gate", "bott.chanpool", "bott.spatial", "dec.conv1+skip+pool-stats",
-         "cbam1.gate", "cbam1.chanpool", "cbam1.spatial*d3", "dec.conv2", "up2+skip1+pool",
-         "cbam2.gate+chanpool", "cbam2.spatial*d2", "dec.conv3", "up3+skip0+pool",
-         "cbam3.gate+chanpool", "cbam3.spatial*d1", "dec.conv4"]
-NAMES += (["tail(fused)"] if fused else (["up4+x+final.l0"] + [f"final.l{i}" for i in range(1, 4)] + ["final.tr+sigmoid->nchw"] if general or prec == "fp32" else
-           ["up4+x+final.l0+tr"] + [f"final.l{i}+tr" for i in range(1, 3)] + ["final.l3+tr+sigmoid->nchw"]))
 net = CDAN(precision=prec)
 net.load_state_dict(P.make_state_dict(42), strict=True)
 net = net.eval().cuda()
@@ -34,9 +26,16 @@ for _ in range(reps):
     ms = [m for _, m in ex["launches"]]
     acc = ms if acc is None else [a + b for a, b in zip(acc, ms)]
 kinds = [k for k, _ in ex["launches"]]
+info = ex["launch_info"]          # (label, algorithmic bytes, FLOPs) per launch, from the engine's own launch list (include/mdie.h: mdie_launch_info)
 tot = 0
+print(f"# {prec} B={B} {S}x{S}: per launch, serial (instrumented mode: side branches in line), mean of {reps} passes; bytes / FLOPs = the launch's share of the SURVEY 8d model")
+print(f"# {'#':>2s} {'layer':34s} {'kind':14s} {'us':>8s} {'alg MB':>8s} {'TB/s':>6s} {'of 8':>5s} {'TFLOP/s':>8s} {'of 2.5PF':>8s}")
 for i, (k, m) in enumerate(zip(kinds, acc)):
     us = m / reps * 1e3
     tot += us
-    print(f"{i:3d} {NAMES[i] if i < len(NAMES) else '?':20s} {k:14s} {us:8.1f} us")
-print(f"total {tot:.1f} us  ({B / tot * 1e6:.0f} img/s kernel-time bound)")
+    label, by, fl = info[i]
+    tbs = by / us / 1e6 if us else 0.0
+    tfs = fl / us / 1e6 if us else 0.0
+    peak = 157.3 if prec == "fp32" else 2500.0
+    print(f"{i:4d} {label:34s} {k:14s} {us:8.1f} {by / 1e6:8.1f} {tbs:6.2f} {tbs / 8:5.2f} {tfs:8.1f} {tfs / peak:8.3f}")
+print(f"total {tot:.1f} us  ({B / tot * 1e6:.0f} img/s kernel-time bound); model: {sum(b for _, b, _ in info) / 1e9:.4f} GB, {sum(f for _, _, f in info) / 1e9:.2f} GFLOP per step")
