@@ -314,6 +314,8 @@ __global__ __launch_bounds__(CT_THREADS) void cbt_bwd1_kernel(const CbtArgs a, c
     for (int k = 0; k < NV; ++k) {
       const size_t vo = (size_t)(k * LPP + sub) * 16;
       float f[VEC], d[VEC], m[VEC], r[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) m[i] = 1.f;                 // (no multiplicand: the bottleneck CBAM)
       Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.x + gp * a.x_stride * sizeof(T) + vo), f);
       Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.dout + gp * a.dout_stride * sizeof(T) + vo), d);
       if (a.mul) Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.mul + gp * a.mul_stride * sizeof(T) + vo), m);
@@ -452,6 +454,8 @@ __global__ __launch_bounds__(CT_THREADS) void cbt_bwd3_kernel(const CbtArgs a, c
     for (int k = 0; k < NV; ++k) {
       const size_t vo = (size_t)(k * LPP + sub) * 16;
       float d[VEC], m[VEC], r[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) m[i] = 1.f;                 // (no multiplicand: the bottleneck CBAM)
       Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.dout + gp * a.dout_stride * sizeof(T) + vo), d);
       if (a.mul) Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a.mul + gp * a.mul_stride * sizeof(T) + vo), m);
 #pragma unroll

@@ -634,6 +634,7 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
     return launch_conv_thin(Traits<T>::DT, a, stream, d->tr);
   }
   if (conv_thin_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr)) return launch_conv_thin(Traits<T>::DT, a, stream);
+  if (conv_ksplit_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr)) return launch_conv_ksplit(Traits<T>::DT, a, stream);
   const int bn = (d->cout % 64 == 0) ? 64 : 16;
   a.n_tiles = d->cout / bn;
   // Small feature maps (32x32 at the network's deep end) do not fill 256 CUs with 16x16 tiles: switch to 8x8 tiles
@@ -811,7 +812,7 @@ extern "C" int mdie_conv_fwd(const mdie_conv_desc* d, void* stream) {
   MDIE_REQUIRE(!d->pool || (d->H % 2 == 0 && d->W % 2 == 0), "mdie_conv_fwd: pool needs even H, W");
   MDIE_REQUIRE(d->out_nchw3 || (d->out_stride % 4 == 0 && d->out_stride >= 4), "mdie_conv_fwd: out_stride %d", d->out_stride);
   MDIE_REQUIRE(((uintptr_t)d->out & 15) == 0 && ((uintptr_t)d->weight & 15) == 0, "mdie_conv_fwd: out/weight alignment");
-#ifndef EXP_STAMPS
+#if !defined(EXP_STAMPS) && !defined(EXP_KSTAMPS)
   MDIE_REQUIRE(!d->residual || (d->res_stride % 4 == 0), "mdie_conv_fwd: res_stride %d", d->res_stride);
 #endif
   MDIE_REQUIRE(!d->pool_partial || (d->ksize == 3 && d->cout % 64 == 0 && d->act == MDIE_ACT_RELU && !d->pool && !d->out_nchw3),

@@ -356,6 +356,10 @@ int launch_conv_wide(int dtype, ConvArgs& a, hipStream_t stream);
 // channels on full 16x16 tiles (decoder.final_dense)
 bool conv_thin_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw3, bool any_batch = false);
 int launch_conv_thin(int dtype, const ConvArgs& a, hipStream_t stream, const mdie_tr_fuse* tr = nullptr);
+// conv_ksplit.hip: the deep DenseBlock layers (16 outputs, >= 128 pre-activated input channels, maps up to 64x64): K split over
+// the four waves of a workgroup, barrier-free chunk loop.  Chosen by (layer, map) only, never by the batch.
+bool conv_ksplit_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw3);
+int launch_conv_ksplit(int dtype, ConvArgs& a, hipStream_t stream);
 // conv_planar.hip: conv_kernel with the output written one plane per 16 channels (no activation, pooling, residual): the input
 // gradients of the DenseBlock layers in training
 int launch_conv_planar(int dtype, ConvArgs& a, int ksize, hipStream_t stream);

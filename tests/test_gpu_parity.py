@@ -831,6 +831,59 @@ def test_thin_single_chunk_conv(E, L, prec, cin_segs, shape, pre):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cin_segs,shape,act", [([128], (3, 32, 32), "none"), ([128, 16], (2, 40, 40), "none"), ([256, 16, 16], (5, 32, 32), "none"),
+                                                ([256, 16, 16, 16], (2, 27, 21), "relu"), ([128, 16, 16, 16, 16], (1, 48, 33), "none"),
+                                                ([256, 128, 64, 48], (2, 16, 24), "none")])
+def test_ksplit_conv_kernel_deep_dense_layers(E, L, prec, cin_segs, shape, act):
+    """conv_ksplit_kernel (csrc/conv_ksplit.hip): the 3x3 / 16-output layers of encoder.dense2 / dense3 (models/cdan.py:41-46: BN ->
+    ReLU -> Conv3x3 over the concatenation of up to five segments) with the K axis split over the four waves of a workgroup --
+    4..16 K chunks (1..4 per wave, a half-empty last chunk), ragged 8x8 tile edges, segments with their own strides, output into a
+    slice of a wider buffer; against torch's CPU convolution on the same rounded operands.  The kernel is chosen by (layer, map)
+    alone: every image of a batch reproduces its single-image run bit for bit."""
+    import ctypes as C
+    import torch.nn.functional as F
+    dt, td = E.dtype_id(prec), TORCH_DT[prec]
+    rnd = (lambda t: t.to(td).float())
+    B, H, W = shape
+    cin, cout = sum(cin_segs), 16
+    g = torch.Generator().manual_seed(cin * 3 + H)
+    strides = [c + (16 if i % 2 else 0) for i, c in enumerate(cin_segs)]
+    bufs = [rnd(torch.randn(B, H, W, st, generator=g)) for st in strides]
+    w = rnd(torch.randn(cout, cin, 3, 3, generator=g) * 0.05)
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ps, pt = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    x = torch.cat([b[..., :c] for b, c in zip(bufs, cin_segs)], 3)
+    xa = rnd(torch.relu(x * ps + pt))
+    ref = F.conv2d(xa.permute(0, 3, 1, 2), w, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    ref = (torch.relu(ref) if act == "relu" else ref).permute(0, 2, 3, 1)
+
+    dbufs = [b.cuda().to(td) for b in bufs]
+    wp = E.pack_conv_weight(w, dt, cin_stored=cin).cuda()
+    dsc, dsh, dps, dpt = sc.cuda(), sh.cuda(), ps.cuda(), pt.cuda()
+
+    def run(first, nb):
+        out = torch.full((nb, H, W, 48), -7.0, device="cuda", dtype=td)
+        d = L.ConvDesc()
+        d.dtype, d.B, d.H, d.W, d.ksize, d.nseg = dt, nb, H, W, 3, len(dbufs)
+        for i, (b, c) in enumerate(zip(dbufs, cin_segs)):
+            d.inp[i] = L.Seg(b[first:].data_ptr(), c, b.shape[3])
+        d.cin, d.cout = cin, cout
+        d.pre_scale, d.pre_shift = dps.data_ptr(), dpt.data_ptr()
+        d.weight, d.post_scale, d.post_shift = wp.data_ptr(), dsc.data_ptr(), dsh.data_ptr()
+        d.act, d.pool = (L.ACT_RELU if act == "relu" else L.ACT_NONE), 0
+        d.out, d.out_stride = out[..., 16:].data_ptr(), 48
+        L.check(L.lib.mdie_conv_fwd(C.byref(d), None), "mdie_conv_fwd")
+        torch.cuda.synchronize()
+        return out
+
+    out = run(0, B)
+    assert rel_to_max(out[..., 16:32], ref) <= {"bf16": 8e-3, "fp16": 1e-3}[prec]
+    assert (out[..., :16] == -7.0).all() and (out[..., 32:] == -7.0).all()     # nothing written outside the slice
+    for i in range(B):                                                          # an image's bits do not depend on its batch
+        assert torch.equal(run(i, 1)[0], out[i])
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", ["plain", "pool", "residual", "stats", "convT_ragged_batch",
                                   "plain_noact", "plain_noact_half", "convT_noact", "convT_noact_half"])
 def test_wide_conv_lds_dma_kernel(E, L, prec, case):
