@@ -490,8 +490,8 @@ class Model:
                 row = {"type": "epoch", "epoch": epoch + 1, "epoch_time_sec": time.time() - t0, "lr": lr, "best_loss_so_far": best}
                 row.update({f"loss_{k}": v for k, v in avg.items()})
                 self.logger.log("train", row)
-        if hooks_on:
-            buckets.remove()
+        if buckets is not None:
+            buckets.close()          # hooks off, and the training Functions stop writing gradients into this instance's buckets
         return self.history
 
     def test(self):

@@ -120,7 +120,31 @@ def _new_zero_arena(dev, n=4096):
     _ZERO_ARENA = [torch.zeros(n, dtype=torch.float32, device=dev), 0]
 
 
-def _zero_grad_vec(n, dev):
+# Data parallel: where a gradient is WRITTEN.  With a GradBuckets active (`_GRAD_SINK`), every kernel that produces a parameter
+# gradient -- the weight-gradient reduce, the BatchNorm backward's dgamma / dbeta, the CBAM backward, the exactly-zero biases --
+# writes straight into that parameter's slice of its flat all-reduce bucket, and the Function returns a fresh VIEW of the slice:
+# autograd's AccumulateGrad takes it over as `.grad` (one reference, the parameter's layout), so `.grad` IS the bucket memory
+# and the exchange moves no gradient in or out (round 3: 140 copies in + 140 back per step).  Only while `param.grad is None`
+# (zero_grad(set_to_none=True), what Model.train_step does): an existing .grad is accumulated into by autograd as usual.
+_GRAD_SINK = None
+
+
+def _gout(param, shape, dev):
+    """the tensor a kernel writes `param`'s gradient into: the parameter's bucket slice (as a fresh view) or a new tensor"""
+    sink = _GRAD_SINK
+    if sink is not None and param is not None and param.grad is None:
+        v = sink.view_of(param)
+        if v is not None and tuple(v.shape) == tuple(shape):
+            return v
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+def _zero_grad_vec(n, dev, param=None):
+    sink = _GRAD_SINK
+    if sink is not None and param is not None and param.grad is None:
+        v = sink.zero_view_of(param)          # (a slice no kernel ever writes: zero since the bucket was made, all-reduced zeros stay zero)
+        if v is not None and v.numel() == n:
+            return v
     a = _ZERO_ARENA
     if a is None or a[0].device != dev or a[1] + n > a[0].numel():
         return torch.zeros(n, dtype=torch.float32, device=dev)
@@ -287,7 +311,8 @@ def join_weight_gradients(dev):
 def _wgrad(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre=None, split=None, gap=0, param=None):
     """dW in the parameter's layout from the convolution's input segments and dy (stored cout_st channels)."""
     dev = dy.device
-    if (_wgrad_side_this_step and WGRAD_STREAM and _wgrad_hooks_active == 0 and param is not None and param.grad is None
+    if (_wgrad_side_this_step and WGRAD_STREAM and (_wgrad_hooks_active == 0 or (_GRAD_SINK is not None and _GRAD_SINK.view_of(param) is not None))
+            and param is not None and param.grad is None
             and not torch.is_grad_enabled()                                                                                   # create_graph: the gradient is cloned / differentiated on the main stream
             and not getattr(param, "_backward_hooks", None) and not getattr(param, "_post_accumulate_grad_hooks", None)     # a hook would read the gradient during backward
             and _first_sighting(dev, param)):                                                                                 # a second dW of one backward is summed with the first on the main stream
@@ -295,7 +320,7 @@ def _wgrad(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre=None, 
         side.wait_stream(main)
         _queue_wgrad_join(dev, main)
         with torch.cuda.stream(side):
-            dw = _wgrad_launch(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre, split, gap)
+            dw = _wgrad_launch(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre, split, gap, param)
         for t in list(segs) + [dy] + (list(pre) if pre is not None else []):
             t.record_stream(side)          # allocated on the main stream, read on the side stream
         return dw
@@ -303,14 +328,14 @@ def _wgrad(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre=None, 
         seen = _wgrad_seen.get(dev)
         if seen is not None and seen[0] == _graph_task() and id(param) in seen[1]:
             torch.cuda.current_stream(dev).wait_stream(_WGRAD_SIDE[dev])     # the first dW of this parameter may still be running: autograd adds the two next
-    return _wgrad_launch(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre, split, gap)
+    return _wgrad_launch(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre, split, gap, param)
 
 
-def _wgrad_launch(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre, split, gap):
+def _wgrad_launch(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre, split, gap, param=None):
     B, _, H, W = dy.shape
     dev = dy.device
     cin_st = sum(s.shape[1] for s in segs)
-    dw = torch.empty(w_shape, dtype=torch.float32, device=dev)
+    dw = _gout(param, w_shape, dev)
     nws = L.lib.mdie_conv_wgrad_workspace_bytes(B, H, W, ks, cin_st, cout_st)
     ws = torch.empty(nws, dtype=torch.uint8, device=dev)
     d = L.WgradDesc()
@@ -413,7 +438,7 @@ class _ConvBnFn(torch.autograd.Function):
         ctx.save_for_backward(x, w32, y, k, mv)
         ctx.set_materialize_grads(False)
         ctx.meta = (dt, pool, p, seed, cin, cout, need_o, need_t)
-        ctx.wparam = weight
+        ctx.wparam, ctx.bparam, ctx.gparams = weight, bias, (gamma, beta)
         ctx.seed_dev = seed_dev
         outs = tuple(v for v in (o, t) if v is not None)
         return outs if len(outs) > 1 else outs[0]
@@ -431,7 +456,7 @@ class _ConvBnFn(torch.autograd.Function):
         d_o = _cl(d_o.to(td)) if d_o is not None else None
         d_t = _cl(d_t.to(td)) if d_t is not None else None
         dz = torch.empty_like(y)
-        dgb = torch.empty(2, cout, dtype=torch.float32, device=dev)
+        dgb = (_gout(ctx.gparams[0], (cout,), dev), _gout(ctx.gparams[1], (cout,), dev))
         coef = torch.empty(2, cout, dtype=torch.float32, device=dev)
         nws = L.lib.mdie_bn_workspace_bytes(cout)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
@@ -453,7 +478,7 @@ class _ConvBnFn(torch.autograd.Function):
             dx = _empty(dt, B, cin_st, H, W, dev)
             _conv_raw(dt, [dz], _pack(dt, w32, 3, True, cin, cout, cin_st, cout), _zeros(cin_st, dev), 3, cin_st, dx)
         dw = _wgrad(dt, [x], dz, w32.shape, 3, False, cin, cout, cout, param=ctx.wparam)
-        return dx, dw, _zero_grad_vec(cout, dev), dgb[0], dgb[1], None, None, None, None, None, None, None, None
+        return dx, dw, _zero_grad_vec(cout, dev, ctx.bparam), dgb[0], dgb[1], None, None, None, None, None, None, None, None
 
 
 class _DenseFn(torch.autograd.Function):
@@ -498,6 +523,7 @@ class _DenseFn(torch.autograd.Function):
         ctx.save_for_backward(x, mv, *grow, *consts, *weights, *([y] if sigmoid else []))
         ctx.meta = (dt, real_c, sigmoid, c0)
         ctx.wparams = [params[4 * l + 2] for l in range(5)]
+        ctx.params = params
         return y if sigmoid else out
 
     @staticmethod
@@ -541,15 +567,15 @@ class _DenseFn(torch.autograd.Function):
                 cout, cout_st, ks, dy = w.shape[0], dz.shape[1], 1, dz
                 mean_dy = torch.empty(2, cout_st, dtype=torch.float32, device=dev)
                 _Bn.stats(dt, dy, mean_dy[0], mean_dy[1])
-                grads[4 * l + 3] = (mean_dy[0, :cout] * N)                     # the only bias here that is not followed by a BatchNorm
+                grads[4 * l + 3] = torch.mul(mean_dy[0, :cout], N, out=_gout(ctx.params[4 * l + 3], (cout,), dev))   # the only bias here that is not followed by a BatchNorm
             else:
                 cout, cout_st, ks, dy = 16, 16, 3, gg[l]   # complete: every consumer of this segment has run
-                grads[4 * l + 3] = _zero_grad_vec(16, dev)
+                grads[4 * l + 3] = _zero_grad_vec(16, dev, ctx.params[4 * l + 3])
             # gradient w.r.t. the activated input a = relu(bn(cat(segs)))
             planar = not acc32
             fuse = planar and BN_REDUCE_IN_DGRAD
             da = torch.empty(cin_st // 16, N, 16, dtype=td, device=dev) if planar else _empty(dt, B, cin_st, H, W, dev)
-            dgb = torch.empty(2, cin_real, dtype=torch.float32, device=dev)
+            dgb = (_gout(ctx.params[4 * l], (cin_real,), dev), _gout(ctx.params[4 * l + 1], (cin_real,), dev))
             coef = torch.empty(2, cin_st, dtype=torch.float32, device=dev)
             if fuse:    # the BatchNorm-ReLU backward sums come out of the input-gradient convolution's epilogue (mdie_conv_desc.bnred)
                 nslab = L.lib.mdie_conv_bnred_slabs(B, H, W, cin_st)
@@ -645,7 +671,7 @@ class _DeconvFn(torch.autograd.Function):
                                              out.data_ptr(), cout_st, _sp(dev)), "mdie_bn_act_up_add_fwd")
         ctx.save_for_backward(x, w32, y, k, mv)
         ctx.meta = (dt, up, cin, cout, cout_st)
-        ctx.wparam = weight
+        ctx.wparam, ctx.bparam, ctx.gparams = weight, bias, (gamma, beta)
         return out
 
     @staticmethod
@@ -656,7 +682,7 @@ class _DeconvFn(torch.autograd.Function):
         dev, td = x.device, E.TORCH_DTYPE[dt]
         d_out = _cl(d_out.to(td))
         dz = torch.empty_like(y)
-        dgb = torch.empty(2, cout, dtype=torch.float32, device=dev)
+        dgb = (_gout(ctx.gparams[0], (cout,), dev), _gout(ctx.gparams[1], (cout,), dev))
         coef = torch.empty(2, cout_st, dtype=torch.float32, device=dev)
         nws = L.lib.mdie_bn_workspace_bytes(cout_st)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
@@ -681,7 +707,7 @@ class _DeconvFn(torch.autograd.Function):
         # input gradient of a transposed convolution = plain convolution with the un-flipped kernel, in/out swapped
         _conv_raw(dt, [dz], _pack(dt, w32, 3, False, cin, cout, cin, cout_st), _zeros(cin, dev), 3, cin, dx)
         dw = _wgrad(dt, [x], dz, w32.shape, 3, True, cin, cout, cout_st, param=ctx.wparam)
-        return dx, dw, _zero_grad_vec(cout, dev), dgb[0], dgb[1], (d_out if ctx.needs_input_grad[5] else None), None, None, None
+        return dx, dw, _zero_grad_vec(cout, dev, ctx.bparam), dgb[0], dgb[1], (d_out if ctx.needs_input_grad[5] else None), None, None, None
 
 
 # ---- the generic convolution Function (kept for callers that compose their own blocks and for the operator tests) -------
@@ -816,6 +842,7 @@ class _CbamFn(torch.autograd.Function):
         L.check(L.lib.mdie_cbam_train_fwd(C.byref(d), _sp(dev)), "mdie_cbam_train_fwd")
         ctx.save_for_backward(x, mul, gate, amax, pooled, comp, smap, bnc, *params)
         ctx.dt = dt
+        ctx.pparams = (w1, b1, w2, b2, w7, gamma, beta)
         return out
 
     @staticmethod
@@ -843,7 +870,7 @@ class _CbamFn(torch.autograd.Function):
         d = _CbamFn._desc(dt, x, mul, params, gate, amax, pooled, comp, smap, bnc)
         dx = torch.empty_like(x)
         dmul = torch.empty_like(mul) if mul is not None else None
-        grads = [torch.empty_like(p) for p in params]
+        grads = [_gout(pp, p.shape, dev) for pp, p in zip(ctx.pparams, params)]
         d.dout, d.dout_stride = d_out.data_ptr(), d_out.stride(3)
         d.dx, d.dx_stride = dx.data_ptr(), dx.stride(3)
         if dmul is not None:
@@ -994,14 +1021,25 @@ class CapturedStep:
 
 # ---- data-parallel gradient exchange ---------------------------------------------------------------------
 class GradBuckets:
-    """Bucketed gradient all-reduce overlapped with backward.
+    """Bucketed gradient all-reduce overlapped with backward; gradients live IN the buckets.
 
-    Parameters are grouped in REVERSE registration order (gradients become ready roughly back-to-front)
-    into `n_buckets` flat fp32 buckets of about equal size (the whole model is 14.3 MB: PyTorch-DDP's 25 MB
-    default would be ONE bucket and zero overlap).  A post-accumulate-grad hook copies each gradient into
-    its bucket; when the last gradient of a bucket has arrived the bucket's all-reduce is launched
-    asynchronously (RCCL over xGMI with the "nccl" backend), so it runs under the rest of backward.
-    `finish()` waits, divides by the world size and scatters the averages back into `.grad`."""
+    Parameters are grouped in REVERSE registration order (gradients become ready roughly back-to-front) into `n_buckets` flat
+    fp32 buckets of about equal size (the whole model is 14.3 MB: PyTorch-DDP's 25 MB default would be ONE bucket and zero
+    overlap).  While an instance is active (`_GRAD_SINK`), the training Functions write every parameter gradient straight into
+    its slice of its bucket and hand autograd a VIEW of it (`_gout`): `.grad` is bucket memory, nothing is copied in or out
+    (round 3 paid 140 `copy_` into the buckets from the hooks and 140 back in `finish()`: 280 launches on a host-bound step).
+    A post-accumulate-grad hook only COUNTS; when the last gradient of a bucket has arrived the bucket's all-reduce is launched
+    asynchronously (RCCL over xGMI under the "nccl" backend, averaging in the collective itself: ReduceOp.AVG), so it runs
+    under the rest of backward.  `finish()` waits (the current stream waits for the communication stream) and points every
+    `.grad` at its slice.  A gradient that did not come from a sink-aware producer (any other autograd node, an existing
+    `.grad` that autograd accumulated into) is copied into its slice by the hook -- the old path, still correct.
+
+    The weight-gradient side stream (train._wgrad, opt-in) stays usable: a bucket's all-reduce is issued from the side stream
+    after that stream has waited for the main one, so it is ordered behind both the dW kernels and the main stream's
+    BatchNorm / CBAM gradients of the bucket.
+
+    `exchange()` serves steps whose backward fired no hooks (a replayed CapturedStep): the captured kernels have written into
+    the same slices (the sink was active at capture time), so it is the five all-reduces and nothing else."""
 
     def __init__(self, params, process_group=None, n_buckets=4):
         import torch.distributed as dist
@@ -1029,54 +1067,123 @@ class GradBuckets:
             for p in b:
                 self._where[p] = (bi, off)
                 off += p.numel()
+        backend = dist.get_backend(process_group)
+        self._avg_op = dist.ReduceOp.AVG if backend == "nccl" else None       # (gloo has no AVG: sum, then one divide per bucket)
+        self._dirty = set()           # parameters whose slice a kernel has written: no longer a valid source of exact zeros
         self._pending = [len(b) for b in self.buckets]
         self._work = [None] * len(self.buckets)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in self.buckets for p in b]
-        global _wgrad_hooks_active
-        _wgrad_hooks_active += 1      # the hooks read .grad during backward: weight gradients stay on the main stream (_wgrad)
+        self._hooks = []
+        self.copies_in = 0            # gradients that had to be copied into their slice (diagnostic: 0 on the engine's own training path)
+        self.activate()
+        self.attach()
 
-    def _on_grad(self, p):
-        bi, off = self._where[p]
-        self.flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
-        self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._work[bi] = self.dist.all_reduce(self.flat[bi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+    # ---- the sink ----
+    def activate(self):
+        global _GRAD_SINK
+        _GRAD_SINK = self
 
-    def finish(self):
-        for bi, b in enumerate(self.buckets):
-            if self._pending[bi] != 0:  # a parameter without gradient this step: reduce what is there
-                for p in b:
-                    if p.grad is None:
-                        _, off = self._where[p]
-                        self.flat[bi][off:off + p.numel()].zero_()
-                self._work[bi] = self.dist.all_reduce(self.flat[bi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._work[bi].wait()
-            self.flat[bi] /= self.world
-            off = 0
-            for p in b:
-                g = self.flat[bi][off:off + p.numel()].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-                off += p.numel()
-            self._pending[bi] = len(b)
-            self._work[bi] = None
+    def close(self):
+        global _GRAD_SINK
+        self.remove()
+        if _GRAD_SINK is self:
+            _GRAD_SINK = None
 
-    def exchange(self):
-        """gradients that did not come through the hooks (a captured step replays kernels, not Python): pack every
-        bucket now, all-reduce, average, unpack"""
-        self._pending = [len(b) for b in self.buckets]
-        self._work = [None] * len(self.buckets)
-        for b in self.buckets:
-            for p in b:
-                if p.grad is not None:
-                    self._on_grad(p)
-        self.finish()
+    def _slice(self, p):
+        w = self._where.get(p)
+        if w is None:
+            return None
+        return self.flat[w[0]][w[1]:w[1] + p.numel()]
+
+    def view_of(self, p):
+        v = self._slice(p)
+        if v is None:
+            return None
+        self._dirty.add(p)
+        return v.view(p.shape)
+
+    def zero_view_of(self, p):
+        v = self._slice(p)
+        if v is None:
+            return None
+        if p in self._dirty:          # a kernel wrote this slice in some earlier step (the parameter changed roles): make it zero again
+            v.zero_()
+            self._dirty.discard(p)
+        return v.view(p.shape)
+
+    def is_view(self, p, g):
+        w = self._where.get(p)
+        return w is not None and g is not None and g.data_ptr() == self.flat[w[0]].data_ptr() + 4 * w[1] and g.is_contiguous() and g.dtype == torch.float32
+
+    # ---- overlap mode: hooks ----
+    def attach(self):
+        if not self._hooks:
+            self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in self.buckets for p in b]
+            global _wgrad_hooks_active
+            _wgrad_hooks_active += 1      # (train._wgrad: the side stream is then taken only for parameters whose gradient is a bucket view)
 
     def remove(self):
+        """stop reacting to backward (a replayed CapturedStep fires no hooks: `exchange()` follows the replay); the sink stays"""
         global _wgrad_hooks_active
         if self._hooks:
             _wgrad_hooks_active = max(0, _wgrad_hooks_active - 1)
         for h in self._hooks:
             h.remove()
+        self._hooks = []
+
+    def _launch(self, bi):
+        flat = self.flat[bi]
+        side = _WGRAD_SIDE.get(flat.device) if (flat.is_cuda and _wgrad_side_this_step and WGRAD_STREAM) else None
+        if side is not None:          # dW kernels of this bucket may be on the side stream: order the collective behind both streams
+            side.wait_stream(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(side):
+                self._work[bi] = self.dist.all_reduce(flat, op=self._avg_op or self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._work[bi] = self.dist.all_reduce(flat, op=self._avg_op or self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        bi, off = self._where[p]
+        if not self.is_view(p, p.grad):
+            self.flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
+            self._dirty.add(p)
+            self.copies_in += 1
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def _settle(self, bi):
+        self._work[bi].wait()         # the current stream waits for the communication stream
+        if self._avg_op is None:
+            self.flat[bi] /= self.world
+        off = 0
+        for p in self.buckets[bi]:
+            if not self.is_view(p, p.grad):
+                p.grad = self.flat[bi][off:off + p.numel()].view(p.shape)      # (no copy back: .grad IS the averaged slice)
+            off += p.numel()
+        self._pending[bi] = len(self.buckets[bi])
+        self._work[bi] = None
+
+    def finish(self):
+        for bi, b in enumerate(self.buckets):
+            if self._work[bi] is None:    # a parameter without gradient this step: reduce what is there (its slice as zeros)
+                for p in b:
+                    if p.grad is None:
+                        self._slice(p).zero_()
+                        self._dirty.discard(p)
+                self._launch(bi)
+            self._settle(bi)
+
+    def exchange(self):
+        """gradients that did not come through the hooks (a captured step replays kernels, not Python): make sure every
+        gradient sits in its slice (a replayed sink-aware backward has written them there already), all-reduce, average"""
+        for bi, b in enumerate(self.buckets):
+            off = 0
+            for p in b:
+                if p.grad is None:
+                    self.flat[bi][off:off + p.numel()].zero_()
+                elif not self.is_view(p, p.grad):
+                    self.flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
+                    self.copies_in += 1
+                off += p.numel()
+            self._launch(bi)
+        for bi in range(len(self.buckets)):
+            self._settle(bi)

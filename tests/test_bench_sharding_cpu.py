@@ -155,3 +155,76 @@ def test_gradbuckets_deliver_the_reference_two_shard_mean():
         assert p.exitcode == 0
     for rank, ok, nb, untouched in res:
         assert ok and nb == 5 and not untouched     # tail..decoder.conv2 | decoder.conv1 | CBAMs, encoder dense blocks | encoder.conv4 | encoder.conv3..1
+
+
+def _sink_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mdie_amd.train as T
+
+    class Scale(torch.autograd.Function):
+        """y = x * w with a sink-aware backward: dw is WRITTEN into the tensor train._gout hands out (the parameter's slice of its
+        all-reduce bucket while a GradBuckets is active) -- what every training Function of mdie_amd/train.py does"""
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x)
+            ctx.wparam = w
+            return x * w
+
+        @staticmethod
+        def backward(ctx, dy):
+            (x,) = ctx.saved_tensors
+            dw = T._gout(ctx.wparam, ctx.wparam.shape, dy.device)
+            torch.sum(dy * x, dim=0, out=dw)
+            return None, dw
+
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(n)) for n in (7, 300, 5, 64)]
+    frozen_bias = torch.nn.Parameter(torch.zeros(9))         # receives an exactly-zero gradient (a bias in front of a batch-statistic BatchNorm)
+    buckets = T.GradBuckets(params + [frozen_bias], n_buckets=2)
+    g = torch.Generator().manual_seed(100 + rank)
+    xs = [torch.randn(4, p.numel(), generator=g) for p in params]
+    out = {}
+    for step in range(2):                                    # the second step reuses the slices (zero_grad(set_to_none=True) in between)
+        for p in params + [frozen_bias]:
+            p.grad = None
+        loss = sum(Scale.apply(x, p).sum() for x, p in zip(xs, params))
+        loss = loss + (frozen_bias * 0).sum()                # autograd's own node: a gradient that is NOT a bucket view
+        loss.backward()
+        views_before = [buckets.is_view(p, p.grad) for p in params]
+        buckets.finish()
+        local = [x.sum(0) for x in xs]
+        means = []
+        for l in local:
+            parts = [torch.zeros_like(l) for _ in range(world)]
+            dist.all_gather(parts, l)
+            means.append(sum(parts) / world)
+        out[step] = (all(views_before), all(buckets.is_view(p, p.grad) for p in params + [frozen_bias]),
+                     all(torch.allclose(p.grad, m, atol=1e-6) for p, m in zip(params, means)), float(frozen_bias.grad.abs().max()))
+    q.put((rank, out, buckets.copies_in))
+    buckets.close()
+    assert T._GRAD_SINK is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradients_are_views_of_the_flat_buckets_two_ranks():
+    """GradBuckets as the gradient SINK (the step being sharded: models/model.py:154-166): a sink-aware backward writes dW
+    into the parameter's bucket slice and autograd adopts the view -- `.grad` is bucket memory before and after the exchange, the
+    only gradient ever copied in is the one an ordinary autograd node produced, and every rank ends with the two-shard mean."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_sink_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, out, copies in res:
+        for step in (0, 1):
+            views_before, views_after, mean_ok, zero_max = out[step]
+            assert views_before and views_after and mean_ok and zero_max == 0.0
+        assert copies == 2          # frozen_bias's autograd-made gradient, once per step; the four sink-aware gradients never

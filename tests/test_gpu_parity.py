@@ -2308,6 +2308,84 @@ def test_side_stream_weight_gradients_equal_main_stream(E, precision, shape, mon
 
 
 @pytest.mark.gpu
+def test_ddp_one_rank_nccl_gradients_live_in_the_buckets(E, monkeypatch):
+    """The data-parallel step on RCCL (a ONE-rank "nccl" group: the one-GPU box has no second device, the code path -- grad hooks ->
+    bucket complete -> asynchronous all-reduce on the communication stream -> finish -- is the one eight ranks run; the step being
+    sharded: models/model.py:154-166).  With GradBuckets active every parameter gradient of the network is written by its kernel
+    into its bucket slice: `.grad` is a view of the flat bucket before and after the exchange, nothing is copied, and losses,
+    gradients and parameters of two optimizer steps are bit-identical to the same steps without the exchange (world size 1:
+    the average of one).  Also with the weight gradients on their side stream, and for a replayed CapturedStep + exchange()."""
+    import torch.distributed as dist
+    import mdie_amd.train as T
+    from models.cdan import CDAN
+    from oracle import params as P
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29500 + os.getpid() % 2000}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sd = P.make_state_dict(42)
+        batches = [tuple(v.cuda() for v in P.lowlight_batch(31 + i, 2, 64, 64)) for i in range(2)]
+        monkeypatch.setattr(T, "WGRAD_STREAM_MIN_PIXELS", 0)
+
+        def run(mode, side=False):
+            monkeypatch.setattr(T, "WGRAD_STREAM", side)
+            torch.manual_seed(5)
+            net = CDAN(precision="bf16")
+            net.load_state_dict(sd, strict=True)
+            net = net.cuda().train()
+            opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+            buckets = T.GradBuckets(net.parameters()) if mode != "plain" else None
+            if mode == "after":
+                buckets.remove()
+            out, views = [], []
+            for x, t in batches:
+                opt.zero_grad(set_to_none=True)
+                loss = torch.sqrt((net(x) - t) ** 2 + 1e-6).mean()
+                loss.backward()
+                if buckets is not None:
+                    views.append(all(buckets.is_view(p, p.grad) for p in net.parameters()))
+                    buckets.finish() if mode == "overlap" else buckets.exchange()
+                    views.append(all(buckets.is_view(p, p.grad) for p in net.parameters()))
+                out.append((loss.detach().clone(), [p.grad.clone() for p in net.parameters()]))
+                opt.step()
+            torch.cuda.synchronize()
+            res = (out, [p.detach().clone() for p in net.parameters()], views, buckets.copies_in if buckets is not None else None,
+                   len(buckets.buckets) if buckets is not None else 0)
+            if buckets is not None:
+                buckets.close()
+            return res
+
+        ref = run("plain")
+        for mode, side in (("overlap", False), ("after", False), ("overlap", True)):
+            got = run(mode, side)
+            assert got[4] == 5 and got[3] == 0, f"{mode}: {got[3]} gradients were copied into the buckets"
+            assert all(got[2]), f"{mode}: a .grad was not a view of its bucket"
+            for (la, ga), (lb, gb) in zip(got[0], ref[0]):
+                assert torch.equal(la, lb) and all(torch.equal(u, v) for u, v in zip(ga, gb))
+            assert all(torch.equal(u, v) for u, v in zip(got[1], ref[1]))
+        assert T._GRAD_SINK is None
+
+        # a captured step writes into the same slices: exchange() after the replay moves nothing either
+        x, t = batches[0]
+        net = CDAN(precision="bf16")
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().train()
+        buckets = T.GradBuckets(net.parameters())
+        buckets.remove()
+        from mdie_amd import host as H
+        losses = H.build_losses({"enabled": True, "terms": [{"name": "charbonnier", "weight": 1.0}]})
+        cap = T.CapturedStep(net, losses, None, x, t)
+        cap(x, t)
+        assert all(buckets.is_view(p, p.grad) for p in net.parameters())
+        before = [p.grad.clone() for p in net.parameters()]
+        buckets.exchange()
+        torch.cuda.synchronize()
+        assert buckets.copies_in == 0 and all(torch.equal(p.grad, b) for p, b in zip(net.parameters(), before))
+        buckets.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
 def test_side_stream_second_gradient_of_a_parameter_stays_on_the_main_stream(E, monkeypatch):
     """The network applied TWICE before one backward: every parameter receives two gradients, which autograd sums on the main
     stream.  Only the first dW of a backward may run on the side stream; the second waits for it and runs on the main stream

@@ -2,7 +2,9 @@
 """Training-step timing (BASELINE configs[2] shape: blur-style loss, 512x512, batch 8 per GPU), eager and as one hipGraph.
   python tools/bench_train.py [bf16|fp16|fp32] [B] [S] [loss terms, e.g. charbonnier:1,ssim:0.5] [eager|graph|both]
   (under torchrun: one rank per GPU, bucketed RCCL all-reduce; the graph then holds forward + loss + backward and the
-   exchange + Adam step follow the replay)
+   exchange + Adam step follow the replay.  MDIE_DDP_SINGLE=1: a ONE-rank "nccl" group on a single GPU -- the whole
+   hook -> bucket -> RCCL all-reduce -> finish path on HIP without a second device; the eager mode then also prints the step with
+   the exchange left out and with the exchange AFTER backward: overlapped vs exposed communication time)
 
 Roofline model of the step (stated, not measured): FLOPs = 3 x the forward's (forward, input-gradient and weight-gradient
 GEMMs of every convolution; `mdie_cdan_flops`); HBM bytes = 3 x the forward's fused-schedule activation bytes
@@ -25,10 +27,11 @@ modes = {"both": ["eager", "graph"]}.get(sys.argv[5] if len(sys.argv) > 5 else "
 rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 torch.cuda.set_device(local)
 dist = None
-if world > 1:
+if world > 1 or os.environ.get("MDIE_DDP_SINGLE") == "1":
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl")
+    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 x, t = P.lowlight_batch(100 + rank, B, S, S)
 x, t = x.cuda(), t.cuda()
 losses = H.build_losses({"enabled": True, "terms": [{"name": s.split(":")[0], "weight": float(s.split(":")[1])} for s in spec.split(",")]})
@@ -37,13 +40,18 @@ flops = 3.0 * L.lib.mdie_cdan_flops(B, S, S)
 byts = 3.0 * L.lib.mdie_cdan_algorithmic_bytes(B, S, S, esz) + 16.0 * 3585663
 peak_tf = 157.3 if prec == "fp32" else 2500.0
 
-for mode in modes:
+variants = [(m, "overlap") for m in modes]
+if dist is not None and "eager" in modes:
+    variants += [("eager", "none"), ("eager", "after")]     # the same step without the exchange, and with it after backward (nothing overlapped)
+for mode, comm in variants:
     torch.manual_seed(42)
     net = CDAN(precision=prec).cuda().train()
     scaler = torch.amp.GradScaler("cuda", enabled=prec == "fp16")
     whole = mode == "graph" and dist is None and not scaler.is_enabled()
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=whole, fused=os.environ.get("ADAM_FUSED", "1") == "1")
-    buckets = T.GradBuckets(net.parameters()) if dist is not None else None
+    buckets = T.GradBuckets(net.parameters()) if (dist is not None and comm != "none") else None
+    if buckets is not None and comm == "after":
+        buckets.remove()
     if mode == "graph":
         if buckets is not None:
             buckets.remove()
@@ -63,7 +71,7 @@ for mode in modes:
             total, _ = losses(net(x), t)
             scaler.scale(total).backward()
             if buckets is not None:
-                buckets.finish()
+                buckets.finish() if comm == "overlap" else buckets.exchange()
             scaler.step(opt)
             scaler.update()
             return total
@@ -77,7 +85,14 @@ for mode in modes:
         l = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+    if buckets is not None:
+        note = f" | exchange: {comm}, {len(buckets.buckets)} buckets, {buckets.copies_in} gradient copies into buckets over {n + 3} steps"
+        buckets.close()
+    else:
+        note = " | no gradient exchange" if dist is not None else ""
     if rank == 0:
         print(f"train[{prec},{mode}] B={B}x{world} {S}x{S} loss={spec}: {dt*1e3:.2f} ms/step, {B*world/dt:.1f} img/s, loss {l.item():.4f} | "
               f"model: {flops/1e9:.0f} GFLOP, {byts/1e9:.2f} GB per rank-step -> {flops/dt/1e12:.0f} TFLOP/s = {flops/dt/1e12/peak_tf:.3f} of the {prec} MFMA peak, "
-              f"{byts/dt/1e9:.0f} GB/s = {byts/dt/8e12:.3f} of 8 TB/s")
+              f"{byts/dt/1e9:.0f} GB/s = {byts/dt/8e12:.3f} of 8 TB/s{note}", flush=True)
+if dist is not None:
+    dist.destroy_process_group()
