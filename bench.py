@@ -107,6 +107,67 @@ def rank_inputs(P, rank, B, S):
     return P.lowlight_batch(1000 + rank, B, S, S)
 
 
+ROUTED_TASKS = ["blur", "color_distortion", "high_light", "jpeg", "low_contrast", "low_light", "motion_blur", "noise", "pixelation"]
+
+
+def routed_labels(step, n, seed=0):
+    """the stub router's output for global batch `step`: the same list on every rank (seeded), a different grouping every step"""
+    g = torch.Generator().manual_seed(seed * 1000003 + step)
+    return [ROUTED_TASKS[i] for i in torch.randint(0, len(ROUTED_TASKS), (n,), generator=g).tolist()]
+
+
+def routed_main(args, rank, world, dev, dist, P):
+    """BASELINE configs[3]: classifier-routed mixed degradations.  One step = one global batch of --batch x N images; tasks are
+    dealt to ranks (engine.routed_shard), every rank holds only its tasks' weight sets and runs its images' task groups
+    concurrently (one stream and one enqueueing host thread per group); no data-path collective.  Labels are a stub router's (seeded, a different
+    grouping every step, 16 distinct batches cycled); the router network itself is timed by tools/bench_configs.py."""
+    from mdie_amd import engine as E
+    B, S, n_lists = args.batch * world, args.size, 16
+    eng = E.RoutedEngine(dev, args.precision)
+    mine_tasks = [t for i, t in enumerate(sorted(ROUTED_TASKS)) if i % world == rank]
+    for t in mine_tasks:
+        eng.load_task(t, P.make_state_dict(100 + ROUTED_TASKS.index(t)))
+    x_all, _ = P.lowlight_batch(2000, B, S, S)
+    batches = []
+    for k in range(n_lists):
+        labels = routed_labels(k, B)
+        idx = E.routed_shard(labels, rank, world, ROUTED_TASKS)
+        batches.append((x_all[idx].to(dev), [labels[i] for i in idx]))
+    it = [0]
+
+    def step():
+        xb, lb = batches[it[0] % n_lists]
+        it[0] += 1
+        if len(lb):
+            eng.forward(xb, lb)
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, n_lists)):
+            step()
+
+        def fence():
+            torch.cuda.synchronize(dev)
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec @256x256 bf16 (classifier-routed mixed degradations, 9 weight sets)", "value": round(B * args.steps / elapsed, 2),
+                          "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, n_lists), "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                          "config": {"workload": f"BASELINE configs[3]: all config/*.json tasks as 9 seeded weight sets, {S}x{S}, global batch {B} labelled by a stub router "
+                                                 f"(a different grouping every step), {args.precision} storage + fp32 accumulate",
+                                     "global_batch": B, "parallelism": f"tasks dealt to {world} rank(s), images follow their task, no collective",
+                                     "launch": "eager, one stream + one enqueueing host thread per task group"}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +183,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-batch", type=int, default=32, help="images of the GPU batch the CPU baseline runs (SURVEY.md 8d: the whole batch)")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed side measurements (fp32 / fp16 paths, nn.Module boundary)")
+    ap.add_argument("--workload", default="forward", choices=["forward", "routed"],
+                    help="forward: the headline (BASELINE configs[1]); routed: BASELINE configs[3] -- 9 task weight sets, a global batch of "
+                         "--batch x N images labelled by a stub router, every rank runs the images of the tasks it owns (no collective)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,6 +206,9 @@ def main():
     from mdie_amd import lib as L
     from models.cdan import CDAN
     from mdie_amd import synthetic as P  # synthetic-input recipe + seeded checkpoint (bit-identical to the oracle's generator)
+
+    if args.workload == "routed":
+        return routed_main(args, rank, world, dev, dist, P)
 
     B, S = args.batch, args.size
     sd = P.make_state_dict(42)

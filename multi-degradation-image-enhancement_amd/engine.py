@@ -153,29 +153,90 @@ class CdanEngine:
         return out
 
 
+def routed_shard(labels, rank, world, tasks):
+    """which images of a routed batch a rank runs: tasks are dealt to ranks by their position in the sorted task list (rank r owns
+    tasks r, r + world, ...), an image follows its task, un-routed images (label None) are dealt round-robin.  Every rank holds
+    only its own tasks' weight sets; no collective is involved ("group images by routed task per rank")."""
+    order = {t: i for i, t in enumerate(sorted(tasks, key=str))}
+    mine, k = [], 0
+    for i, t in enumerate(labels):
+        if t is None:
+            if k % world == rank:
+                mine.append(i)
+            k += 1
+        elif order[t] % world == rank:
+            mine.append(i)
+    return mine
+
+
 class RoutedEngine:
     """Classifier-routed inference (BASELINE configs[3]): one weight set per degradation task
-    (the reference trains one CDAN per config/*.json), every image pre-labelled with its task by a router.  Images are
-    grouped by task so each weight set is bound once per batch.  A group of 3-4 images cannot fill 256 CUs, so the
-    groups run CONCURRENTLY: one HIP stream and one workspace slice per group, forked from and joined to the caller's
-    stream with events.  The router itself (ResNet18, classification/train_multilabel_classifier.py) is out of scope:
-    labels come from the caller."""
+    (the reference trains one CDAN per config/*.json), every image labelled with its task by a router
+    (mdie_amd/router.py; classification/train_multilabel_classifier.py:251-253 for the thresholds).  Images are grouped by task
+    so each weight set is bound once per batch.  A group of 3-4 images cannot fill 256 CUs, so the groups run CONCURRENTLY, one
+    HIP stream per group, forked from and joined to the caller's stream with events.
 
-    def __init__(self, device, precision="bf16"):
+    The step is HOST-bound: nine groups are 9 x 39 kernel launches.  Round 4 measured the two obvious cures on one box
+    (tools/bench_configs.py, B = 32 at 256x256, a different grouping every batch):
+      * one hipGraph per (task, group size), fixed input / output slots, LRU cache -- 3.15 ms per batch against 2.73 ms for the
+        eager launches: hipGraphLaunch of a 39-node graph costs the host about what the 39 launches do, nine of them in a row
+        are no cheaper, and replaying several such graphs on several streams took the process down once
+        (hipGraphLaunch, gpurun_out/r04e/tests.log): not kept;
+      * the groups ENQUEUED IN PARALLEL: one host thread per group (ctypes releases the GIL inside mdie_cdan_forward; HIP takes
+        launches for different streams from different threads) -- kept, `threads`.
+    What would remove the cause -- ONE launch chain over the whole batch, every kernel looking up its image's weight set -- is
+    stated in DESIGN.md section 8 (round 4) and not built.  Results are bit-identical to per-task engines
+    (tests/test_gpu_parity.py::test_routed_*)."""
+
+    def __init__(self, device, precision="bf16", threads=True):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.MdieError(f"RoutedEngine needs a GPU device, got {self.device} (no CPU fallback)")
         self.dtype = dtype_id(precision)
         self.blobs = {}
         self._streams = []
-        self._ws = None
+        self._slots = None           # (capacity, H, W, x_slots, y_slots, {task: workspace}, {task: index})
+        self.threads = threads
+        self._pool = None
 
     def load_task(self, task, state_dict):
         self.blobs[task] = pack_checkpoint(state_dict, self.dtype).to(self.device)
+        self._slots = None
         return self
 
+    def _ensure_slots(self, B, H, W):
+        sl = self._slots
+        if sl is not None and sl[0] >= B and sl[1] == H and sl[2] == W and set(sl[5]) == set(self.blobs):
+            return sl
+        self._slots = None
+        n = L.lib.mdie_cdan_workspace_bytes(self.dtype, B, H, W)
+        if n == 0:
+            raise L.MdieError(f"unsupported input extent {B}x3x{H}x{W}: H and W must be multiples of 8")
+        tasks = sorted(self.blobs, key=str)
+        xs = torch.empty(len(tasks) * B, 3, H, W, dtype=torch.float32, device=self.device)
+        ys = torch.empty_like(xs)
+        ws = {t: torch.empty(n, dtype=torch.uint8, device=self.device) for t in tasks}      # (a stream-ordered allocation: earlier users of a
+        self._slots = (B, H, W, xs, ys, ws, {t: i for i, t in enumerate(tasks)})             #  replaced buffer finish before it is recycled)
+        return self._slots
+
+    def _launch_group(self, task, n, H, W, x_ptr, y_ptr, ws, stream_ptr):
+        d = L.CdanFwdDesc()
+        d.dtype, d.B, d.H, d.W = self.dtype, n, H, W
+        d.params, d.x, d.y = self.blobs[task].data_ptr(), x_ptr, y_ptr
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        d.flags, d.aux = 0, None
+        L.check(L.lib.mdie_cdan_forward(C.byref(d), stream_ptr), "mdie_cdan_forward")
+
+    def _workers(self, n):
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            self._pool = ThreadPoolExecutor(max_workers=16, thread_name_prefix="mdie-routed",
+                                            initializer=lambda: torch.cuda.set_device(dev))      # HIP's current device is per thread
+        return self._pool
+
     def forward(self, x, labels):
-        """x: float32 NCHW [B,3,H,W] on the GPU; labels: B task keys (host side).  Returns [B,3,H,W] in input order."""
+        """x: float32 NCHW [B,3,H,W] on the GPU; labels: B task keys (host side; None = pass through).  Returns [B,3,H,W] in input order."""
         _require_gpu(x, "RoutedEngine.forward")
         labels = list(labels)
         if x.dim() != 4 or x.shape[1] != 3 or len(labels) != x.shape[0]:
@@ -184,49 +245,53 @@ class RoutedEngine:
         if missing:
             raise L.MdieError(f"RoutedEngine.forward: no weights loaded for task(s) {missing}")
         B, _, H, W = x.shape
-        order = sorted(range(B), key=lambda i: (str(labels[i]), i))               # stable grouping
-        groups, a = [], 0
-        while a < B:
-            b = a
-            while b < B and labels[order[b]] == labels[order[a]]:
-                b += 1
-            groups.append((a, b, labels[order[a]]))
-            a = b
-        sizes = [L.lib.mdie_cdan_workspace_bytes(self.dtype, b - a, H, W) for a, b, _ in groups]
-        if 0 in sizes:
-            raise L.MdieError(f"unsupported input extent {B}x3x{H}x{W}: H and W must be multiples of 8")
-        sizes = [(n + 255) // 256 * 256 for n in sizes]
-        if self._ws is None or self._ws.numel() < sum(sizes):
-            self._ws = None
-            self._ws = torch.empty(sum(sizes), dtype=torch.uint8, device=self.device)
+        x = x.to(torch.float32).contiguous()
         with torch.cuda.device(self.device):
+            cap_B, _, _, xs, ys, wss, tindex = self._ensure_slots(B, H, W)
+            counts, slot, routed = {}, [], []
+            for i, t in enumerate(labels):
+                if t is None:
+                    continue
+                j = counts.get(t, 0)
+                counts[t] = j + 1
+                slot.append(tindex[t] * cap_B + j)         # task t's images sit at rows t * capacity ... of the slot buffers
+                routed.append(i)
+            out = torch.empty_like(x)
+            if len(routed) < B:                           # the router found no degradation: those images pass through unchanged
+                out.copy_(x)
+            if not routed:
+                return out
+            main = torch.cuda.current_stream(self.device)
+            slot_t = torch.tensor(slot, device=self.device)
+            src = x if len(routed) == B else x.index_select(0, torch.tensor(routed, device=self.device))
+            xs.index_copy_(0, slot_t, src)
+            groups = sorted(counts.items(), key=lambda kv: str(kv[0]))
             while len(self._streams) < len(groups):
                 self._streams.append(torch.cuda.Stream(self.device))
-            main = torch.cuda.current_stream(self.device)
-            idx = torch.tensor(order, device=self.device)
-            xs = x.to(torch.float32).index_select(0, idx)
-            ys = torch.empty_like(xs)
             fork = torch.cuda.Event()
             fork.record(main)
-            off = 0
-            for (a, b, task), n, st in zip(groups, sizes, self._streams):
-                if task is None:                     # the router found no degradation: the image passes through unchanged
-                    ys[a:b].copy_(xs[a:b])
-                    off += n
-                    continue
+            esz = 3 * H * W * 4
+            jobs = []
+            for (task, n), st in zip(groups, self._streams):
+                base = tindex[task] * cap_B * esz
                 st.wait_event(fork)
-                d = L.CdanFwdDesc()
-                d.dtype, d.B, d.H, d.W = self.dtype, b - a, H, W
-                d.params, d.x, d.y = self.blobs[task].data_ptr(), xs[a:b].data_ptr(), ys[a:b].data_ptr()
-                d.workspace, d.workspace_bytes = self._ws.data_ptr() + off, n
-                d.flags, d.aux = 0, None
-                L.check(L.lib.mdie_cdan_forward(C.byref(d), st.cuda_stream), "mdie_cdan_forward")
-                off += n
+                jobs.append((task, n, H, W, xs.data_ptr() + base, ys.data_ptr() + base, wss[task], st.cuda_stream))
+            if self.threads and len(jobs) > 1:
+                futs = [self._workers(len(jobs)).submit(self._launch_group, *j) for j in jobs]
+                for f in futs:
+                    f.result()                            # (re-raises a launch error of that group)
+            else:
+                for j in jobs:
+                    self._launch_group(*j)
+            for st in self._streams[:len(groups)]:
                 done = torch.cuda.Event()
                 done.record(st)
                 main.wait_event(done)
-            out = torch.empty_like(ys)
-            out.index_copy_(0, idx, ys)
+            res = ys.index_select(0, slot_t)
+            if len(routed) == B:
+                out = res
+            else:
+                out.index_copy_(0, torch.tensor(routed, device=self.device), res)
         return out
 
 

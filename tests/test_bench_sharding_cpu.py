@@ -228,3 +228,42 @@ def test_gradients_are_views_of_the_flat_buckets_two_ranks():
             views_before, views_after, mean_ok, zero_max = out[step]
             assert views_before and views_after and mean_ok and zero_max == 0.0
         assert copies == 2          # frozen_bias's autograd-made gradient, once per step; the four sink-aware gradients never
+
+
+def _routed_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from mdie_amd import engine as E
+    labels = bench.routed_labels(3, 64)                  # the same list on every rank
+    labels[5] = labels[17] = labels[40] = None           # images the router left alone
+    mine = E.routed_shard(labels, rank, world, bench.ROUTED_TASKS)
+    tasks = sorted({labels[i] for i in mine if labels[i] is not None})
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (mine, tasks))
+    t = bench.max_over_ranks(0.5 + rank, dist, "cpu")
+    q.put((rank, gathered, t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_routed_batch_is_dealt_by_task_two_ranks():
+    """bench.py --workload routed (BASELINE configs[3]; classification/train_multilabel_classifier.py:251-253 labels the images): every
+    image of the global batch runs on exactly one rank, a task's images all on the rank that owns the task (so a rank binds only its
+    own weight sets), un-routed images are spread; the step time is the max over ranks.  No collective on the data path."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 39500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_routed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, gathered, t in res:
+        (m0, t0), (m1, t1) = gathered
+        assert sorted(m0 + m1) == list(range(64)) and not set(m0) & set(m1)
+        assert not set(t0) & set(t1) and len(t0) + len(t1) == 9
+        assert t == 1.5
