@@ -634,7 +634,9 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
     return launch_conv_thin(Traits<T>::DT, a, stream, d->tr);
   }
   if (conv_thin_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr)) return launch_conv_thin(Traits<T>::DT, a, stream);
+#ifndef EXP_NO_KSPLIT   // (A/B builds only: tools/measure_all.sh compares the step with and without the kernel on one box)
   if (conv_ksplit_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr)) return launch_conv_ksplit(Traits<T>::DT, a, stream);
+#endif
   const int bn = (d->cout % 64 == 0) ? 64 : 16;
   a.n_tiles = d->cout / bn;
   // Small feature maps (32x32 at the network's deep end) do not fill 256 CUs with 16x16 tiles: switch to 8x8 tiles
