@@ -8,8 +8,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
+PART=${2:-all}     # benches | profiler | all   (a gpurun call is limited to 20 minutes: the two halves fit one call each)
 run() { local name=$1; shift; echo "== $name"; timeout -k 10 600 "$@" > "$OUT/$name.txt" 2> "$OUT/$name.err" || echo "   ($name: exit $?)"; }
 
+if [ "$PART" != profiler ]; then
 run bench_bf16 python bench.py
 run bench_bf16_graph python bench.py --launch graph --no-cpu --no-extra
 run bench_fp16 python bench.py --precision fp16 --no-cpu --no-extra
@@ -34,6 +36,8 @@ run conv_microbench python tools/bench_conv.py bf16 conv2 conv3 conv4 dec1 dec2 
 run ab_ksplit bash tools/bench_ab.sh "$ROOT/multi-degradation-image-enhancement_amd/libmdie_hip_noksplit.so" 3
 run train_ddp1_bf16_b8_512 env MDIE_DDP_SINGLE=1 python tools/bench_train.py bf16 8 512 charbonnier:1,ssim:0.5 eager
 run bench_routed python bench.py --workload routed
+fi
+if [ "$PART" = benches ]; then echo "done (benches): $(ls "$OUT" | wc -l) files"; exit 0; fi
 
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprofv3 kernel stats"
