@@ -123,15 +123,18 @@ def routed_main(args, rank, world, dev, dist, P):
     grouping every step, 16 distinct batches cycled); the router network itself is timed by tools/bench_configs.py."""
     from mdie_amd import engine as E
     B, S, n_lists = args.batch * world, args.size, 16
-    eng = E.RoutedEngine(dev, args.precision)
-    mine_tasks = [t for i, t in enumerate(sorted(ROUTED_TASKS)) if i % world == rank]
+    mode = args.routed_mode
+    eng = E.RoutedEngine(dev, args.precision, mode=mode)
+    # "chain": every rank holds all nine weight sets (9 x 7 MB) and takes an equal slice of the global batch -- one launch chain per
+    # rank whatever the labels.  "groups": tasks dealt to ranks, images follow their task (engine.routed_shard)
+    mine_tasks = sorted(ROUTED_TASKS) if mode == "chain" else [t for i, t in enumerate(sorted(ROUTED_TASKS)) if i % world == rank]
     for t in mine_tasks:
         eng.load_task(t, P.make_state_dict(100 + ROUTED_TASKS.index(t)))
     x_all, _ = P.lowlight_batch(2000, B, S, S)
     batches = []
     for k in range(n_lists):
         labels = routed_labels(k, B)
-        idx = E.routed_shard(labels, rank, world, ROUTED_TASKS)
+        idx = list(range(rank * args.batch, (rank + 1) * args.batch)) if mode == "chain" else E.routed_shard(labels, rank, world, ROUTED_TASKS)
         batches.append((x_all[idx].to(dev), [labels[i] for i in idx]))
     it = [0]
 
@@ -162,8 +165,11 @@ def routed_main(args, rank, world, dev, dist, P):
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                           "config": {"workload": f"BASELINE configs[3]: all config/*.json tasks as 9 seeded weight sets, {S}x{S}, global batch {B} labelled by a stub router "
                                                  f"(a different grouping every step), {args.precision} storage + fp32 accumulate",
-                                     "global_batch": B, "parallelism": f"tasks dealt to {world} rank(s), images follow their task, no collective",
-                                     "launch": "eager, one stream + one enqueueing host thread per task group"}}))
+                                     "global_batch": B,
+                                     "parallelism": (f"{world} rank(s), each holds all 9 weight sets and an equal slice of the batch, no collective" if mode == "chain"
+                                                     else f"tasks dealt to {world} rank(s), images follow their task, no collective"),
+                                     "launch": ("eager, ONE launch chain per rank-batch: every kernel looks up its image's weight set (mdie_cdan_fwd_desc.blob_delta)"
+                                                if mode == "chain" else "eager, one stream + one enqueueing host thread per task group")}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -173,6 +179,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--routed-mode", choices=["chain", "groups"], default="chain", help="--workload routed: one launch chain (default) or task groups on streams")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 22
+#define MDIE_ABI_VERSION 23
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1,
        MDIE_F16 = 2 /* IEEE half: the reference's mixed-precision dtype (torch.cuda.amp.autocast, models/model.py:15,159) */ };
@@ -123,6 +123,10 @@ typedef struct {
                               pooling, residual) -- the layout mdie_bn_bwd_reduce / mdie_bn_bwd_apply_multi take `da` in (da_plane), so that
                               one feature segment of several layers' input gradients is a set of dense streams */
   const struct mdie_bn_reduce_fuse* bnred;   /* optional, with out_group_stride only: see below */
+  const long long* blob_delta;   /* optional, DEVICE array [B]: SEVERAL WEIGHT SETS IN ONE LAUNCH.  Image b adds blob_delta[b] bytes to every
+                                    parameter pointer of this descriptor (weight, pre_* / post_* vectors, the members of `tr`): all
+                                    parameter blobs of one architecture share one layout (mdie_cdan_pack_params), so one offset per image
+                                    selects its weight set.  NULL: one weight set.  Not with out_group_stride / bnred (training). */
 } mdie_conv_desc;
 
 /* The BatchNorm-ReLU backward SUMS fused into the input-gradient convolution of a DenseBlock layer (training).  The convolution's
@@ -218,6 +222,7 @@ typedef struct {
   int pool;
   void* out;
   int out_stride;
+  const long long* blob_delta;   /* optional, device [B]: per-image byte offset of the parameter pointers (see mdie_conv_desc) */
 } mdie_conv_first_desc;
 
 int mdie_conv_first_fwd(const mdie_conv_first_desc* d, void* stream);
@@ -251,6 +256,7 @@ typedef struct {
   const float* pool_partial; int pool_slabs; /* optional: per-(image, slab) channel sums / maxima of x,
                                                 [B][pool_slabs][2][C], already produced by the kernel that wrote x
                                                 (mdie_upsample2x_add); pass 1 is skipped */
+  const long long* blob_delta;   /* optional, device [B]: per-image byte offset of w1, b1, w2, b2, w7, bn (see mdie_conv_desc) */
 } mdie_cbam_desc;
 
 size_t mdie_cbam_workspace_bytes(int B, int H, int W, int C);
@@ -373,6 +379,7 @@ typedef struct {
   void* g0; int g0_stride;
   const mdie_tr_fuse* tr;      /* optional (16-bit types): start the transition's partial sums with the terms of `base` (the transition's
                                   stored channels 0..2) and of g0 (stored channels tr->c0 ..); partial_in is ignored, partial_out written */
+  const long long* blob_delta; /* optional, device [B]: per-image byte offset of the parameter pointers (see mdie_conv_desc) */
 } mdie_up_dense0_desc;
 int mdie_up_add_dense0_fwd(const mdie_up_dense0_desc* d, void* stream);
 
@@ -418,6 +425,10 @@ typedef struct {
   void* aux;                /* mdie_aux_create handle or NULL; used only when `stream` is not capturing (see above) */
   float* launch_ms; int* launch_kind; int max_launches; int* n_launches;
   mdie_launch_info* launch_info;
+  const long long* blob_delta;  /* optional, device [B]: image b runs with the parameter blob at (char*)params + blob_delta[b] -- a batch of
+                                   mixed tasks (BASELINE configs[3]) as ONE launch chain instead of one chain per task group.  Every blob
+                                   must be a mdie_cdan_pack_params blob of this dtype; images of one task should be contiguous (the
+                                   persistent kernels reload their weights where the offset changes along their run of tiles). */
 } mdie_cdan_fwd_desc;
 
 enum { MDIE_FWD_FUSED_TAIL = 1 /* run upsample + final_dense + sigmoid as ONE launch (mdie_tail_fwd) instead of 7 */,

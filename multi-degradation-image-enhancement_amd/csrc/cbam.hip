@@ -38,7 +38,19 @@ struct CbamArgs {
   int nslab, slab;  // pool blocks per image, pixels per block
   int spatial;     // 0: channel gate only
   int gate_ready;  // pass 3: the gate was computed by cbam_gate_kernel (wide tensors), do not re-derive it per block
+  const long long* delta;   // several weight sets in one launch (mdie_cbam_desc.blob_delta): per-image byte offset of w1, b1, w2, b2, w7, bn
 };
+
+// the arguments with image `img`'s weight set selected (a scalar load and six pointer additions; nothing for the usual single set)
+__device__ __forceinline__ CbamArgs cbam_select(const CbamArgs& a0, int img) {
+  CbamArgs a = a0;
+  if (a0.delta) {
+    const long long dl = a0.delta[img];
+    auto sh = [&](const float* p) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + dl); };
+    a.w1 = sh(a0.w1); a.b1 = sh(a0.b1); a.w2 = sh(a0.w2); a.b2 = sh(a0.b2); a.w7 = sh(a0.w7); a.bn = sh(a0.bn);
+  }
+  return a;
+}
 
 // ---- pass 1 ----------------------------------------------------------------------------------------
 template <typename T>
@@ -84,7 +96,8 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_pool_kernel(const CbamArgs a)
 // are issued at once (a per-output loop serialises 2*Hd cold-miss round trips: 42 us at C=512).
 // gate[c] of image `img` into LDS (`gate`, [C]); scratch: avg[C], mx[C], part[2*CB_THREADS], hid[Hd]
 template <int W1V, int W2V>   // float4 of layer-1 / layer-2 weights a thread holds: <16, 8> covers C <= 512, <1, 2> C <= 128
-__device__ __forceinline__ void cbam_gate_block(const CbamArgs& a, int img, float* avg, float* mx, float* part, float* hid, float* gate) {
+__device__ __forceinline__ void cbam_gate_block(const CbamArgs& a0, int img, float* avg, float* mx, float* part, float* hid, float* gate) {
+  const CbamArgs a = cbam_select(a0, img);
   const int Hd = a.C / 16;
   const int tid = threadIdx.x;
   const float inv = 1.0f / (float)(a.H * a.W);
@@ -325,9 +338,10 @@ __global__ __launch_bounds__(CB_THREADS) void cbam_chanpool_kernel(const CbamArg
 
 // ---- pass 4 ----------------------------------------------------------------------------------------
 template <typename T, int TS>
-__global__ __launch_bounds__(CB_THREADS) void cbam_spatial_kernel(const CbamArgs a) {
+__global__ __launch_bounds__(CB_THREADS) void cbam_spatial_kernel(const CbamArgs a0) {
   constexpr int VEC = Traits<T>::VEC;
   constexpr int PW = TS + 6;
+  const CbamArgs a = cbam_select(a0, blockIdx.y);
   extern __shared__ __attribute__((aligned(16))) char dyn[];
   float* gate = reinterpret_cast<float*>(dyn);     // [C]
   float* patch = gate + a.C;                       // [2][PW][PW]
@@ -450,6 +464,7 @@ static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream, c
   a.x = reinterpret_cast<const char*>(d->x); a.x_stride = d->x_stride;
   a.w1 = d->w1; a.b1 = d->b1; a.w2 = d->w2; a.b2 = d->b2; a.w7 = d->w7;
   a.bn = d->bn;
+  a.delta = d->blob_delta;
   a.mul = reinterpret_cast<const char*>(d->mul); a.mul_stride = d->mul_stride;
   a.out = reinterpret_cast<char*>(d->out); a.out_stride = d->out_stride;
   a.nslab = nslab_for(d->H, d->W);
@@ -574,6 +589,7 @@ extern "C" int mdie_cbam_conv_fwd(const mdie_cbam_conv_desc* f, void* stream) {
   MDIE_REQUIRE(f != nullptr, "mdie_cbam_conv_fwd: null descriptor");
   const mdie_cbam_desc* d = &f->cbam;
   if (int e = check_cbam(d, false)) return e;
+  MDIE_REQUIRE(!d->blob_delta, "mdie_cbam_conv_fwd: one weight set only (no blob_delta)");
   MDIE_REQUIRE(f->weight && f->post_scale && f->post_shift && f->out && f->out_stride >= 16 && f->out_stride % 4 == 0 && ((uintptr_t)f->out & 15) == 0 &&
                ((uintptr_t)f->weight & 15) == 0, "mdie_cbam_conv_fwd: convolution side: null pointer / out_stride %d / alignment", f->out_stride);
   MDIE_REQUIRE(f->act == MDIE_ACT_NONE || f->act == MDIE_ACT_RELU || f->act == MDIE_ACT_SIGMOID, "mdie_cbam_conv_fwd: act %d", f->act);

@@ -209,6 +209,7 @@ struct FirstArgs {
   const float* x;      // NCHW fp32 [B,3,H,W]
   const char* weight;  // [step][cout][64 B], k = tap*3 + c
   EpiArgs e;
+  const long long* delta;   // several weight sets in one launch (mdie_conv_first_desc.blob_delta): conv_first_kernel only
 };
 
 template <typename T, int BN>
@@ -226,18 +227,19 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_first_kernel(const First
   const int ty = bid % a.tiles_y; bid /= a.tiles_y;
   const int img = bid;
   const int y0 = ty * TILE, x0 = tx * TILE, n0 = nt * BN;
+  const long long dl = a.delta ? a.delta[img] : 0;   // (several weight sets in one launch: this tile's image selects its set)
   // weight fragments -> registers (issued first; they land while the patch is staged)
   uint4 wf[STEPS][NCS];
 #pragma unroll
   for (int s = 0; s < STEPS; ++s)
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs)
-      wf[s][cs] = *reinterpret_cast<const uint4*>(a.weight + ((size_t)s * a.cout + n0 + cs * 16 + lp) * 64 + lq * 16);
+      wf[s][cs] = *reinterpret_cast<const uint4*>(a.weight + dl + ((size_t)s * a.cout + n0 + cs * 16 + lp) * 64 + lq * 16);
 
   // epilogue constants -> LDS (written with the patch, read back per pixel subtile: 8*NCS registers less across the loop)
   __shared__ __attribute__((aligned(16))) float lds_epi[2 * BN];
   float cepi[2] = {0.f, 0.f};
-  if (tid < BN) { cepi[0] = a.e.post_scale[n0 + tid]; cepi[1] = a.e.post_shift[n0 + tid]; }
+  if (tid < BN) { cepi[0] = param_shift(a.e.post_scale, dl)[n0 + tid]; cepi[1] = param_shift(a.e.post_shift, dl)[n0 + tid]; }
   // input patch: issue every global load before the first wait
   const size_t plane = (size_t)a.H * a.W;
   constexpr int PIT = (PW * PW + CONV_THREADS - 1) / CONV_THREADS;
@@ -607,6 +609,8 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   a.weight = reinterpret_cast<const char*>(d->weight);
   fill_epi(a.e, d->H, d->W, d->post_scale, d->post_shift, d->act, d->pool, d->residual, d->res_stride, d->out, d->out_stride, d->out_nchw3);
   a.pool_partial = d->pool_partial;
+  a.delta = d->blob_delta;
+  MDIE_REQUIRE(!d->blob_delta || (!d->bnred && (d->out_group_stride == 0 || d->out_group_stride == 16)), "mdie_conv_fwd: blob_delta is an inference feature (no out_group_stride / bnred)");
   if (d->out_group_stride != 0 && d->out_group_stride != 16) {   // one plane per 16 output channels: conv_planar.hip
     MDIE_REQUIRE(!d->tr, "mdie_conv_fwd: out_group_stride and tr exclude each other");
     a.e.out_gs = d->out_group_stride;
@@ -646,7 +650,9 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
   const bool small = wgs16 < SMALL_GRID_WGS;
   // (64-wide output tiles only: with 16 outputs there are 4 MFMAs per 4 loads and the staged kernel is faster -- measured
   //  final.tr 85 us staged vs 92 us streaming, dense1.tr 58 us staged vs 47 us streaming, B=32 256x256 bf16)
-  if (d->ksize == 1 && !d->pool && bn == 64 &&
+  // (several weight sets in one launch: conv_kernel instead -- a streaming workgroup keeps ITS weights in LDS while it walks tiles of
+  //  every image)
+  if (d->ksize == 1 && !d->pool && bn == 64 && !a.delta &&
       (size_t)a.nchunk * 4 * bn * 16 + (size_t)2 * a.nchunk * KC * sizeof(float) <= 96 * 1024)
     return launch_conv1x1_stream<T, 4>(a, stream);
   if (d->pool_partial) {   // 3x3, 64-wide, ReLU, no max-pool: checked by the caller below
@@ -771,6 +777,7 @@ static int dispatch_first(const mdie_conv_first_desc* d, hipStream_t stream) {
   a.tiles_x = cdiv(d->W, 16); a.tiles_y = cdiv(d->H, 16);
   a.x = d->x; a.weight = reinterpret_cast<const char*>(d->weight);
   fill_epi(a.e, d->H, d->W, d->post_scale, d->post_shift, d->act, d->pool, nullptr, 0, d->out, d->out_stride);
+  a.delta = d->blob_delta;
 #ifdef EXP_FSTAMPS
   if (g_exp_dbg) { a.e.residual = (const char*)g_exp_dbg; a.e.res_stride = -12345; }
 #endif
@@ -779,7 +786,9 @@ static int dispatch_first(const mdie_conv_first_desc* d, hipStream_t stream) {
   const int grid = a.n_tiles * a.tiles_x * a.tiles_y * a.B;
   TimedLaunch tl(MDIE_K_CONV3);
   if constexpr (sizeof(T) == 2) {
-    if (bn == 64 && d->pool && d->act == MDIE_ACT_RELU && (size_t)18 * d->W * 4 < (1ull << 32)) {
+    // (several weight sets in one launch: the per-tile kernel below -- the persistent one keeps its weight fragments in registers
+    //  across a run of tiles; the two agree bit for bit, tests/test_gpu_parity.py::test_first_layer_*)
+    if (bn == 64 && d->pool && d->act == MDIE_ACT_RELU && (size_t)18 * d->W * 4 < (1ull << 32) && !d->blob_delta) {
       constexpr int per_cu = 4;
       const int tiles = a.tiles_x * a.tiles_y * a.B;
       const int wgs = 8 * cdiv(std::min(tiles, std::max(256 * per_cu / a.n_tiles, 8)), 8);   // persistent: resident workgroups walk the tiles

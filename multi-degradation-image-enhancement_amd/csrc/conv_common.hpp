@@ -47,7 +47,15 @@ struct ConvArgs {
   const char* weight;
   float* pool_partial;   // STATS kernels: [B][tiles per image][2][cout] channel sums / maxima of the output
   EpiArgs e;
+  // several weight sets in one launch (mdie_conv_desc.blob_delta): image b adds delta[b] bytes to weight, pre_scale / pre_shift
+  // and e.post_scale / e.post_shift (param_shift below); nullptr = one weight set
+  const long long* delta;
 };
+
+// parameter pointer of image `img`'s weight set
+template <typename P> __device__ __forceinline__ const P* param_shift(const P* p, long long dl) {
+  return reinterpret_cast<const P*>(reinterpret_cast<const char*>(p) + dl);
+}
 
 template <typename T> __device__ __forceinline__ f32x4 mma16(const uint4& w, const uint4& x, f32x4 acc);
 template <> __device__ __forceinline__ f32x4 mma16<bf16>(const uint4& w, const uint4& x, f32x4 acc) {

@@ -81,6 +81,11 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
   const int trem = patch - img * tpi;
   const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
   const int y0 = ty * TILE, x0 = tx * TILE, n0 = blockIdx.y * BN;
+  // several weight sets in one launch: this tile's image selects its set (one scalar load; 0 for the usual single set)
+  const long long dl = a.delta ? a.delta[img] : 0;
+  const char* const p_weight = a.weight + dl;
+  const float* const p_pre_scale = param_shift(a.pre_scale, dl), * const p_pre_shift = param_shift(a.pre_shift, dl);
+  const float* const p_post_scale = param_shift(a.e.post_scale, dl), * const p_post_shift = param_shift(a.e.post_shift, dl);
 
   const int q = tid & 3;  // this thread's 16-byte column while staging the patch (CONV_THREADS % 4 == 0)
   const bool has_pre = a.pre_scale != nullptr;
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
       gp += g_step + (((pwrap >> it) & 1) ? g_wrap : 0);
     }
     // weights of this chunk: global [chunk][q][tap][cout] x 16 B  ->  LDS [q][tap][BN] x 16 B (linear copy per (q, tap))
-    const char* wsrc = a.weight + chunk * wchunk_bytes;
+    const char* wsrc = p_weight + chunk * wchunk_bytes;
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
       wv[it] = make_uint4(0, 0, 0, 0);
@@ -206,11 +211,11 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
 #pragma unroll
     for (int i = 0; i < PRE_IT; ++i) {
       const int c = tid + i * CONV_THREADS;
-      cpre[0][i] = c < a.cin ? a.pre_scale[c] : 0.f;
-      cpre[1][i] = c < a.cin ? a.pre_shift[c] : 0.f;
+      cpre[0][i] = c < a.cin ? p_pre_scale[c] : 0.f;
+      cpre[1][i] = c < a.cin ? p_pre_shift[c] : 0.f;
     }
   }
-  if (tid < BN) { cepi[0] = a.e.post_scale[n0 + tid]; cepi[1] = a.e.post_shift[n0 + tid]; }
+  if (tid < BN) { cepi[0] = p_post_scale[n0 + tid]; cepi[1] = p_post_shift[n0 + tid]; }
   load_chunk(0);
   if (has_pre) {   // launch-uniform
 #pragma unroll
@@ -219,8 +224,8 @@ __global__ __launch_bounds__(CONV_THREADS, conv_min_waves(BN, TILE)) void conv_k
       if (c < kpad) { lds_pre[c] = cpre[0][i]; lds_pre[kpad + c] = cpre[1][i]; }
     }
     for (int c = tid + PRE_IT * CONV_THREADS; c < kpad; c += CONV_THREADS) {
-      lds_pre[c] = c < a.cin ? a.pre_scale[c] : 0.f;
-      lds_pre[kpad + c] = c < a.cin ? a.pre_shift[c] : 0.f;
+      lds_pre[c] = c < a.cin ? p_pre_scale[c] : 0.f;
+      lds_pre[kpad + c] = c < a.cin ? p_pre_shift[c] : 0.f;
     }
   }
   if (tid < BN) { lds_epi[tid] = cepi[0]; lds_epi[BN + tid] = cepi[1]; }   // read back after the last MFMA: visible after any barrier below

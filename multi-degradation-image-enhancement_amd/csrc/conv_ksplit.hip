@@ -91,7 +91,8 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_ksplit_kernel(const Conv
   const size_t img_pix = (size_t)img * a.H * a.W;
   constexpr int COUT = 16;                                                        // (conv_ksplit_applicable) -- taps become immediate offsets
   constexpr int wchunk_bytes = 4 * 9 * COUT * 16;
-  const char* const wlane = a.weight + (lq * 9 * COUT + lp) * 16;                 // + tap * COUT * 16 + chunk * wchunk_bytes
+  const long long dl = a.delta ? a.delta[img] : 0;                                // (several weight sets in one launch: this tile's image selects its set)
+  const char* const wlane = a.weight + dl + (lq * 9 * COUT + lp) * 16;            // + tap * COUT * 16 + chunk * wchunk_bytes
 
   uint4 pv[KS_PATCH_IT], wv[9];
   bool live = false;
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_ksplit_kernel(const Conv
   // pre-activation constants of the layer -> LDS once (a wave reads 16 floats of them per chunk while staging); behind the first
   // chunk's loads, so their latency and this loop's run together
   for (int c = tid; c < a.nchunk * KC; c += CONV_THREADS) {
-    lds_pre[c] = c < a.cin ? a.pre_scale[c] : 0.f;
-    lds_pre[KS_MAX_CIN + c] = c < a.cin ? a.pre_shift[c] : 0.f;
+    lds_pre[c] = c < a.cin ? param_shift(a.pre_scale, dl)[c] : 0.f;
+    lds_pre[KS_MAX_CIN + c] = c < a.cin ? param_shift(a.pre_shift, dl)[c] : 0.f;
   }
   __syncthreads();
   KSTAMP(2);
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_ksplit_kernel(const Conv
   for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const f32x4*>(smem + w * KS_WAVE_LDS + (wave * 64 + lane) * 16);
 
   const int gy = y0 + 2 * wave + (lp >> 3), gx = x0 + (lp & 7);
-  const float4 sc = *reinterpret_cast<const float4*>(a.e.post_scale + lq * 4), sh = *reinterpret_cast<const float4*>(a.e.post_shift + lq * 4);
+  const float4 sc = *reinterpret_cast<const float4*>(param_shift(a.e.post_scale, dl) + lq * 4), sh = *reinterpret_cast<const float4*>(param_shift(a.e.post_shift, dl) + lq * 4);
   float v[4] = {fmaf(sum[0], sc.x, sh.x), fmaf(sum[1], sc.y, sh.y), fmaf(sum[2], sc.z, sh.z), fmaf(sum[3], sc.w, sh.w)};
   if (a.e.act == MDIE_ACT_RELU) {
 #pragma unroll

@@ -67,6 +67,7 @@ struct ThinArgs {
   const float* tr_in; float* tr_out;    // [pixel][4] fp32 partial sums of the transition (may be the same buffer)
   int nunit; int unit_col[TH_MAXUNIT]; int unit_ncol[TH_MAXUNIT];   // PAIR form: unit u = columns unit_col[u] .. + unit_ncol[u] (1 or 2) of ONE segment
   const float *tr_post_scale, *tr_post_shift; float* tr_nchw3;   // TR == 2: the transition's epilogue constants and the network output
+  const long long* delta;           // MULTI: several weight sets in one launch, a byte offset per image for every parameter pointer above
 };
 
 #ifdef EXP_TSTAMPS   // diagnostic build only (tools/stamp_thin.py): per-segment shader-clock sums of wave 0 of each workgroup
@@ -98,7 +99,13 @@ static unsigned long long* g_thin_dbg = nullptr;
 // with lane = (pixel, 16-byte half): a wave instruction reads 32 pixels x 32 bytes = 1 KiB CONTIGUOUS, 11 loads per lane cover
 // the patch, and the lane writes its half into its own plane.  Single-column units (the 8-channel base) run the same 11
 // iterations with both halves reading the same 16 bytes and the odd lanes writing nothing.  Needs <= 4 units (one per wave).
-template <typename T, int NCHUNK, int ACT, int TR = 0, bool PAIR = false>
+// MULTI (round 4): several weight sets in one launch (mdie_conv_desc.blob_delta).  A workgroup's run of tiles is contiguous, so
+// with the images of a task next to each other it crosses a weight-set boundary at most a few times.  The run is cut into
+// STRETCHES of tiles that share a weight set; everything the workgroup loads once -- weight fragments, pre-activation constants
+// in LDS, epilogue and transition constants -- is loaded per stretch, and the tile pipeline (prefetch of the next tile under the
+// current one) runs inside a stretch exactly as in the single-set form (a reload inside the tile loop, with the prefetch
+// registers live, spilled 50-60 registers).
+template <typename T, int NCHUNK, int ACT, int TR = 0, bool PAIR = false, bool MULTI = false>
 __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs a, const int n_items) {
   static_assert(sizeof(T) == 2, "16-bit storage types");
   constexpr int PW = TH_PW, PIT = PAIR ? TH_PIT2 : TH_PIT, CPW = PAIR ? 1 : NCHUNK;
@@ -114,8 +121,9 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
   const int band0 = ((int)blockIdx.x & 7) * per_xcd, band1 = min(band0 + per_xcd, n_items);
   const int run = (per_xcd + nwg - 1) / nwg;
   int item = band0 + ((int)blockIdx.x >> 3) * run;
-  const int item_end = min(item + run, band1);
-  if (item >= item_end) return;
+  const int run_end = min(item + run, band1);
+  if (item >= run_end) return;
+  int item_end = run_end;             // end of the current stretch (MULTI: where the weight set changes)
 #ifdef EXP_TSTAMPS
   unsigned long long* const dbg = a.dbg;
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0, rstart = 0;
@@ -123,37 +131,6 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
   const int item_first = item;
 #endif
   int tx, ty, img;
-  { int r = item; tx = r % a.tiles_x; r /= a.tiles_x; ty = r % a.tiles_y; img = r / a.tiles_y; }
-
-  // ---- once per workgroup: weight fragments -> registers (A row lp = output channel, K group lq), constants -> LDS ----
-  uint4 wreg[NCHUNK][9];
-#pragma unroll
-  for (int k = 0; k < NCHUNK; ++k)
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) wreg[k][tap] = *reinterpret_cast<const uint4*>(a.weight + (size_t)k * TH_WCHUNK + ((lq * 9 + tap) * 16 + lp) * 16);
-  {
-    const int nc = a.ncol * 8;
-    for (int c = tid; c < nc; c += TH_THREADS) { lds_pre[c] = c < a.cin ? a.pre_scale[c] : 0.f; lds_pre[nc + c] = c < a.cin ? a.pre_shift[c] : 0.f; }
-  }
-  const float4 esc = *reinterpret_cast<const float4*>(a.post_scale + 4 * lq), esh = *reinterpret_cast<const float4*>(a.post_shift + 4 * lq);
-  // transition term: A fragments (row lp of subtile ps' operand = output lp - 4 ps, K group lq = this layer's channels
-  // 4 lq .. 4 lq + 3 in elements 0..3) and the transition's BatchNorm constants of the lane's 4 channels
-  uint2 tra[4];
-  f32x2 trs[2], trb[2];
-  float4 trps = make_float4(0.f, 0.f, 0.f, 0.f), trpb = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (TR != 0) {
-    const int c = a.tr_c0 + 4 * lq;                                          // stored input channel of the transition
-    const char* const wrow = a.tr_w + ((size_t)(c >> 5) * 4 + ((c & 31) >> 3)) * (16 * 16) + (c & 7) * 2;
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int o = lp - 4 * ps;
-      const uint2 w = *reinterpret_cast<const uint2*>(wrow + (unsigned)(o & 15) * 16);   // (unconditional load, masked after)
-      tra[ps] = (o >= 0 && o < 4) ? w : make_uint2(0u, 0u);
-    }
-    const float4 s4 = *reinterpret_cast<const float4*>(a.tr_scale + 4 * lq), b4 = *reinterpret_cast<const float4*>(a.tr_shift + 4 * lq);
-    trs[0] = f32x2{s4.x, s4.y}; trs[1] = f32x2{s4.z, s4.w}; trb[0] = f32x2{b4.x, b4.y}; trb[1] = f32x2{b4.z, b4.w};
-    if constexpr (TR == 2) { trps = *reinterpret_cast<const float4*>(a.tr_post_scale); trpb = *reinterpret_cast<const float4*>(a.tr_post_shift); }
-  }
 
   // ---- lane constants ----
   // staging: patch pixel p = lane + 64 it: offset in pixels from the patch corner, LDS offset inside a plane, border classes
@@ -212,6 +189,47 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
     }
   };
 
+  do {   // MULTI: one pass per stretch of the run that shares a weight set; otherwise exactly one pass
+  { int r = item; tx = r % a.tiles_x; r /= a.tiles_x; ty = r % a.tiles_y; img = r / a.tiles_y; }
+  long long dl = 0;
+  if constexpr (MULTI) {
+    dl = a.delta[img];
+    const int per_img = a.tiles_x * a.tiles_y;
+    int nimg_ = img + 1;
+    while (nimg_ * per_img < run_end && a.delta[nimg_] == dl) ++nimg_;       // wave-uniform, scalar: the first image of another set
+    item_end = min(run_end, nimg_ * per_img);
+    __syncthreads();                                                         // (the previous stretch's readers of the LDS constants are done)
+  }
+  // ---- once per stretch: weight fragments -> registers (A row lp = output channel, K group lq), constants -> LDS ----
+  uint4 wreg[NCHUNK][9];
+#pragma unroll
+  for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) wreg[k][tap] = *reinterpret_cast<const uint4*>(a.weight + dl + (size_t)k * TH_WCHUNK + ((lq * 9 + tap) * 16 + lp) * 16);
+  {
+    const int nc = a.ncol * 8;
+    const float* const psc_ = param_shift(a.pre_scale, dl), * const psh_ = param_shift(a.pre_shift, dl);
+    for (int c = tid; c < nc; c += TH_THREADS) { lds_pre[c] = c < a.cin ? psc_[c] : 0.f; lds_pre[nc + c] = c < a.cin ? psh_[c] : 0.f; }
+  }
+  const float4 esc = *reinterpret_cast<const float4*>(param_shift(a.post_scale, dl) + 4 * lq), esh = *reinterpret_cast<const float4*>(param_shift(a.post_shift, dl) + 4 * lq);
+  // transition term: A fragments (row lp of subtile ps' operand = output lp - 4 ps, K group lq = this layer's channels
+  // 4 lq .. 4 lq + 3 in elements 0..3) and the transition's BatchNorm constants of the lane's 4 channels
+  uint2 tra[4];
+  f32x2 trs[2], trb[2];
+  float4 trps = make_float4(0.f, 0.f, 0.f, 0.f), trpb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (TR != 0) {
+    const int c = a.tr_c0 + 4 * lq;                                          // stored input channel of the transition
+    const char* const wrow = a.tr_w + dl + ((size_t)(c >> 5) * 4 + ((c & 31) >> 3)) * (16 * 16) + (c & 7) * 2;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int o = lp - 4 * ps;
+      const uint2 w = *reinterpret_cast<const uint2*>(wrow + (unsigned)(o & 15) * 16);   // (unconditional load, masked after)
+      tra[ps] = (o >= 0 && o < 4) ? w : make_uint2(0u, 0u);
+    }
+    const float4 s4 = *reinterpret_cast<const float4*>(param_shift(a.tr_scale, dl) + 4 * lq), b4 = *reinterpret_cast<const float4*>(param_shift(a.tr_shift, dl) + 4 * lq);
+    trs[0] = f32x2{s4.x, s4.y}; trs[1] = f32x2{s4.z, s4.w}; trb[0] = f32x2{b4.x, b4.y}; trb[1] = f32x2{b4.z, b4.w};
+    if constexpr (TR == 2) { trps = *reinterpret_cast<const float4*>(param_shift(a.tr_post_scale, dl)); trpb = *reinterpret_cast<const float4*>(param_shift(a.tr_post_shift, dl)); }
+  }
   int y0 = ty * TH_TILE, x0 = tx * TH_TILE;
   issue(img, y0, x0);
   __syncthreads();                                                           // the constants are in LDS
@@ -333,6 +351,7 @@ __global__ __launch_bounds__(TH_THREADS, 2) void conv_thin_kernel(const ThinArgs
   // (first tile peeled: the loop is entered, like its back edge, with "this wave's loads, then 4 stores" outstanding)
   tile();
   while (!last) tile();
+  } while (MULTI && item < run_end);
 #ifdef EXP_TSTAMPS
   if (dbg && tid == 0) {
     unsigned long long t1, r1; asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
@@ -365,12 +384,13 @@ static int launch_thin_t(const ThinArgs& t, int act, int tr, int items, hipStrea
   const int per_cu = 2;                                                       // (registers: weights live in them)
   const int wgs = 8 * cdiv(std::min(items, 256 * per_cu), 8);
   TimedLaunch tl(MDIE_K_CONV3);
-#define MDIE_THIN_P(ACT, TR, PAIR)                                                                                    \
+#define MDIE_THIN_M(ACT, TR, PAIR, MULTI_)                                                                            \
   do {                                                                                                                \
     static LdsOptIn opt;                                                                                              \
-    if (!opt.ensure(reinterpret_cast<const void*>(&conv_thin_kernel<T, NCHUNK, ACT, TR, PAIR>), 64 * 1024)) return MDIE_ELAUNCH; \
-    hipLaunchKernelGGL((conv_thin_kernel<T, NCHUNK, ACT, TR, PAIR>), dim3(wgs), dim3(TH_THREADS), lds, stream, t, items);      \
+    if (!opt.ensure(reinterpret_cast<const void*>(&conv_thin_kernel<T, NCHUNK, ACT, TR, PAIR, MULTI_>), 64 * 1024)) return MDIE_ELAUNCH; \
+    hipLaunchKernelGGL((conv_thin_kernel<T, NCHUNK, ACT, TR, PAIR, MULTI_>), dim3(wgs), dim3(TH_THREADS), lds, stream, t, items);      \
   } while (0)
+#define MDIE_THIN_P(ACT, TR, PAIR) do { if (t.delta) MDIE_THIN_M(ACT, TR, PAIR, true); else MDIE_THIN_M(ACT, TR, PAIR, false); } while (0)
 #define MDIE_THIN(ACT, TR) do { if (t.nunit > 0) MDIE_THIN_P(ACT, TR, true); else MDIE_THIN_P(ACT, TR, false); } while (0)
   if (tr == 1) MDIE_THIN(MDIE_ACT_NONE, 1);
   else if (tr == 2) MDIE_THIN(MDIE_ACT_NONE, 2);
@@ -378,6 +398,7 @@ static int launch_thin_t(const ThinArgs& t, int act, int tr, int items, hipStrea
   else MDIE_THIN(MDIE_ACT_NONE, 0);
 #undef MDIE_THIN
 #undef MDIE_THIN_P
+#undef MDIE_THIN_M
   MDIE_LAUNCH_CHECK("mdie_conv_fwd");
   return MDIE_OK;
 }
@@ -412,6 +433,7 @@ int launch_conv_thin(int dtype, const ConvArgs& a, hipStream_t stream, const mdi
   t.pre_scale = a.pre_scale; t.pre_shift = a.pre_shift; t.weight = a.weight;
   t.post_scale = a.e.post_scale; t.post_shift = a.e.post_shift;
   t.out = a.e.out; t.out_stride = (unsigned)a.e.out_stride * 2u;
+  t.delta = a.delta;
   int mode = 0;
   if (tr) {
     const bool last = tr->out_nchw3 != nullptr;

@@ -73,7 +73,10 @@ __device__ __forceinline__ void dma_piece(const char* src, unsigned lds) {
 // NCS = 16-output subtiles an item computes: 4 (the 64 staged outputs) or 2 -- the HALF-WIDTH form for layers whose 64-wide
 // item count leaves CUs idle (dec.conv2 at B = 32: 128 items on 256 CUs): two workgroups stage the same 64-output weight
 // tile and each runs the MFMAs of one half of it, so a stage's matrix work halves while twice the CUs are busy.
-template <typename T, int ACT, bool POOL, bool STATS, int NCS = 4>
+// MULTI (round 4): several weight sets in one launch (ConvArgs.delta: a byte offset per image).  An item's weights are DMA'd per
+// stage anyway -- the item's image adds its offset to the source; the epilogue constants, which the single-set form parks in LDS
+// once per workgroup, are read from the item's weight set when its epilogue runs.
+template <typename T, int ACT, bool POOL, bool STATS, int NCS = 4, bool MULTI = false>
 __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs w) {
 #ifdef EXP_STAMPS
   WideArgs w2 = w;
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
   unsigned pvalid = 0;        // bit j: inside the picture (else the zero page)
   int d_item = first, d_chunk = 0;
   int d_n0 = 0;
+  long long d_delta = 0;      // MULTI: weight-set offset of the item being fetched
   // item independent: the lane's patch pixel (row, col) per piece and its K group's byte offset
   int prow[WD_PP], pcol[WD_PP];   // row = -1: the lane's pixel is padding of the LDS image (pitch 36 > 34 columns, last piece's tail)
 #pragma unroll
@@ -152,6 +156,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
     const int ty = trem / w.tiles_x, tx = trem - ty * w.tiles_x;
     const int y0 = ty * WD_TH - 1, x0 = tx * WD_TW - 1;
     d_n0 = (nt * BNI) / WD_BN * WD_BN;                    // the 64-output weight tile this item's outputs live in
+    if constexpr (MULTI) d_delta = a.delta[img];
     pvalid = 0;
 #pragma unroll
     for (int j = 0; j < WD_PP; ++j) {
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
       if (wp < WD_W_PIECES)
         // POOL: LDS row cs*16 + j of the piece holds output channel 4j + cs (see the epilogue): the permutation costs nothing,
         // it is the lane's SOURCE row
-        dma_piece(a.weight + (size_t)chunk * (4 * 9 * 16) * a.cout + (size_t)d_n0 * 16 + (POOL ? 4 * (lane & 15) + (lane >> 4) : lane) * 16 + (size_t)wp * a.cout * 16,
+        dma_piece(a.weight + d_delta + (size_t)chunk * (4 * 9 * 16) * a.cout + (size_t)d_n0 * 16 + (POOL ? 4 * (lane & 15) + (lane >> 4) : lane) * 16 + (size_t)wp * a.cout * 16,
                   sb + WD_PATCH_BYTES + wp * 1024);
     }
   };
@@ -186,7 +191,8 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
 
   // the layer's epilogue constants -> LDS, before any DMA is in flight (a compiler-visible load waits vmcnt(0), which
   // would drain the asynchronous stage behind it); read back per item, many barriers later
-  for (int c = tid; c < a.cout; c += WD_THREADS) { lds_epi[c] = a.e.post_scale[c]; lds_epi[WD_MAX_COUT + c] = a.e.post_shift[c]; }
+  if constexpr (!MULTI)
+    for (int c = tid; c < a.cout; c += WD_THREADS) { lds_epi[c] = a.e.post_scale[c]; lds_epi[WD_MAX_COUT + c] = a.e.post_shift[c]; }
   dma_setup(d_item);
   dma_issue(0, 0);
   if (++d_chunk == a.nchunk) { d_chunk = 0; d_item += istep; }
@@ -256,11 +262,14 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
       const int img = patch / tpi, trem = patch - img * tpi;
       const int ty = trem / w.tiles_x, tx = trem - ty * w.tiles_x;
       const int y0 = ty * WD_TH, x0 = tx * WD_TW + 16 * half;
+      // the epilogue constants: the layer's, parked in LDS at kernel entry -- or (MULTI) this item's weight set's, from memory
+      const float* e_sc = lds_epi; const float* e_sh = lds_epi + WD_MAX_COUT;
+      if constexpr (MULTI) { const long long dl = a.delta[img]; e_sc = param_shift(a.e.post_scale, dl); e_sh = param_shift(a.e.post_shift, dl); }
       float4 esc[NCS], esh[NCS];
 #pragma unroll
       for (int cs = 0; cs < NCS; ++cs) {
-        esc[cs] = *reinterpret_cast<const float4*>(lds_epi + n0 + cs * 16 + lq * 4);
-        esh[cs] = *reinterpret_cast<const float4*>(lds_epi + WD_MAX_COUT + n0 + cs * 16 + lq * 4);
+        esc[cs] = *reinterpret_cast<const float4*>(e_sc + n0 + cs * 16 + lq * 4);
+        esh[cs] = *reinterpret_cast<const float4*>(e_sh + n0 + cs * 16 + lq * 4);
       }
       if constexpr (POOL) {
         // Pooled form (encoder.conv2/conv3), operand roles exchanged as in conv_first_pool_kernel: a lane's four accumulator
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void conv_wide_kernel(const WideArgs
         // all 64 lanes for a result a quarter of them keep -- and the lane stores 4 consecutive channels (8 bytes).  The
         // epilogue was 3.1 k of the 15 k cycles conv2 spends per item (tools/stamp_wide.py).  Scalar fma on purpose: see
         // conv_first_pool_kernel about the splat v_pk_fma_f32 forms.
-        const float4 p_sc = *reinterpret_cast<const float4*>(lds_epi + n0 + 4 * lp), p_sh = *reinterpret_cast<const float4*>(lds_epi + WD_MAX_COUT + n0 + 4 * lp);
+        const float4 p_sc = *reinterpret_cast<const float4*>(e_sc + n0 + 4 * lp), p_sh = *reinterpret_cast<const float4*>(e_sh + n0 + 4 * lp);
         const float sc4[4] = {p_sc.x, p_sc.y, p_sc.z, p_sc.w}, sh4[4] = {p_sh.x, p_sh.y, p_sh.z, p_sh.w};
         const int Ho = a.e.H >> 1, Wo = a.e.W >> 1;
 #pragma unroll
@@ -361,18 +370,14 @@ static int launch_wide_t(WideArgs& w, hipStream_t stream) {
   const ConvArgs& a = w.c;
   const int grid = 8 * w.wgs_per_xcd;
   TimedLaunch tl(MDIE_K_CONV3);
-#define MDIE_WIDE(ACT, POOL, STATS)                                                                              \
+#define MDIE_WIDE_M(ACT, POOL, STATS, NCS_, MULTI_)                                                               \
   do {                                                                                                           \
     static LdsOptIn opt;                                                                                         \
-    if (!opt.ensure(reinterpret_cast<const void*>(&conv_wide_kernel<T, ACT, POOL, STATS>), WD_LDS)) return MDIE_ELAUNCH; \
-    hipLaunchKernelGGL((conv_wide_kernel<T, ACT, POOL, STATS>), dim3(grid), dim3(WD_THREADS), WD_LDS, stream, w); \
+    if (!opt.ensure(reinterpret_cast<const void*>(&conv_wide_kernel<T, ACT, POOL, STATS, NCS_, MULTI_>), WD_LDS)) return MDIE_ELAUNCH; \
+    hipLaunchKernelGGL((conv_wide_kernel<T, ACT, POOL, STATS, NCS_, MULTI_>), dim3(grid), dim3(WD_THREADS), WD_LDS, stream, w); \
   } while (0)
-#define MDIE_WIDE_HALF(ACT)                                                                                      \
-  do {                                                                                                           \
-    static LdsOptIn opt;                                                                                         \
-    if (!opt.ensure(reinterpret_cast<const void*>(&conv_wide_kernel<T, ACT, false, false, 2>), WD_LDS)) return MDIE_ELAUNCH; \
-    hipLaunchKernelGGL((conv_wide_kernel<T, ACT, false, false, 2>), dim3(grid), dim3(WD_THREADS), WD_LDS, stream, w); \
-  } while (0)
+#define MDIE_WIDE(ACT, POOL, STATS) do { if (a.delta) MDIE_WIDE_M(ACT, POOL, STATS, 4, true); else MDIE_WIDE_M(ACT, POOL, STATS, 4, false); } while (0)
+#define MDIE_WIDE_HALF(ACT) do { if (a.delta) MDIE_WIDE_M(ACT, false, false, 2, true); else MDIE_WIDE_M(ACT, false, false, 2, false); } while (0)
   if (w.half_width) { if (a.e.act == MDIE_ACT_NONE) MDIE_WIDE_HALF(MDIE_ACT_NONE); else MDIE_WIDE_HALF(MDIE_ACT_RELU); }
   else if (a.pool_partial) MDIE_WIDE(MDIE_ACT_RELU, false, true);
   else if (a.e.pool) MDIE_WIDE(MDIE_ACT_RELU, true, false);
@@ -380,6 +385,7 @@ static int launch_wide_t(WideArgs& w, hipStream_t stream) {
   else MDIE_WIDE(MDIE_ACT_RELU, false, false);
 #undef MDIE_WIDE
 #undef MDIE_WIDE_HALF
+#undef MDIE_WIDE_M
   MDIE_LAUNCH_CHECK("mdie_conv_fwd");
   return MDIE_OK;
 }

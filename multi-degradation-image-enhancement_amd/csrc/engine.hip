@@ -465,6 +465,7 @@ struct Ctx {
   hipStream_t stream;
   size_t esz;
   const Notes* notes = nullptr;
+  const long long* delta = nullptr;   // several weight sets in one launch chain (mdie_cdan_fwd_desc.blob_delta)
 };
 
 static mdie_seg seg(const Ctx& c, const Buf& b) { return mdie_seg{c.ws + b.off, b.C, b.C}; }
@@ -492,6 +493,7 @@ static int run_conv(const Ctx& c, const char* label, int id, int H, int W, std::
   d.out_nchw3 = out_nchw3;
   d.pool_partial = pool_partial;
   d.tr = tr;
+  d.blob_delta = c.delta;
   const int rc = mdie_conv_fwd(&d, c.stream);
   if (c.notes && label && !tr) {
     const double pin = (double)H * W;
@@ -532,6 +534,7 @@ static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, con
   d.out = c.ws + out.off; d.out_stride = out.C;
   d.workspace = c.ws + P.cbam_ws; d.workspace_bytes = P.cbam_ws_bytes;
   if (pooled_slabs > 0) { d.pool_partial = reinterpret_cast<const float*>(c.ws + P.pool_ws); d.pool_slabs = pooled_slabs; }
+  d.blob_delta = c.delta;
   const int rc = mdie_cbam_fwd(&d, c.stream);
   if (c.notes) {
     static const char* const names[4] = {"bott", "cbam1", "cbam2", "cbam3"}, * const muls[4] = {"", "d3", "d2", "d1"};
@@ -676,6 +679,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   Notes notes;
   notes.lt = current_timer(); notes.esz = (double)c.esz; notes.Bn = (double)B; notes.dtype = d->dtype;
   if (notes.on()) c.notes = &notes;
+  c.delta = d->blob_delta;
   const double PX = (double)H * W;
   const int h1 = H / 2, w1 = W / 2, h2 = H / 4, w2 = W / 4, h3 = H / 8, w3 = W / 8;
   int e;
@@ -710,6 +714,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     f.post_shift = reinterpret_cast<const float*>(c.params + c.L.conv[CV_E1].post_shift);
     f.cout = 64; f.act = MDIE_ACT_RELU; f.pool = 1;
     f.out = c.ws + P.o[0].off; f.out_stride = P.o[0].C;
+    f.blob_delta = c.delta;
     const int from = notes.mark();
     RUN(mdie_conv_first_fwd(&f, stream));
     notes.conv(from, "enc.conv1+pool", CV_E1, PX, PX / 4);
@@ -753,7 +758,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   // pixel per load, twice, with an 18x18 halo) of two tensors plus 18 KB of weights per 256 pixels and sits on the vector memory
   // path (tools/stamp_gated.py: 8 k cycles to issue a tile's loads, 10 k for a round trip); what it saves in HBM bytes
   // (134 MB written + 170 MB re-read) it gives back there.  Opt-in (MDIE_FWD_FUSED_CBAM3), never with `taps`.
-  const bool fuse3 = !d->taps && (d->flags & MDIE_FWD_FUSED_CBAM3) && mdie_cbam_conv_applicable(d->dtype, h1, w1, 64, P.t4lo.C, P.t3.C, P.d[0].C, 1);
+  const bool fuse3 = !d->taps && !d->blob_delta && (d->flags & MDIE_FWD_FUSED_CBAM3) && mdie_cbam_conv_applicable(d->dtype, h1, w1, 64, P.t4lo.C, P.t3.C, P.d[0].C, 1);
   if (fuse3) {
     RUN(run_cbam_conv(c, P, CB_3, CV_D4, h1, w1, P.t3, P.d[0], P.t4lo, mdie_pool_slabs(h1, w1)));
   } else {
@@ -789,6 +794,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
       mdie_tr_fuse t0 = tr;
       t0.c0 = P.t4.C;                                       // g0 follows the base group in the transition's stored input
       if (fold_tr) u.tr = &t0;
+      u.blob_delta = c.delta;
       const int from = notes.mark();
       RUN(mdie_up_add_dense0_fwd(&u, stream));
       if (notes.on()) {
@@ -888,6 +894,7 @@ extern "C" int mdie_cdan_forward(const mdie_cdan_fwd_desc* d, void* stream) {
                "mdie_cdan_forward: H, W must be multiples of 8 (three 2x2 pools + three x2 upsamples with skip adds), got %dx%d", d->H, d->W);
   MDIE_REQUIRE(d->params && d->x && d->y && d->workspace, "mdie_cdan_forward: null pointer");
   MDIE_REQUIRE((((uintptr_t)d->params | (uintptr_t)d->workspace) & 255) == 0, "mdie_cdan_forward: params/workspace must be 256-byte aligned");
+  MDIE_REQUIRE(!d->blob_delta || !(d->flags & MDIE_FWD_FUSED_TAIL), "mdie_cdan_forward: blob_delta (several weight sets) does not combine with MDIE_FWD_FUSED_TAIL");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (!d->launch_ms) return forward_impl(d, s);
 

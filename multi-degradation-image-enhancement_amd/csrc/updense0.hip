@@ -37,6 +37,7 @@ struct UpDense0Args {
   const char* tr_w; int tr_c0;    // the transition's packed 1x1 weights; its stored input channel of g0's channel 0 (base sits at 0..2)
   const float *tr_scale, *tr_shift;   // the transition's folded BatchNorm, by its stored input channel
   float* tr_out;                  // [pixel][4] fp32: the partial sums (base term + g0 term)
+  const long long* delta;         // several weight sets in one launch (mdie_up_dense0_desc.blob_delta): per-image byte offset of every parameter pointer
 };
 
 __device__ __forceinline__ void ud_src(int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {   // = resample.hip src_index
@@ -64,7 +65,7 @@ template <> __device__ __forceinline__ f32x4 ud_mma<float>(const uint4& w, const
 }
 
 template <typename T, int BASE_CH, bool TR = false>
-__global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0Args a) {
+__global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0Args a0) {
   static_assert(!TR || sizeof(T) == 2, "the transition fusion is built for the 16-bit storage types");
   constexpr int E = sizeof(T);
   constexpr int VEC = Traits<T>::VEC;
@@ -77,11 +78,24 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
   const int tid = threadIdx.x, lane = tid & 63, lq = lane >> 4, lp = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = blockIdx.x;
-  const int tiles_x = (a.W + UD_TILE - 1) / UD_TILE, tiles_y = (a.H + UD_TILE - 1) / UD_TILE;
+  const int tiles_x = (a0.W + UD_TILE - 1) / UD_TILE, tiles_y = (a0.H + UD_TILE - 1) / UD_TILE;
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int ty = bid % tiles_y; bid /= tiles_y;
   const int img = bid;
   const int y0 = ty * UD_TILE, x0 = tx * UD_TILE;
+  UpDense0Args a = a0;
+  if (a0.delta) {   // (launch-uniform) this tile's image selects its weight set
+    const long long dl = a0.delta[img];
+    a.weight = a0.weight + dl;
+    a.pre_scale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a0.pre_scale) + dl);
+    a.pre_shift = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a0.pre_shift) + dl);
+    a.bias = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a0.bias) + dl);
+    if constexpr (TR) {
+      a.tr_w = a0.tr_w + dl;
+      a.tr_scale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a0.tr_scale) + dl);
+      a.tr_shift = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a0.tr_shift) + dl);
+    }
+  }
 
   // weight fragments and constants first: they land while the patch is computed
   uint4 wf[STEPS];
@@ -278,6 +292,7 @@ extern "C" int mdie_up_add_dense0_fwd(const mdie_up_dense0_desc* d, void* stream
   a.weight = reinterpret_cast<const char*>(d->weight);
   a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift; a.bias = d->bias;
   a.g0 = reinterpret_cast<char*>(d->g0); a.g0_stride = d->g0_stride;
+  a.delta = d->blob_delta;
   if (d->tr) {
     MDIE_REQUIRE(d->dtype != MDIE_F32 && d->base_channels == vec, "mdie_up_add_dense0_fwd: tr needs a 16-bit type with the base stored as one 16-byte group");
     MDIE_REQUIRE(d->tr->weight && d->tr->pre_scale && d->tr->pre_shift && d->tr->partial_out && d->tr->c0 >= vec && d->tr->c0 % 8 == 0 && !d->tr->out_nchw3,

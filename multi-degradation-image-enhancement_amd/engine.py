@@ -172,23 +172,18 @@ def routed_shard(labels, rank, world, tasks):
 class RoutedEngine:
     """Classifier-routed inference (BASELINE configs[3]): one weight set per degradation task
     (the reference trains one CDAN per config/*.json), every image labelled with its task by a router
-    (mdie_amd/router.py; classification/train_multilabel_classifier.py:251-253 for the thresholds).  Images are grouped by task
-    so each weight set is bound once per batch.  A group of 3-4 images cannot fill 256 CUs, so the groups run CONCURRENTLY, one
-    HIP stream per group, forked from and joined to the caller's stream with events.
+    (mdie_amd/router.py; classification/train_multilabel_classifier.py:251-253 for the thresholds).
 
-    The step is HOST-bound: nine groups are 9 x 39 kernel launches.  Round 4 measured the two obvious cures on one box
-    (tools/bench_configs.py, B = 32 at 256x256, a different grouping every batch):
-      * one hipGraph per (task, group size), fixed input / output slots, LRU cache -- 3.15 ms per batch against 2.73 ms for the
-        eager launches: hipGraphLaunch of a 39-node graph costs the host about what the 39 launches do, nine of them in a row
-        are no cheaper, and replaying several such graphs on several streams took the process down once
-        (hipGraphLaunch, gpurun_out/r04e/tests.log): not kept;
-      * the groups ENQUEUED IN PARALLEL: one host thread per group (ctypes releases the GIL inside mdie_cdan_forward; HIP takes
-        launches for different streams from different threads) -- kept, `threads`.
-    What would remove the cause -- ONE launch chain over the whole batch, every kernel looking up its image's weight set -- is
-    stated in DESIGN.md section 8 (round 4) and not built.  Results are bit-identical to per-task engines
-    (tests/test_gpu_parity.py::test_routed_*)."""
+    mode "chain" (default): ONE launch chain over the whole batch.  The task weight sets are rows of one device table; the batch is
+    ordered by task and every kernel of the chain looks up its image's row through `mdie_cdan_fwd_desc.blob_delta` (a device array of
+    byte offsets, one per image) -- 39 launches per batch whatever the grouping, the side branches on the engine's aux streams as
+    in CdanEngine.  mode "groups" (round 3 / early round 4, kept for the A/B in tools/bench_configs.py): images grouped by task, one
+    39-launch chain per group on its own stream, the groups enqueued by one host thread each (`threads`) -- host-bound at
+    9 x 39 launches; a hipGraph per (task, group size) was slower still and took the process down once (gpurun_out/r04e/tests.log).
+    Both modes are bit-identical to per-task engines (tests/test_gpu_parity.py::test_routed_*): a kernel is chosen by (layer, map)
+    alone and the several-weight-sets variants keep the arithmetic order of the plain ones."""
 
-    def __init__(self, device, precision="bf16", threads=True):
+    def __init__(self, device, precision="bf16", threads=True, mode=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.MdieError(f"RoutedEngine needs a GPU device, got {self.device} (no CPU fallback)")
@@ -198,11 +193,77 @@ class RoutedEngine:
         self._slots = None           # (capacity, H, W, x_slots, y_slots, {task: workspace}, {task: index})
         self.threads = threads
         self._pool = None
+        self.mode = mode or os.environ.get("MDIE_ROUTED_MODE", "chain")
+        if self.mode not in ("chain", "groups"):
+            raise L.MdieError(f"RoutedEngine mode {self.mode!r}: 'chain' or 'groups'")
+        self._table = None           # (rows [ntask, stride] uint8, {task: row})
+        self._ws = None
+        self._aux = C.c_void_p(0)
+        with torch.cuda.device(self.device):
+            L.check(L.lib.mdie_aux_create(C.byref(self._aux)), "mdie_aux_create")
+
+    def __del__(self):
+        try:
+            if self._aux:
+                L.lib.mdie_aux_destroy(self._aux)
+                self._aux = C.c_void_p(0)
+        except Exception:
+            pass
 
     def load_task(self, task, state_dict):
         self.blobs[task] = pack_checkpoint(state_dict, self.dtype).to(self.device)
         self._slots = None
+        self._table = None
         return self
+
+    def _weight_table(self):
+        """the task weight sets as rows of one device buffer (row stride a multiple of 256 bytes): an image's byte offset
+        from row 0 is its task's row x stride"""
+        if self._table is None:
+            tasks = sorted(self.blobs, key=str)
+            n = max(b.numel() for b in self.blobs.values())
+            if any(b.numel() != n for b in self.blobs.values()):
+                raise L.MdieError("RoutedEngine: the task weight sets differ in size (one architecture per engine)")
+            stride = (n + 255) // 256 * 256
+            rows = torch.zeros(len(tasks), stride, dtype=torch.uint8, device=self.device)
+            for i, t in enumerate(tasks):
+                rows[i, :n].copy_(self.blobs[t].view(torch.uint8).reshape(-1))
+            self._table = (rows, {t: i for i, t in enumerate(tasks)}, stride)
+        return self._table
+
+    def _chain(self, x, labels, routed):
+        """one launch chain: images ordered by task, delta[i] = row(task of image i) x stride"""
+        B, _, H, W = x.shape
+        rows, row_of, stride = self._weight_table()
+        order = sorted(routed, key=lambda i: row_of[labels[i]])
+        n = len(order)
+        nbytes = L.lib.mdie_cdan_workspace_bytes(self.dtype, n, H, W)
+        if nbytes == 0:
+            raise L.MdieError(f"unsupported input extent {n}x3x{H}x{W}: H and W must be multiples of 8")
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        # one host -> device copy carries both the order and the offsets
+        meta = torch.tensor([order, [row_of[labels[i]] * stride for i in order]], dtype=torch.int64).to(self.device, non_blocking=True)
+        identity = n == B and order == list(range(B))
+        xs = x if identity else x.index_select(0, meta[0])
+        ys = torch.empty_like(xs)
+        d = L.CdanFwdDesc()
+        d.dtype, d.B, d.H, d.W = self.dtype, n, H, W
+        d.params, d.x, d.y = rows.data_ptr(), xs.data_ptr(), ys.data_ptr()
+        d.workspace, d.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+        d.flags, d.aux = 0, self._aux
+        d.blob_delta = meta[1].data_ptr()
+        L.check(L.lib.mdie_cdan_forward(C.byref(d), _stream_ptr(self.device)), "mdie_cdan_forward")
+        self._keep = (meta, xs)          # (alive until the next call: the chain reads them asynchronously)
+        if identity:
+            return ys
+        if n == B:
+            out = torch.empty_like(x)
+        else:
+            out = x.clone()              # the router found no degradation: those images pass through unchanged
+        out.index_copy_(0, meta[0], ys)
+        return out
 
     def _ensure_slots(self, B, H, W):
         sl = self._slots
@@ -246,6 +307,10 @@ class RoutedEngine:
             raise L.MdieError(f"RoutedEngine.forward: no weights loaded for task(s) {missing}")
         B, _, H, W = x.shape
         x = x.to(torch.float32).contiguous()
+        if self.mode == "chain":
+            routed = [i for i, t in enumerate(labels) if t is not None]
+            with torch.cuda.device(self.device):
+                return self._chain(x, labels, routed) if routed else x.clone()
         with torch.cuda.device(self.device):
             cap_B, _, _, xs, ys, wss, tindex = self._ensure_slots(B, H, W)
             counts, slot, routed = {}, [], []

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 22
+ABI_VERSION = 23
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 FWD_SERIAL = 2
@@ -55,7 +55,7 @@ class ConvDesc(C.Structure):
                 ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int), ("pool", C.c_int),
                 ("residual", C.c_void_p), ("res_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int),
                 ("out_nchw3", C.c_void_p), ("pool_partial", C.c_void_p), ("tr", C.POINTER(TrFuse)), ("out_group_stride", C.c_long),
-                ("bnred", C.POINTER(BnReduceFuse))]
+                ("bnred", C.POINTER(BnReduceFuse)), ("blob_delta", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -135,14 +135,14 @@ class LossTerm(C.Structure):
 class ConvFirstDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("x", C.c_void_p),
                 ("weight", C.c_void_p), ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("cout", C.c_int),
-                ("act", C.c_int), ("pool", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int)]
+                ("act", C.c_int), ("pool", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int), ("blob_delta", C.c_void_p)]
 
 
 class UpDense0Desc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("lo", C.c_void_p), ("lo_stride", C.c_int),
                 ("x", C.c_void_p), ("base", C.c_void_p), ("base_channels", C.c_int), ("weight", C.c_void_p),
                 ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("bias", C.c_void_p), ("g0", C.c_void_p), ("g0_stride", C.c_int),
-                ("tr", C.POINTER(TrFuse))]
+                ("tr", C.POINTER(TrFuse)), ("blob_delta", C.c_void_p)]
 
 
 class CbamDesc(C.Structure):
@@ -153,7 +153,7 @@ class CbamDesc(C.Structure):
                 ("mul", C.c_void_p), ("mul_stride", C.c_int),
                 ("out", C.c_void_p), ("out_stride", C.c_int),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("pool_partial", C.c_void_p), ("pool_slabs", C.c_int)]
+                ("pool_partial", C.c_void_p), ("pool_slabs", C.c_int), ("blob_delta", C.c_void_p)]
 
 
 class CbamConvDesc(C.Structure):
@@ -190,7 +190,7 @@ class CdanFwdDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("taps", C.POINTER(Tap)), ("flags", C.c_int), ("aux", C.c_void_p),
                 ("launch_ms", C.POINTER(C.c_float)), ("launch_kind", C.POINTER(C.c_int)),
-                ("max_launches", C.c_int), ("n_launches", C.POINTER(C.c_int)), ("launch_info", C.POINTER(LaunchInfo))]
+                ("max_launches", C.c_int), ("n_launches", C.POINTER(C.c_int)), ("launch_info", C.POINTER(LaunchInfo)), ("blob_delta", C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list every function include/mdie.h declares

@@ -191,5 +191,5 @@ def test_shipped_code_objects_pass_the_isa_guard():
     assert not isa_guard.vgpr_swizzle("v_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[8:9]") and not isa_guard.vgpr_swizzle("v_pk_mul_f32 v[2:3], v[4:5], 1.0 op_sel_hi:[1,0]")
     bad = isa_guard.violations(rows)
     assert not bad, [(r["pretty"], r["pk_sel"][:2]) for r in bad]
-    spills = [r["pretty"] for r in rows if r["scratch"]]
+    spills = [(r["pretty"], r["scratch"], r["scratch_hot"]) for r in isa_guard.spills(rows)]     # (one documented exception: isa_guard.spills)
     assert not spills, spills

@@ -1556,23 +1556,33 @@ def test_cbam_module_train_mode(E):
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[3] (routed mixed degradations) and configs[4] (1024x1024, batch 1)
 # ---------------------------------------------------------------------------------------------------------------------
-def test_routed_inference_matches_per_task_engines(E):
-    """images grouped by task label run with that task's weights; the result is bitwise what a dedicated engine returns
-    for the same image (batch independence), in the caller's order"""
+@pytest.mark.parametrize("mode,prec,hw", [("chain", "bf16", (32, 40)), ("chain", "fp16", (64, 64)), ("chain", "fp32", (32, 40)),
+                                          ("chain", "bf16", (128, 192)), ("groups", "bf16", (32, 40))])
+def test_routed_inference_matches_per_task_engines(E, mode, prec, hw):
+    """images labelled with a task run with that task's weights -- as ONE launch chain whose kernels look up each image's
+    weight set ("chain"), or grouped by task ("groups"); the result is bitwise what a dedicated engine returns for the same
+    image (batch independence), in the caller's order; unlabelled images pass through"""
     from oracle import params as P
     tasks = {"noise": 11, "blur": 12, "low_light": 13}
-    routed = E.RoutedEngine("cuda", "bf16")
+    routed = E.RoutedEngine("cuda", prec, mode=mode)
     single = {}
     for t, seed in tasks.items():
         sd = P.make_state_dict(seed)
         routed.load_task(t, sd)
-        single[t] = E.CdanEngine("cuda", "bf16").load(sd)
-    x, _ = P.lowlight_batch(9, 7, 32, 40)
+        single[t] = E.CdanEngine("cuda", prec).load(sd)
+    x, _ = P.lowlight_batch(9, 7, *hw)
     x = x.cuda()
     labels = ["blur", "noise", "blur", "low_light", "noise", "noise", "blur"]
     y = routed.forward(x, labels)
     for i, t in enumerate(labels):
         assert torch.equal(y[i], single[t].forward(x[i:i + 1])[0]), (i, t)
+    some = ["blur", None, "low_light", None, None, "noise", "blur"]
+    y2 = routed.forward(x, some)
+    for i, t in enumerate(some):
+        assert torch.equal(y2[i], x[i] if t is None else y[i] if t == labels[i] else single[t].forward(x[i:i + 1])[0]), (i, t)
+    assert torch.equal(routed.forward(x, [None] * 7), x)
+    one = routed.forward(x, ["noise"] * 7)                # a single weight set through the several-sets kernels
+    assert torch.equal(one, single["noise"].forward(x))
     with pytest.raises(Exception):
         routed.forward(x, ["jpeg"] * 7)
     with pytest.raises(Exception):
@@ -1630,15 +1640,15 @@ def test_training_steps_in_flight_match_serial_steps():
             assert all(torch.equal(a, b) for a, b in zip(grads(k), ref[k][1])), (rep, k)
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp16"])
-def test_routed_groups_in_flight_match_serial_groups(E, prec):
+@pytest.mark.parametrize("prec,mode", [("bf16", "chain"), ("fp16", "chain"), ("bf16", "groups"), ("fp16", "groups")])
+def test_routed_groups_in_flight_match_serial_groups(E, prec, mode):
     """BASELINE configs[3] at size: 32 images of 256x256, 9 tasks, the task groups running concurrently on their own streams
     (RoutedEngine), ten times -- every group's output must equal, bit for bit, what a dedicated engine returns for the same
     group run alone (same batch size, so the same kernels).  The concurrency counterpart of
     test_engines_in_flight_on_different_inputs for the routed path: different weights AND different inputs side by side."""
     from oracle import params as P
     tasks = [f"t{i}" for i in range(9)]
-    routed = E.RoutedEngine("cuda", prec)
+    routed = E.RoutedEngine("cuda", prec, mode=mode)
     sds = {t: P.make_state_dict(20 + i) for i, t in enumerate(tasks)}
     for t in tasks:
         routed.load_task(t, sds[t])
