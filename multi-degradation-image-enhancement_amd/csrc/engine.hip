@@ -470,9 +470,30 @@ struct Ctx {
 
 static mdie_seg seg(const Ctx& c, const Buf& b) { return mdie_seg{c.ws + b.off, b.C, b.C}; }
 
+// Diagnostic build only (-DEXP_ABLATE, tools/ablate.sh): MDIE_ABLATE = comma-separated label prefixes whose launches are LEFT OUT
+// (results are garbage; the step time without a stage is what the stage costs the step, as opposed to its serial time).
+#ifdef EXP_ABLATE
+static bool ablated(const char* label) {
+  const char* e = getenv("MDIE_ABLATE");
+  if (!e || !label) return false;
+  const size_t n = strlen(label);
+  for (const char* p = e; *p;) {
+    const char* q = strchr(p, ',');
+    const size_t k = q ? (size_t)(q - p) : strlen(p);
+    if (k > 0 && k <= n && strncmp(p, label, k) == 0) return true;
+    if (!q) break;
+    p = q + 1;
+  }
+  return false;
+}
+#else
+static inline bool ablated(const char*) { return false; }
+#endif
+
 static int run_conv(const Ctx& c, const char* label, int id, int H, int W, std::initializer_list<Buf> in, const Buf& out, int act, int pool,
                     const Buf* residual, float* out_nchw3 = nullptr, float* pool_partial = nullptr, const mdie_tr_fuse* tr = nullptr) {
   const ConvSpec& s = arch(c.dtype).conv[id];
+  if (ablated(label)) return MDIE_OK;
   const int from = c.notes ? c.notes->mark() : 0;
   mdie_conv_desc d{};
   d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.ksize = s.ks;
@@ -522,6 +543,7 @@ static int run_dense(const Ctx& c, int block, int H, int W, const Buf& base, con
 static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, const Buf& x, const Buf* mul, const Buf& out,
                           int pooled_slabs = 0) {
   const CbamBlob& o = c.L.cbam[id];
+  { static const char* const nm[4] = {"bott", "cbam1", "cbam2", "cbam3"}; if (id >= 0 && id < 4 && ablated(nm[id])) return MDIE_OK; }
   const int from = c.notes ? c.notes->mark() : 0;
   mdie_cbam_desc d{};
   d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.C = arch(c.dtype).cbam[id].C;
@@ -577,6 +599,7 @@ static int run_cbam_conv(const Ctx& c, const Plan& P, int id, int conv_id, int H
 
 static int run_up(const Ctx& c, const Plan& P, const char* label, int H, int W, const Buf& lo, const Buf& skip, const Buf& out) {
   // the upsampled + skip tensor feeds a CBAM: reduce it for the channel gate while writing it
+  if (ablated(label)) return MDIE_OK;
   const int from = c.notes ? c.notes->mark() : 0;
   const int rc = mdie_upsample2x_add_pool(c.dtype, c.B, H, W, lo.C, c.ws + lo.off, lo.C, c.ws + skip.off, skip.C, c.ws + out.off, out.C,
                                           reinterpret_cast<float*>(c.ws + P.pool_ws), mdie_pool_slabs(2 * H, 2 * W), c.stream);
@@ -716,7 +739,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     f.out = c.ws + P.o[0].off; f.out_stride = P.o[0].C;
     f.blob_delta = c.delta;
     const int from = notes.mark();
-    RUN(mdie_conv_first_fwd(&f, stream));
+    if (!ablated("enc.conv1")) RUN(mdie_conv_first_fwd(&f, stream));
     notes.conv(from, "enc.conv1+pool", CV_E1, PX, PX / 4);
   }
   // WHERE the side branches start (round 3, same-box sweep over fork points, eager launches, B = 32 at 256x256): forking each block
@@ -796,7 +819,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
       if (fold_tr) u.tr = &t0;
       u.blob_delta = c.delta;
       const int from = notes.mark();
-      RUN(mdie_up_add_dense0_fwd(&u, stream));
+      if (!ablated("final.l0")) RUN(mdie_up_add_dense0_fwd(&u, stream));
       if (notes.on()) {
         // upsample + x (read lo, read x, the sum written once as the block's base), layer 0 (reads the base, writes g0); folded: + the
         // transition's terms of the base and of g0
@@ -820,6 +843,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
       for (int l = 1; l <= 3; ++l) {
         const int from = notes.mark();
         const mdie_tr_fuse* tl = l == 1 ? &t1 : l == 2 ? &t2 : &t3;
+        { static const char* const an[4] = {"", "final.l1", "final.l2", "final.l3"}; if (ablated(an[l])) continue; }
         if (l == 1) RUN(run_conv(c, nullptr, id0 + 1, H, W, {P.t4, P.fg[0]}, P.fg[1], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, tl));
         else if (l == 2) RUN(run_conv(c, nullptr, id0 + 2, H, W, {P.t4, P.fg[0], P.fg[1]}, P.fg[2], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, tl));
         else RUN(run_conv(c, nullptr, id0 + 3, H, W, {P.t4, P.fg[0], P.fg[1], P.fg[2]}, P.fg[3], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, tl));
