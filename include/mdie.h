@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 23
+#define MDIE_ABI_VERSION 24
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1,
        MDIE_F16 = 2 /* IEEE half: the reference's mixed-precision dtype (torch.cuda.amp.autocast, models/model.py:15,159) */ };
@@ -54,7 +54,11 @@ enum {
 typedef struct {
   const void* ptr;  /* first element of pixel (0,0,0) */
   int channels;     /* whole 16-byte groups: multiple of 8 (bf16) / 4 (f32); multiple of 16 for the training kernels */
-  int stride;       /* elements between consecutive pixels */
+  int stride;       /* elements between consecutive pixels (>= channels).  One exception, 16-bit types, a mdie_conv_desc that carries
+                       `tr` (decoder.final_dense's folded chain): channels == 8 with stride == 4 -- a HALF group: 4 stored channels
+                       per pixel (the block's 3-channel base), read with the group's 16-byte load whose upper half is the next
+                       pixel's bytes; the weights of channels 4..7 must be zero (they are: the base has 3 real channels) and the
+                       buffer readable 8 bytes past its last pixel.  Halves the base's bytes in all four launches of the chain. */
 } mdie_seg;
 
 /* ---------------------------------------------------------------------------------
@@ -373,6 +377,8 @@ typedef struct {
   const void* lo; int lo_stride;
   const float* x;              /* fp32 NCHW [B,3,H,W] */
   void* base; int base_channels;
+  int base_stride;             /* elements between consecutive pixels of `base`; 0 = base_channels.  With `tr` (16-bit types) 4 is
+                                  accepted for base_channels == 8: only the first 4 channels of the group are stored (mdie_seg) */
   const void* weight;
   const float* pre_scale; const float* pre_shift;   /* >= 3 entries */
   const float* bias;           /* [16] */

@@ -203,7 +203,7 @@ static bool bn_fold(const TensorMap& T, const std::string& p, int c, std::vector
 }
 
 // ---- workspace plan ---------------------------------------------------------------------------------------------------
-struct Buf { size_t off; int C; };  // NHWC, stride == C
+struct Buf { size_t off; int C; int st = 0; };  // NHWC, C stored channels, pixel stride st (0: == C)
 struct Plan {
   Buf x16, o[3], g[3][4], d[3], e, bott, t1, u1, t2lo, t2, u2, t3lo, t3, u3, t4lo, t4, fg[4], out16;
   size_t cbam_ws, cbam_ws_bytes;
@@ -468,7 +468,7 @@ struct Ctx {
   const long long* delta = nullptr;   // several weight sets in one launch chain (mdie_cdan_fwd_desc.blob_delta)
 };
 
-static mdie_seg seg(const Ctx& c, const Buf& b) { return mdie_seg{c.ws + b.off, b.C, b.C}; }
+static mdie_seg seg(const Ctx& c, const Buf& b) { return mdie_seg{c.ws + b.off, b.C, b.st ? b.st : b.C}; }
 
 // Diagnostic build only (-DEXP_ABLATE, tools/ablate.sh): MDIE_ABLATE = comma-separated label prefixes whose launches are LEFT OUT
 // (results are garbage; the step time without a stage is what the stage costs the step, as opposed to its serial time).
@@ -788,6 +788,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3, mdie_pool_slabs(h1, w1)));
     RUN(run_conv(c, "dec.conv4", CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
   }
+  bool half_base = false;
   if (!(d->flags & MDIE_FWD_FUSED_TAIL)) {
     // bilinear x2 + x (x read from its fp32 NCHW planes), final_dense, sigmoid written straight to NCHW
     // upsample + x and final_dense layer 0 in one launch (csrc/updense0.hip); then layers 1..3 and the transition.
@@ -798,6 +799,12 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     // depend on what it is batched with.  Everything else (fp32, ragged extents) runs the general chain.
     const int id0 = CV_DENSE0 + 3 * 5;
     const bool fold_tr = !(d->flags & MDIE_FWD_GENERAL_TAIL) && d->dtype != MDIE_F32 && H % 16 == 0 && W % 16 == 0 && (size_t)W * 20 < ((size_t)1 << 24) && (size_t)H * W * 16 < ((size_t)1 << 32);
+    // the block's base has 3 real channels: in the folded chain it is stored as HALF a 16-byte group (4 channels, 8 bytes per pixel;
+    // mdie_seg) -- written once and read by three launches with an 18x18 halo, 38 of the chain's ~470 bytes per pixel
+    Buf t4 = P.t4;
+#ifndef EXP_FULL_BASE   // (A/B builds only: the base as a whole 16-byte group)
+    if (fold_tr && t4.C == 8) { t4.st = 4; half_base = true; }
+#endif
     mdie_tr_fuse tr{};
     tr.weight = c.params + c.L.conv[id0 + 4].w;
     tr.pre_scale = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + 4].pre_scale);
@@ -808,7 +815,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
       mdie_up_dense0_desc u{};
       u.dtype = d->dtype; u.B = B; u.H = H; u.W = W;
       u.lo = c.ws + P.t4lo.off; u.lo_stride = P.t4lo.C; u.x = d->x;
-      u.base = c.ws + P.t4.off; u.base_channels = P.t4.C;
+      u.base = c.ws + t4.off; u.base_channels = t4.C; u.base_stride = t4.st;
       u.weight = c.params + c.L.fl0_w;
       u.pre_scale = reinterpret_cast<const float*>(c.params + c.L.conv[id0].pre_scale);
       u.pre_shift = reinterpret_cast<const float*>(c.params + c.L.conv[id0].pre_shift);
@@ -844,9 +851,9 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
         const int from = notes.mark();
         const mdie_tr_fuse* tl = l == 1 ? &t1 : l == 2 ? &t2 : &t3;
         { static const char* const an[4] = {"", "final.l1", "final.l2", "final.l3"}; if (ablated(an[l])) continue; }
-        if (l == 1) RUN(run_conv(c, nullptr, id0 + 1, H, W, {P.t4, P.fg[0]}, P.fg[1], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, tl));
-        else if (l == 2) RUN(run_conv(c, nullptr, id0 + 2, H, W, {P.t4, P.fg[0], P.fg[1]}, P.fg[2], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, tl));
-        else RUN(run_conv(c, nullptr, id0 + 3, H, W, {P.t4, P.fg[0], P.fg[1], P.fg[2]}, P.fg[3], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, tl));
+        if (l == 1) RUN(run_conv(c, nullptr, id0 + 1, H, W, {t4, P.fg[0]}, P.fg[1], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, tl));
+        else if (l == 2) RUN(run_conv(c, nullptr, id0 + 2, H, W, {t4, P.fg[0], P.fg[1]}, P.fg[2], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, tl));
+        else RUN(run_conv(c, nullptr, id0 + 3, H, W, {t4, P.fg[0], P.fg[1], P.fg[2]}, P.fg[3], MDIE_ACT_NONE, 0, nullptr, nullptr, nullptr, tl));
         if (notes.on()) {
           const double cin = 3 + 16.0 * l;
           static const char* const nm[4] = {"", "final.l1+tr", "final.l2+tr", "final.l3+tr+sigmoid->nchw"};
@@ -878,6 +885,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     tap(MDIE_TAP_ENC, P.e, h3, w3); tap(MDIE_TAP_BOTT, P.bott, h3, w3);
     tap(MDIE_TAP_DEC1, P.u1, h3, w3); tap(MDIE_TAP_DEC2, P.u2, h2, w2); tap(MDIE_TAP_DEC3, P.u3, h1, w1);
     tap(MDIE_TAP_DEC4, P.t4, H, W);
+    if (half_base) d->taps[MDIE_TAP_DEC4] = mdie_tap{c.ws + P.t4.off, 4, 4, H, W};   // (the folded chain stores 4 of the base group's 8 channels)
     if (d->flags & MDIE_FWD_FUSED_TAIL) d->taps[MDIE_TAP_DEC4].ptr = nullptr;  // never materialised when fused
   }
   return MDIE_OK;

@@ -64,7 +64,8 @@ template <> __device__ __forceinline__ f32x4 ud_mma<float>(const uint4& w, const
   return acc;
 }
 
-template <typename T, int BASE_CH, bool TR = false>
+// BASE_ST: stored channels per pixel of `base` (= BASE_CH, or 4 of the 8-channel group: the half-group form of mdie_seg)
+template <typename T, int BASE_CH, bool TR = false, int BASE_ST = BASE_CH>
 __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0Args a0) {
   static_assert(!TR || sizeof(T) == 2, "the transition fusion is built for the 16-bit storage types");
   constexpr int E = sizeof(T);
@@ -178,9 +179,15 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
         float o[BASE_CH];
 #pragma unroll
         for (int c = 0; c < BASE_CH; ++c) o[c] = c < 3 ? f[c] : 0.f;
-        uint4* dst = reinterpret_cast<uint4*>(a.base + (size_t)img * plane * (BASE_CH * E) + (__umul24(y0 + py - 1, a.W) + (x0 + px - 1)) * (unsigned)(BASE_CH * E));
+        char* const dstb = a.base + (size_t)img * plane * (BASE_ST * E) + (__umul24(y0 + py - 1, a.W) + (x0 + px - 1)) * (unsigned)(BASE_ST * E);
+        if constexpr (BASE_ST == BASE_CH) {
+          uint4* dst = reinterpret_cast<uint4*>(dstb);
 #pragma unroll
-        for (int v = 0; v < BASE_CH / VEC; ++v) dst[v] = Vec16<T>::pack(o + v * VEC);
+          for (int v = 0; v < BASE_CH / VEC; ++v) dst[v] = Vec16<T>::pack(o + v * VEC);
+        } else {   // half group (16-bit types): the 3 real channels and one zero, 8 bytes per pixel
+          static_assert(E == 2 && BASE_ST == 4 && BASE_CH == 8, "half-group base: 16-bit types, 4 of 8 channels");
+          *reinterpret_cast<uint2*>(dstb) = make_uint2(Half<T>::pack(o[0], o[1]), Half<T>::pack(o[2], 0.f));
+        }
         if constexpr (TR) {   // the transition's pre-activation of the stored base (f[] is already rounded to T)
           const float t0 = fmaxf(fmaf(f[0], tbs[0], tbb[0]), 0.f), t1 = fmaxf(fmaf(f[1], tbs[1], tbb[1]), 0.f), t2 = fmaxf(fmaf(f[2], tbs[2], tbb[2]), 0.f);
           *reinterpret_cast<uint2*>(trpatch + ((py - 1) * UD_TILE + (px - 1)) * 4) = make_uint2(Half<T>::pack(t0, t1), Half<T>::pack(t2, 0.f));
@@ -279,6 +286,10 @@ extern "C" int mdie_up_add_dense0_fwd(const mdie_up_dense0_desc* d, void* stream
   MDIE_REQUIRE(d->lo_stride >= 4 && d->lo_stride % 4 == 0 && ((uintptr_t)d->lo & 15) == 0,
                "mdie_up_add_dense0_fwd: lo must be 16-byte aligned with a pixel stride that is a multiple of 4 channels (%d)", d->lo_stride);
   MDIE_REQUIRE(d->base_channels == 16 || d->base_channels == vec, "mdie_up_add_dense0_fwd: base_channels %d (16 or %d)", d->base_channels, vec);
+  const int base_stride = d->base_stride ? d->base_stride : d->base_channels;
+  MDIE_REQUIRE(base_stride == d->base_channels || (d->tr && d->dtype != MDIE_F32 && d->base_channels == 8 && base_stride == 4),
+               "mdie_up_add_dense0_fwd: base_stride %d (base_channels %d; 4 of 8 only for the 16-bit types with tr)", base_stride, d->base_channels);
+  MDIE_REQUIRE(((uintptr_t)d->base & 15) == 0, "mdie_up_add_dense0_fwd: base must be 16-byte aligned");
   MDIE_REQUIRE(d->g0_stride >= 16 && d->g0_stride % 4 == 0 && (((uintptr_t)d->g0 | (uintptr_t)d->base | (uintptr_t)d->weight) & 15) == 0,
                "mdie_up_add_dense0_fwd: g0_stride %d / alignment", d->g0_stride);
   MDIE_REQUIRE((size_t)d->H * d->W < ((size_t)1 << 24) && (size_t)d->H * d->W * (size_t)std::max(d->g0_stride, 16) * dtype_size(d->dtype) < ((size_t)1 << 32) &&
@@ -305,8 +316,13 @@ extern "C" int mdie_up_add_dense0_fwd(const mdie_up_dense0_desc* d, void* stream
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   TimedLaunch tl(MDIE_K_CONV3);
   if (d->tr) {
-    if (d->dtype == MDIE_BF16) hipLaunchKernelGGL((up_dense0_kernel<bf16, 8, true>), dim3(grid), dim3(UD_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((up_dense0_kernel<f16, 8, true>), dim3(grid), dim3(UD_THREADS), 0, s, a);
+    if (base_stride == 4) {
+      if (d->dtype == MDIE_BF16) hipLaunchKernelGGL((up_dense0_kernel<bf16, 8, true, 4>), dim3(grid), dim3(UD_THREADS), 0, s, a);
+      else hipLaunchKernelGGL((up_dense0_kernel<f16, 8, true, 4>), dim3(grid), dim3(UD_THREADS), 0, s, a);
+    } else {
+      if (d->dtype == MDIE_BF16) hipLaunchKernelGGL((up_dense0_kernel<bf16, 8, true>), dim3(grid), dim3(UD_THREADS), 0, s, a);
+      else hipLaunchKernelGGL((up_dense0_kernel<f16, 8, true>), dim3(grid), dim3(UD_THREADS), 0, s, a);
+    }
   } else
   MDIE_SWITCH_T(d->dtype,
     if (d->base_channels == 16) hipLaunchKernelGGL((up_dense0_kernel<T, 16>), dim3(grid), dim3(UD_THREADS), 0, s, a);

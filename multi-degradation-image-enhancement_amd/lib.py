@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 23
+ABI_VERSION = 24
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_FUSED_TAIL = 1
 FWD_SERIAL = 2
@@ -140,7 +140,7 @@ class ConvFirstDesc(C.Structure):
 
 class UpDense0Desc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("lo", C.c_void_p), ("lo_stride", C.c_int),
-                ("x", C.c_void_p), ("base", C.c_void_p), ("base_channels", C.c_int), ("weight", C.c_void_p),
+                ("x", C.c_void_p), ("base", C.c_void_p), ("base_channels", C.c_int), ("base_stride", C.c_int), ("weight", C.c_void_p),
                 ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("bias", C.c_void_p), ("g0", C.c_void_p), ("g0_stride", C.c_int),
                 ("tr", C.POINTER(TrFuse)), ("blob_delta", C.c_void_p)]
 
