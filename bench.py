@@ -134,7 +134,7 @@ def routed_main(args, rank, world, dev, dist, P):
     batches = []
     for k in range(n_lists):
         labels = routed_labels(k, B)
-        idx = list(range(rank * args.batch, (rank + 1) * args.batch)) if mode == "chain" else E.routed_shard(labels, rank, world, ROUTED_TASKS)
+        idx = E.routed_slice(B, rank, world) if mode == "chain" else E.routed_shard(labels, rank, world, ROUTED_TASKS)
         batches.append((x_all[idx].to(dev), [labels[i] for i in idx]))
     it = [0]
 

@@ -169,6 +169,14 @@ def routed_shard(labels, rank, world, tasks):
     return mine
 
 
+def routed_slice(n, rank, world):
+    """which images of a routed batch of n a rank runs in chain mode: every rank holds all the weight sets, so the batch is cut into
+    `world` contiguous slices whose sizes differ by at most one -- whatever the labels; no collective is involved."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return list(range(lo, lo + q + (1 if rank < r else 0)))
+
+
 class RoutedEngine:
     """Classifier-routed inference (BASELINE configs[3]): one weight set per degradation task
     (the reference trains one CDAN per config/*.json), every image labelled with its task by a router

@@ -241,7 +241,7 @@ def _routed_worker(rank, world, port, q):
     mine = E.routed_shard(labels, rank, world, bench.ROUTED_TASKS)
     tasks = sorted({labels[i] for i in mine if labels[i] is not None})
     gathered = [None] * world
-    dist.all_gather_object(gathered, (mine, tasks))
+    dist.all_gather_object(gathered, (mine, tasks, E.routed_slice(65, rank, world)))
     t = bench.max_over_ranks(0.5 + rank, dist, "cpu")
     q.put((rank, gathered, t))
     dist.barrier()
@@ -263,7 +263,8 @@ def test_routed_batch_is_dealt_by_task_two_ranks():
         p.join(60)
         assert p.exitcode == 0
     for rank, gathered, t in res:
-        (m0, t0), (m1, t1) = gathered
+        (m0, t0, s0), (m1, t1, s1) = gathered
         assert sorted(m0 + m1) == list(range(64)) and not set(m0) & set(m1)
         assert not set(t0) & set(t1) and len(t0) + len(t1) == 9
+        assert s0 + s1 == list(range(65)) and abs(len(s0) - len(s1)) <= 1     # chain mode: equal contiguous slices, labels play no part
         assert t == 1.5

@@ -184,7 +184,7 @@ def test_full_batch_properties(E, net, precision):
     image of the batch must equal the same image run alone, bit for bit, and a repeated
     run must be bitwise identical (no atomics on the path)."""
     from oracle import params as P
-    B = 32 if precision == "bf16" else 8   # (bf16 = BASELINE configs[1] itself; the others at a quarter of the batch)
+    B = 32                                  # BASELINE configs[1] itself, in every storage type
     x, _ = P.lowlight_batch(3, B, 256, 256)
     x = x.cuda()
     net.precision = precision
@@ -200,7 +200,7 @@ def test_full_batch_properties(E, net, precision):
 
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_every_image_is_independent_of_its_batch_at_every_stage(E, precision):
-    """Bitwise batch independence, all of it: the batch of 32 at 256x256 (16 for fp32) cut into sub-batches of 8, 4 and 1
+    """Bitwise batch independence, all of it: the batch of 32 at 256x256 (every storage type) cut into sub-batches of 8, 4 and 1
     at EVERY position -- each sub-batch through an engine of its own -- must reproduce its images of the whole batch bit for bit
     in the output and in every stage tap.  (Round 3 found images 16 and 28 of this very batch one bf16 ulp apart, in ONE
     element of the bottleneck CBAM's output, between a batch of 32 and a batch of 8: the tile edge of the pooling partials
@@ -210,7 +210,7 @@ def test_every_image_is_independent_of_its_batch_at_every_stage(E, precision):
     from oracle import params as P
     dev = torch.device("cuda", 0)
     sd = P.make_state_dict(42)
-    B = 16 if precision == "fp32" else 32
+    B = 32
     x = P.lowlight_batch(1, B, 256, 256)[0].to(dev)
     with torch.no_grad():
         whole = EG.CdanEngine(dev, precision).load(sd)
