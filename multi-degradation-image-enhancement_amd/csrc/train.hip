@@ -163,7 +163,11 @@ template <> __device__ __forceinline__ f32x4 mma_tr<f16>(const v8s& a, const v8s
 }
 
 // waves are arranged WC x WO; each owns CSW x OSW 16x16 subtiles of every tap; T = bf16 or f16 (same layouts, other MFMA)
-template <typename T, int NTAP, int CSW, int OSW, int WC, int WO, bool PRE>
+// PF (the thin configurations, one subtile pair per wave: 36 accumulator registers): the NEXT tile's X patch and dY tile are requested
+// into registers right after the barrier and land under this tile's MFMAs; without it a tile is "load, wait, stage, barrier, MFMA" in
+// sequence -- two exposed memory round trips per tile for the 64-channel patch (11 staging iterations in batches of 6), hidden only by
+// the CU's second workgroup.  The sums are formed in the same order either way.
+template <typename T, int NTAP, int CSW, int OSW, int WC, int WO, bool PRE, bool PF = false>
 __global__ __launch_bounds__(TR_THREADS, 2) void wgrad_tile_kernel(const WgradTileArgs a) {
   using G = WgGeom<NTAP>;
   constexpr int KS = NTAP == 9 ? 3 : 1;
@@ -220,6 +224,71 @@ __global__ __launch_bounds__(TR_THREADS, 2) void wgrad_tile_kernel(const WgradTi
 
   const int t_begin = split * a.tiles_per_split, t_end = min(t_begin + a.tiles_per_split, a.total_tiles);
   const int tpi = a.tiles_x * a.tiles_y;
+
+  // ---- PF: the tile in flight (registers) ----
+  uint4 xv[PF ? X_IT : 1], yv[PF ? Y_IT : 1];
+  unsigned xokm = 0;
+  auto issue_tile = [&](int tile) {
+    const int img = tile / tpi;
+    const int trem = tile - img * tpi;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int y0 = ty * WT, x0 = tx * WT;
+    const size_t ibase = (size_t)img * a.H * a.W;
+    int pix = tid / UPX;
+    int py = pix / G::PWD, px = pix - py * G::PWD;
+    xokm = 0;
+#pragma unroll
+    for (int it = 0; it < (PF ? X_IT : 0); ++it) {
+      const int gy = y0 + py - G::PAD, gx = x0 + px - G::PAD;
+      const bool ok = py < G::PWD && xbase != nullptr && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      xv[it] = make_uint4(0, 0, 0, 0);
+      if (ok) xv[it] = *reinterpret_cast<const uint4*>(xbase + (ibase + (size_t)gy * a.W + gx) * xstride);
+      xokm |= ok ? 1u << it : 0u;
+      px += X_PPI % G::PWD; py += X_PPI / G::PWD;
+      if (px >= G::PWD) { px -= G::PWD; py += 1; }
+    }
+    pix = tid / UPY;
+#pragma unroll
+    for (int it = 0; it < (PF ? Y_IT : 0); ++it) {
+      const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
+      yv[it] = make_uint4(0, 0, 0, 0);
+      if (pix < WT * WT && ylive && gy < a.H && gx < a.W) yv[it] = *reinterpret_cast<const uint4*>(ybase + (ibase + (size_t)gy * a.W + gx) * a.dy_stride * 2);
+      pix += Y_PPI;
+    }
+  };
+  auto commit_tile = [&]() {   // pre-activation and the LDS images of the tile in flight
+    float psc[8], psh[8];
+    if (has_pre) {
+      const float4 s0 = *reinterpret_cast<const float4*>(a.pre_scale + c0 + xchunk * 8), s1 = *reinterpret_cast<const float4*>(a.pre_scale + c0 + xchunk * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(a.pre_shift + c0 + xchunk * 8), b1 = *reinterpret_cast<const float4*>(a.pre_shift + c0 + xchunk * 8 + 4);
+      psc[0] = s0.x; psc[1] = s0.y; psc[2] = s0.z; psc[3] = s0.w; psc[4] = s1.x; psc[5] = s1.y; psc[6] = s1.z; psc[7] = s1.w;
+      psh[0] = b0.x; psh[1] = b0.y; psh[2] = b0.z; psh[3] = b0.w; psh[4] = b1.x; psh[5] = b1.y; psh[6] = b1.z; psh[7] = b1.w;
+    }
+    int pix = tid / UPX;
+    int py = pix / G::PWD, px = pix - py * G::PWD;
+#pragma unroll
+    for (int it = 0; it < (PF ? X_IT : 0); ++it) {
+      uint4 v = xv[it];
+      if (has_pre && ((xokm >> it) & 1u)) {   // pre-activation BN + ReLU of the dense layers; the zero padding stays zero
+        float f[8];
+        Vec16<T>::unpack(v, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = fmaxf(fmaf(f[i], psc[i], psh[i]), 0.f);
+        v = Vec16<T>::pack(f);
+      }
+      if (py < G::PWD) *reinterpret_cast<uint4*>(lds_x + xdst0 + (py * G::PWD + px) * 32) = v;
+      px += X_PPI % G::PWD; py += X_PPI / G::PWD;
+      if (px >= G::PWD) { px -= G::PWD; py += 1; }
+    }
+    pix = tid / UPY;
+#pragma unroll
+    for (int it = 0; it < (PF ? Y_IT : 0); ++it) {
+      if (pix < WT * WT) *reinterpret_cast<uint4*>(lds_y + ydst0 + pix * 32) = yv[it];
+      pix += Y_PPI;
+    }
+  };
+  if constexpr (PF) { if (t_begin < t_end) issue_tile(t_begin); }
+
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int img = tile / tpi;
     const int trem = tile - img * tpi;
@@ -228,6 +297,11 @@ __global__ __launch_bounds__(TR_THREADS, 2) void wgrad_tile_kernel(const WgradTi
     const size_t ibase = (size_t)img * a.H * a.W;
 
     if (tile > t_begin) __syncthreads();   // the previous tile's fragment reads are done
+    if constexpr (PF) {
+      commit_tile();
+      __syncthreads();
+      if (tile + 1 < t_end) issue_tile(tile + 1);   // (workgroup-uniform)
+    } else {
     // ---- stage X patch: unit u = tid + it*256 -> patch pixel u / UPX (in batches, to bound the registers in flight) ----
     {
       int pix = tid / UPX;
@@ -290,6 +364,7 @@ __global__ __launch_bounds__(TR_THREADS, 2) void wgrad_tile_kernel(const WgradTi
       }
     }
     __syncthreads();
+    }   // (!PF)
 
     if (wave_live) {   // wave-uniform: EXEC stays all ones around the transposing reads
 #pragma unroll WG_KUNROLL
@@ -534,7 +609,12 @@ template <typename T, int NTAP, int CSW, int OSW, int WC, int WO, bool PRE>
 static void launch_wgrad_tile_t(const WgradTileArgs& a, const WgTilePlan& p, hipStream_t s) {
   using G = WgGeom<NTAP>;
   const size_t lds = (size_t)CSW * WC * G::XPLANE + (size_t)OSW * WO * G::YPLANE;
-  auto kern = wgrad_tile_kernel<T, NTAP, CSW, OSW, WC, WO, PRE>;
+#ifdef EXP_NO_WGRAD_PF   // (A/B builds only)
+  constexpr bool PF = false;
+#else
+  constexpr bool PF = CSW * OSW == 1;
+#endif
+  auto kern = wgrad_tile_kernel<T, NTAP, CSW, OSW, WC, WO, PRE, PF>;
   static LdsOptIn opt;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
   if (!opt.ensure(reinterpret_cast<const void*>(kern), (int)lds)) return;   // (the caller's MDIE_LAUNCH_CHECK reports it)
   hipLaunchKernelGGL(kern, dim3(p.c_tiles * p.o_tiles, p.splits), dim3(TR_THREADS), lds, s, a);
