@@ -422,7 +422,9 @@ class Model:
         # (auto: only while a step is launch-bound -- measured on MI355X, bf16, B = 8, round 3: 256x256 6.2 -> 3.8 ms per step as a
         #  graph; 512x512 7.9 eager -- weight gradients overlap the backward chain on a side stream there, train._wgrad -- 8.4 as a graph)
         mode = os.environ.get("MDIE_TRAIN_GRAPH", "auto") if self.device.type == "cuda" else "0"
-        want_graph = (lambda x: mode == "1" or (mode == "auto" and x.shape[0] * x.shape[2] * x.shape[3] <= 8 * 384 * 384))
+        # (round 4: the side stream is opt-in, MDIE_TRAIN_WGRAD_STREAM=1 -- without it the graph is at least as fast at every size, 8.28 against
+        #  8.30 ms at 8x512x512, and takes the ~5.8 ms of host work per eager step off the critical path altogether: auto = always)
+        want_graph = (lambda x: mode == "1" or (mode == "auto" and (not T.WGRAD_STREAM or x.shape[0] * x.shape[2] * x.shape[3] <= 8 * 384 * 384)))
         whole = mode != "0" and not distributed and not scaler.is_enabled()      # the Adam step rides in the graph too
         # (fused=True: torch's single-kernel Adam -- the same update as the reference's default foreach form, models/model.py:146,
         #  in 1 launch instead of 19: 0.28 -> 0.06 ms of a 10 ms step; CPU runs keep the default)
