@@ -2,6 +2,7 @@
 // pixel <-> lane map of a 16x16 tile and the fused epilogue (affine, activation, residual, 2x2 max-pool, NHWC store, CBAM
 // pooling partials).  See conv.hip for the formulation.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace mdie {
@@ -278,6 +279,15 @@ __device__ __forceinline__ void conv_epilogue_bnred(const EpiArgs& e, const floa
   const size_t pix0 = ((size_t)img * e.H + gy0) * e.W + gx0;
   const ptrdiff_t ogs = (ptrdiff_t)e.out_gs;
   T* const orow0 = reinterpret_cast<T*>(e.out) + pix0 * e.out_stride + (ptrdiff_t)(n0 >> 4) * ogs + lq * 4;
+  // EVERY x load of the tile (all channel groups, all subtiles) and the groups' constants are requested up front: the stores below sit
+  // under per-lane branches, across which the compiler does not move the next group's loads -- group by group this was NCS exposed
+  // memory round trips behind the MFMA phase (4 for the 64-output input-gradient layers of the DenseBlocks: 1.2 ms of an 8.3 ms step)
+  typedef typename std::conditional<sizeof(T) == 4, float4, uint2>::type RawX;
+  RawX xr[NCS][NPS];
+  float4 bsc_[NCS], bsh_[NCS];
+  bool inside[NPS];
+#pragma unroll
+  for (int ps = 0; ps < NPS; ++ps) inside[ps] = gy0 + TS::dy(ps) < e.H && gx0 + TS::dx(ps) < e.W;
 #pragma unroll
   for (int cs = 0; cs < NCS; ++cs) {
     const int c16 = n0 + cs * 16;                                   // wave-uniform: first stored channel of this group
@@ -287,23 +297,26 @@ __device__ __forceinline__ void conv_epilogue_bnred(const EpiArgs& e, const floa
       if (k < e.bx_nseg && c16 >= e.bx[k].ch_begin && c16 < e.bx[k].ch_end) {
         xb = reinterpret_cast<const T*>(e.bx[k].ptr) + (c16 - e.bx[k].ch_begin) + lq * 4; xs = e.bx[k].stride;
       }
-    const float4 bsc = *reinterpret_cast<const float4*>(e.b_scale + c16 + lq * 4), bsh = *reinterpret_cast<const float4*>(e.b_shift + c16 + lq * 4);
+    bsc_[cs] = *reinterpret_cast<const float4*>(e.b_scale + c16 + lq * 4); bsh_[cs] = *reinterpret_cast<const float4*>(e.b_shift + c16 + lq * 4);
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const size_t pix = inside[ps] ? pix0 + (size_t)TS::dy(ps) * e.W + TS::dx(ps) : pix0 - (size_t)ty0 * e.W - tx0;   // (outside: the tile's first pixel, not used)
+      xr[cs][ps] = *reinterpret_cast<const RawX*>(xb + pix * xs);
+    }
+  }
+#pragma unroll
+  for (int cs = 0; cs < NCS; ++cs) {
+    const float4 bsc = bsc_[cs], bsh = bsh_[cs];
     const float bs[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, bh[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
     const float sc[4] = {esc[cs].x, esc[cs].y, esc[cs].z, esc[cs].w}, sh[4] = {esh[cs].x, esh[cs].y, esh[cs].z, esh[cs].w};
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     float xv[NPS][4];
-    bool inside[NPS];
 #pragma unroll
-    for (int ps = 0; ps < NPS; ++ps) {                              // all of the group's x loads first (in flight together)
-      const int gy = gy0 + TS::dy(ps), gx = gx0 + TS::dx(ps);
-      inside[ps] = gy < e.H && gx < e.W;
-      const size_t pix = inside[ps] ? pix0 + (size_t)TS::dy(ps) * e.W + TS::dx(ps) : pix0 - (size_t)ty0 * e.W - tx0;   // (outside: the tile's first pixel, not used)
+    for (int ps = 0; ps < NPS; ++ps) {
       if constexpr (sizeof(T) == 4) {
-        const float4 v = *reinterpret_cast<const float4*>(xb + pix * xs);
-        xv[ps][0] = v.x; xv[ps][1] = v.y; xv[ps][2] = v.z; xv[ps][3] = v.w;
+        xv[ps][0] = xr[cs][ps].x; xv[ps][1] = xr[cs][ps].y; xv[ps][2] = xr[cs][ps].z; xv[ps][3] = xr[cs][ps].w;
       } else {
-        const uint2 v = *reinterpret_cast<const uint2*>(xb + pix * xs);
-        xv[ps][0] = Half<T>::lo(v.x); xv[ps][1] = Half<T>::hi(v.x); xv[ps][2] = Half<T>::lo(v.y); xv[ps][3] = Half<T>::hi(v.y);
+        xv[ps][0] = Half<T>::lo(xr[cs][ps].x); xv[ps][1] = Half<T>::hi(xr[cs][ps].x); xv[ps][2] = Half<T>::lo(xr[cs][ps].y); xv[ps][3] = Half<T>::hi(xr[cs][ps].y);
       }
     }
 #pragma unroll
