@@ -31,12 +31,14 @@ cp("layers_bf16_general_tail.txt", "layers_bf16_general_tail.txt")
 cp("batch_independence_probe.txt", "batch_independence_probe.txt")
 cp("train_timeline.txt", "train_timeline_bf16_b8_512.txt")
 cp("infer_timeline.txt", "infer_timeline_bf16_b32.txt")
+cp("ablate_bf16.txt", "ablate_bf16.txt")
+cp("bench_routed.txt", "bench_routed.json")
 with open(os.path.join(dst, f"{pre}_configs.txt"), "w") as f:
     f.write("# BASELINE configs[2] (training step shape), [3] (routed, 9 weight sets) and [4] (1024x1024, its stated dtype fp16), plus the\n"
             "# PCIe-inclusive and batches-in-flight serving rates: output lines of tools/bench_train.py, bench_configs.py, bench_e2e.py,\n"
             "# bench_inflight.py on one MI355X (tools/measure_all.sh)\n")
     for name in ("configs_large_fp16", "configs_large_bf16", "configs_routed_bf16", "train_bf16_b8_512", "train_bf16_b8_256", "train_fp16_b8_512", "train_fp16_b8_256",
-                 "e2e_bf16", "inflight_bf16"):
+                 "e2e_bf16", "inflight_bf16", "train_ddp1_bf16_b8_512", "train_host_enqueue", "configs_routed_groups_bf16"):
         p = os.path.join(src, name + ".txt")
         if os.path.exists(p):
             f.write("".join(l for l in open(p) if "amdgpu.ids" not in l))

@@ -33,7 +33,10 @@ run tail_fold_ab_fp16 python tools/bench_tail_ab.py fp16
 run layers_bf16_general_tail env GENERAL_TAIL=1 python tools/profile_layers.py bf16
 run batch_independence_probe python tools/probe_concurrent.py bf16 4 5
 run conv_microbench python tools/bench_conv.py bf16 conv2 conv3 conv4 dec1 dec2 dec3 first d1l0 d1l3 d2l3 d3l3 fl3 ftr
-run ab_ksplit bash tools/bench_ab.sh "$ROOT/multi-degradation-image-enhancement_amd/libmdie_hip_noksplit.so" 3
+# what each stage costs the step (needs libmdie_hip_ablate.so: `tools/ablate.sh build` before the gpurun call)
+[ -f "$ROOT/multi-degradation-image-enhancement_amd/libmdie_hip_ablate.so" ] && run ablate_bf16 python tools/ablate.py bf16 3
+run train_host_enqueue python tools/host_time_train.py bf16 8 512
+run configs_routed_groups_bf16 python bench.py --workload routed --routed-mode groups
 run train_ddp1_bf16_b8_512 env MDIE_DDP_SINGLE=1 python tools/bench_train.py bf16 8 512 charbonnier:1,ssim:0.5 eager
 run bench_routed python bench.py --workload routed
 fi
