@@ -548,8 +548,13 @@ def test_transition_folded_into_its_producers(E, L, precision, shape):
     b_d = [b.cuda() for b in bs]
     bt_d = pad_v(bt, 16).cuda()
 
-    def run(fold):
-        base = torch.zeros(B, H, W, 8, device="cuda", dtype=td)
+    def run(fold, half=False):
+        # half: the base stored as HALF a 16-byte group (4 channels per pixel, mdie_seg / base_stride: ABI 24) -- the chain's 16-byte column
+        # loads then read the NEXT pixel's bytes into channels 4..7, whose weights are zero (one spare pixel behind the buffer, filled with a
+        # large finite value: it must not reach any output)
+        bs_ = 4 if half else 8
+        base_buf = torch.full((B * H * W + 1, bs_), 3.0e4, device="cuda", dtype=td)
+        base = base_buf[:B * H * W].view(B, H, W, bs_)
         gs = [torch.full((B, H, W, 16), -7.0, device="cuda", dtype=td) for _ in range(4)]
         y = torch.full((B, 3, H, W), -1.0, device="cuda")
         part = torch.full((B, H, W, 4), 1e9, device="cuda")
@@ -566,7 +571,7 @@ def test_transition_folded_into_its_producers(E, L, precision, shape):
         u = L.UpDense0Desc()
         u.dtype, u.B, u.H, u.W = dt, B, H, W
         u.lo, u.lo_stride, u.x = lo.data_ptr(), 16, x.data_ptr()
-        u.base, u.base_channels, u.weight = base.data_ptr(), 8, w0.data_ptr()
+        u.base, u.base_channels, u.base_stride, u.weight = base.data_ptr(), 8, (4 if half else 0), w0.data_ptr()
         u.pre_scale, u.pre_shift, u.bias = ps_d[0].data_ptr(), pb_d[0].data_ptr(), b_d[0].data_ptr()
         u.g0, u.g0_stride = gs[0].data_ptr(), 16
         if fold:
@@ -575,7 +580,7 @@ def test_transition_folded_into_its_producers(E, L, precision, shape):
         for l in (1, 2, 3):
             d = L.ConvDesc()
             d.dtype, d.B, d.H, d.W, d.ksize, d.nseg = dt, B, H, W, 3, l + 1
-            d.inp[0] = L.Seg(base.data_ptr(), 8, 8)
+            d.inp[0] = L.Seg(base.data_ptr(), 8, bs_)
             for i in range(l):
                 d.inp[1 + i] = L.Seg(gs[i].data_ptr(), 16, 16)
             d.cin, d.cout = 8 + 16 * l, 16
@@ -604,6 +609,9 @@ def test_transition_folded_into_its_producers(E, L, precision, shape):
 
     base_u, gs_u, y_u = run(False)
     base_f, gs_f, y_f = run(True)
+    base_h, gs_h, y_h = run(True, half=True)
+    assert torch.equal(base_h[..., :3], base_f[..., :3]) and (base_h[..., 3] == 0).all()
+    assert torch.equal(y_h, y_f) and all(torch.equal(gs_h[l], gs_f[l]) for l in range(3)), "the half-group base must not change a bit"
     assert torch.equal(base_u, base_f)
     for l in range(3):
         assert torch.equal(gs_u[l], gs_f[l]), f"growth map {l} must not change"
@@ -622,9 +630,19 @@ def test_transition_folded_into_its_producers(E, L, precision, shape):
 
 
 def test_transition_fusion_rejects_what_it_cannot_run(E, L):
-    """mdie_tr_fuse is built for 16-bit types on whole 16x16 tiles: everything else is refused loudly (the engine runs the general chain there)"""
+    """mdie_tr_fuse is built for 16-bit types on whole 16x16 tiles: everything else is refused loudly (the engine runs the general chain there);
+    so is a half-group segment (8 channels at stride 4) outside the folded chain"""
     import ctypes as C
     x = torch.zeros(1, 24, 32, 16, device="cuda")
+    d = L.ConvDesc()
+    d.dtype, d.B, d.H, d.W, d.ksize, d.nseg = L.BF16, 1, 16, 16, 3, 2
+    d.inp[0], d.inp[1] = L.Seg(x.data_ptr(), 8, 4), L.Seg(x.data_ptr(), 16, 16)
+    d.cin, d.cout = 24, 16
+    wv = torch.zeros(L.lib.mdie_conv_weight_bytes(L.BF16, 3, 16, 24), dtype=torch.uint8, device="cuda")
+    vv = torch.zeros(80, device="cuda")
+    d.pre_scale, d.pre_shift, d.weight, d.post_scale, d.post_shift = vv.data_ptr(), vv.data_ptr(), wv.data_ptr(), vv.data_ptr(), vv.data_ptr()
+    d.out, d.out_stride = x.data_ptr(), 16
+    assert L.lib.mdie_conv_fwd(C.byref(d), None) == -1 and "stride" in L.lib.mdie_last_error().decode()      # no tr: stride < channels is invalid
     w = torch.zeros(L.lib.mdie_conv_weight_bytes(L.BF16, 3, 16, 16), dtype=torch.uint8, device="cuda")
     v = torch.zeros(80, device="cuda")
     t = L.TrFuse()
@@ -1587,6 +1605,32 @@ def test_routed_inference_matches_per_task_engines(E, mode, prec, hw):
         routed.forward(x, ["jpeg"] * 7)
     with pytest.raises(Exception):
         routed.forward(x, labels[:3])
+
+
+def test_routed_chain_serves_changing_batches_and_extents(E):
+    """one RoutedEngine (chain mode) called with batches of different size and extent in a row -- its workspace grows and is reused, the
+    weight table is built once -- each result bitwise what per-task engines return"""
+    from oracle import params as P
+    tasks = {"a": 31, "b": 32, "c": 33}
+    routed = E.RoutedEngine("cuda", "bf16")
+    single = {}
+    for t, seed in tasks.items():
+        sd = P.make_state_dict(seed)
+        routed.load_task(t, sd)
+        single[t] = E.CdanEngine("cuda", "bf16").load(sd)
+    names = sorted(tasks)
+    for k, (B, H, W) in enumerate([(2, 32, 32), (9, 64, 48), (1, 32, 32), (5, 128, 128), (3, 32, 32)]):
+        x = P.lowlight_batch(40 + k, B, H, W)[0].cuda()
+        labels = [names[(3 * i + k) % 3] for i in range(B)]
+        y = routed.forward(x, labels)
+        for i, t in enumerate(labels):
+            assert torch.equal(y[i], single[t].forward(x[i:i + 1])[0]), (k, i, t)
+    routed.load_task("d", P.make_state_dict(34))          # a new weight set: the table is rebuilt
+    single["d"] = E.CdanEngine("cuda", "bf16").load(P.make_state_dict(34))
+    x = P.lowlight_batch(50, 4, 32, 32)[0].cuda()
+    y = routed.forward(x, ["d", "a", "d", "c"])
+    for i, t in enumerate(["d", "a", "d", "c"]):
+        assert torch.equal(y[i], single[t].forward(x[i:i + 1])[0]), (i, t)
 
 
 def test_training_steps_in_flight_match_serial_steps():
