@@ -204,6 +204,8 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    from mdie_amd import host as _host
+    _host.bind_to_gpu_numa(local)        # the launching thread next to its GPU (two-socket hosts; MDIE_NUMA_BIND=0 turns it off)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -225,6 +225,40 @@ def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
+def _cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_gpu_numa(device_index=0):
+    """Keep this process on the CPUs of the NUMA node its GPU hangs off (MDIE_NUMA_BIND=0 turns it off).
+    A two-socket MI355X host gives a process CPUs of both sockets; where its threads happen to run decides on which node pinned host
+    buffers are first touched, and a batch that crosses the socket link on its way to PCIe moves at half the rate -- the PCIe-inclusive
+    serving rate was bimodal by process, 26 k or 13.7 k images/s on one box (tools/bench_e2e.py).  The node comes from the
+    device's PCI address (torch's device properties -> /sys/bus/pci/devices/<bdf>/local_cpulist); the binding is the intersection with
+    the CPUs the process is allowed.  Returns the CPU set bound to, or None when nothing was changed (no sysfs entry, no GPU, a single
+    node, an empty intersection, or switched off) -- never raises: placement is speed, not correctness."""
+    if os.environ.get("MDIE_NUMA_BIND", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
+            local = _cpulist(f.read())
+        allowed = os.sched_getaffinity(0)
+        want = local & allowed
+        if not want or want == allowed:
+            return None
+        os.sched_setaffinity(0, want)
+        return want
+    except Exception:
+        return None
+
+
 def init_distributed(backend=None):
     """Under torchrun: bind this process to its GPU and join the process group (RCCL over xGMI = backend "nccl";
     "gloo" on a CPU-only host, which only the plumbing tests use).  No-op for a single process."""
@@ -236,6 +270,7 @@ def init_distributed(backend=None):
     os.environ.setdefault("MASTER_PORT", "29500")
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
+        bind_to_gpu_numa(local)
         dist.init_process_group(backend or "nccl", device_id=torch.device("cuda", local))
     else:
         dist.init_process_group(backend or "gloo")
@@ -374,6 +409,8 @@ class Model:
         self.device = torch.device(sect["device"])
         if self.world > 1 and self.device.type == "cuda" and self.device.index is None:
             self.device = torch.device("cuda", local)          # one process per GPU
+        if self.device.type == "cuda" and torch.cuda.is_available():
+            bind_to_gpu_numa(self.device.index if self.device.index is not None else torch.cuda.current_device())   # pinned batches stay on the GPU's socket
         self.model_path, self.model_name = sect["model_path"], sect["model_name"]
         test = config.get("test") or {}
         self.is_dataset_paired = bool((test.get("dataset") or {}).get("is_paired", True))

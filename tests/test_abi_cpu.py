@@ -193,3 +193,14 @@ def test_shipped_code_objects_pass_the_isa_guard():
     assert not bad, [(r["pretty"], r["pk_sel"][:2]) for r in bad]
     spills = [(r["pretty"], r["scratch"], r["scratch_hot"]) for r in isa_guard.spills(rows)]     # (one documented exception: isa_guard.spills)
     assert not spills, spills
+
+
+def test_numa_binding_helper_is_inert_without_a_gpu(monkeypatch):
+    """host.bind_to_gpu_numa: the CPU-list parser, and that placement never raises or changes anything where there is no GPU / sysfs entry"""
+    import os
+    from mdie_amd import host as H
+    assert H._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and H._cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    assert H.bind_to_gpu_numa(0) is None and os.sched_getaffinity(0) == before
+    monkeypatch.setenv("MDIE_NUMA_BIND", "0")
+    assert H.bind_to_gpu_numa(0) is None

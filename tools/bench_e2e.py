@@ -17,6 +17,8 @@ S = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 N = int(sys.argv[4]) if len(sys.argv) > 4 else 60
 DEPTH = 3
 dev = torch.device("cuda")
+from mdie_amd import host as H
+bound = H.bind_to_gpu_numa(0)     # BEFORE the pinned buffers are touched: on a two-socket host the rate is 26 k or 13.7 k img/s by placement
 net = CDAN(precision=prec)
 net.load_state_dict(P.make_state_dict(42), strict=True)
 net = net.eval().to(dev)
@@ -65,4 +67,4 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N
 mb = 2 * B * S * S * 3 / 1e6
 print(f"e2e[{prec}] B={B} {S}x{S} uint8 in/out over PCIe, {DEPTH} batches in flight: {dt*1e3:.2f} ms/batch = {B/dt:.0f} img/s "
-      f"({mb/dt/1e3:.1f} GB/s of host traffic)")
+      f"({mb/dt/1e3:.1f} GB/s of host traffic); process bound to the GPU's NUMA node: {'yes, ' + str(len(bound)) + ' CPUs' if bound else 'no'}")
