@@ -19,7 +19,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (mdie_amd/__init__.py says why); before the runtime initialises
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

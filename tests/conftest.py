@@ -3,6 +3,7 @@ import sys
 
 import pytest
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # (mdie_amd/__init__.py: the product's runtime default, set before anything touches the GPU)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
