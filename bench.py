@@ -171,7 +171,8 @@ def routed_main(args, rank, world, dev, dist, P):
                                      "parallelism": (f"{world} rank(s), each holds all 9 weight sets and an equal slice of the batch, no collective" if mode == "chain"
                                                      else f"tasks dealt to {world} rank(s), images follow their task, no collective"),
                                      "launch": ("eager, ONE launch chain per rank-batch: every kernel looks up its image's weight set (mdie_cdan_fwd_desc.blob_delta)"
-                                                if mode == "chain" else "eager, one stream + one enqueueing host thread per task group")}}))
+                                                if mode == "chain" else "eager, one stream + one enqueueing host thread per task group"),
+                                     "runtime": getattr(args, "runtime", None)}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -207,7 +208,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from mdie_amd import host as _host
-    _host.bind_to_gpu_numa(local)        # the launching thread next to its GPU (two-socket hosts; MDIE_NUMA_BIND=0 turns it off)
+    numa = _host.bind_to_gpu_numa(local)  # the launching thread next to its GPU (two-socket hosts; MDIE_NUMA_BIND=0 turns it off)
+    args.runtime = {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"), "bound_to_gpu_numa_node": bool(numa)}
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -355,7 +357,8 @@ def main():
            "config": {"workload": f"config/low_light.json CDAN forward (eval), {S}x{S}, batch {B}/GPU, {args.precision} storage + fp32 accumulate, "
                                   f"seeded random-init weights, synthetic low-light images resident in HBM",
                       "global_batch": B * world, "parallelism": f"batch-parallel x{world}, no collective",
-                      "launch": (f"eager (one host call, {sum(v[0] for v in prof.values())} launches)" if graph is None else "hipGraph replay") + (", chosen in warmup" if args.launch == "auto" else "")},
+                      "launch": (f"eager (one host call, {sum(v[0] for v in prof.values())} launches)" if graph is None else "hipGraph replay") + (", chosen in warmup" if args.launch == "auto" else ""),
+                      "runtime": args.runtime},
            "roofline": roofline}
 
     if not args.no_extra and world == 1:
