@@ -36,9 +36,9 @@ def cpu_baseline(sd, x_cpu, seconds_budget=16.0):
     (B = 32 at 256x256, 1 warm-up + timed forwards, median) on every core this process may use, plus a
     one-thread figure on a 2-image sample (a one-thread pass over 32 images alone would take most of a minute)."""
     from oracle import cdan_oracle as O
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # a one-GPU box owns a 16-core share of its host; more threads than that only oversubscribe
-    cores = int(os.environ.get("MDIE_CPU_THREADS", min(avail, 16)))
+    # the cores this process is GRANTED (affinity mask and cgroup quota: a one-GPU box sees 256 CPUs and owns 16; more threads only oversubscribe)
+    from mdie_amd import host as _host
+    cores = int(os.environ.get("MDIE_CPU_THREADS", min(_host.cpu_share(), 64)))
 
     def timed(x, threads, budget, max_reps, min_reps=1):
         torch.set_num_threads(threads)

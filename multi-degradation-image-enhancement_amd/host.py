@@ -225,6 +225,35 @@ def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
+def cpu_share():
+    """CPUs this process can actually use: the smaller of its affinity mask and its cgroup's CPU quota (cgroup v2 `cpu.max`, v1
+    `cpu.cfs_quota_us / cpu.cfs_period_us`).  A one-GPU share of an MI355X host sees all 256 CPUs and is granted 16: sizing a thread pool
+    by os.cpu_count() there makes every parallel CPU operation crawl (a 6 MB tensor copy took 60 ms)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f1, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                q, p = int(f1.read()), int(f2.read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cap_cpu_threads():
+    """torch's intra-op pool never larger than cpu_share() (only ever lowered); returns the pool size in force"""
+    n = cpu_share()
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return torch.get_num_threads()
+
+
 def _cpulist(text):
     cpus = set()
     for part in text.strip().split(","):
@@ -409,6 +438,7 @@ class Model:
         self.device = torch.device(sect["device"])
         if self.world > 1 and self.device.type == "cuda" and self.device.index is None:
             self.device = torch.device("cuda", local)          # one process per GPU
+        cap_cpu_threads()
         if self.device.type == "cuda" and torch.cuda.is_available():
             bind_to_gpu_numa(self.device.index if self.device.index is not None else torch.cuda.current_device())   # pinned batches stay on the GPU's socket
         self.model_path, self.model_name = sect["model_path"], sect["model_name"]

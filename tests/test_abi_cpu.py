@@ -204,3 +204,7 @@ def test_numa_binding_helper_is_inert_without_a_gpu(monkeypatch):
     assert H.bind_to_gpu_numa(0) is None and os.sched_getaffinity(0) == before
     monkeypatch.setenv("MDIE_NUMA_BIND", "0")
     assert H.bind_to_gpu_numa(0) is None
+    n = H.cpu_share()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    import torch
+    assert H.cap_cpu_threads() <= max(n, 1) or torch.get_num_threads() <= n

@@ -1607,6 +1607,31 @@ def test_routed_inference_matches_per_task_engines(E, mode, prec, hw):
         routed.forward(x, labels[:3])
 
 
+def test_serving_loop_matches_one_batch_at_a_time(E, net):
+    """pipeline.ServingLoop (uint8 batches over PCIe, three in flight on three streams, one engine per stream) returns, in submission order,
+    exactly what the one-batch-at-a-time path returns -- also when the batch shape changes mid-stream and with post-processing on"""
+    from mdie_amd import pipeline as PL
+    from oracle import params as P
+    net.precision = "bf16"
+    shapes = [(4, 64, 64)] * 4 + [(2, 32, 48)] * 2 + [(4, 64, 64)] * 3
+    batches = [(P.lowlight_batch(60 + i, *s)[0].permute(0, 2, 3, 1) * 255).round().to(torch.uint8).contiguous() for i, s in enumerate(shapes)]
+    for pp in (None, {"enabled": True, "ops": [{"name": "enhance_contrast", "args": {"contrast_factor": 1.2}}, {"name": "sharpen"}]}):
+        with torch.no_grad():
+            refs = []
+            for b in batches:
+                y = net(PL.feed_uint8(b.cuda()))
+                refs.append((PL.apply_postprocessing(y, pp, want_uint8=True)[1] if pp else PL.to_uint8_hwc(y)).cpu())
+        torch.cuda.synchronize()
+        loop = PL.ServingLoop(net, depth=3, postprocessing=pp)
+        n = 0
+        for out, ref in zip(loop.run(batches), refs):
+            assert out.shape == ref.shape and torch.equal(out, ref), f"batch {n} differs"
+            n += 1
+        assert n == len(batches)
+    with pytest.raises(Exception):
+        list(PL.ServingLoop(net).run([torch.zeros(2, 3, 32, 32)]))          # float NCHW is not this loop's input
+
+
 def test_routed_chain_serves_changing_batches_and_extents(E):
     """one RoutedEngine (chain mode) called with batches of different size and extent in a row -- its workspace grows and is reused, the
     weight table is built once -- each result bitwise what per-task engines return"""

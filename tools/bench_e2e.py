@@ -23,48 +23,33 @@ net = CDAN(precision=prec)
 net.load_state_dict(P.make_state_dict(42), strict=True)
 net = net.eval().to(dev)
 deg, _ = P.lowlight_batch(7, B, S, S)
-host_in = [(deg.permute(0, 2, 3, 1) * 255).round().to(torch.uint8).contiguous().pin_memory() for _ in range(DEPTH)]
-host_out = [torch.empty(B, S, S, 3, dtype=torch.uint8).pin_memory() for _ in range(DEPTH)]
-streams = [torch.cuda.Stream(dev) for _ in range(DEPTH)]
-done = [None] * DEPTH
+batch_u8 = (deg.permute(0, 2, 3, 1) * 255).round().to(torch.uint8).contiguous()
+pinned_u8 = [batch_u8.clone().pin_memory() for _ in range(DEPTH)]   # a decoder that writes into pinned memory of its own (no staging copy)
+loop = PL.ServingLoop(net, depth=DEPTH)          # the package's serving loop (pipeline.py): pinned slots, one stream + engine per slot
 
+# every in-flight slot must reproduce the one-batch-at-a-time result bit for bit, also when the slots overlap on the GPU
+with torch.no_grad():
+    ref = PL.to_uint8_hwc(net(PL.feed_uint8(batch_u8.to(dev)))).cpu()
+torch.cuda.synchronize()
+for rep in range(3):
+    for out in loop.run([batch_u8] * DEPTH):
+        assert torch.equal(out, ref), f"a slot differs from the single-stream output (round {rep})"
 
-def check_slots():
-    """every in-flight slot (its own stream, hence its own engine and workspace: modules.CDAN._engine) must reproduce
-    the single-stream result bit for bit, also when the three overlap on the GPU"""
-    with torch.no_grad():
-        ref = PL.to_uint8_hwc(net(PL.feed_uint8(host_in[0].to(dev)))).cpu()
+def timed(src):
+    for k in range(DEPTH):
+        loop.submit(k, src[k])
     torch.cuda.synchronize()
-    for rep in range(3):
-        for i in range(DEPTH):
-            submit(i)
-        torch.cuda.synchronize()
-        for k in range(DEPTH):
-            assert torch.equal(host_out[k], ref), f"slot {k} differs from the single-stream output (round {rep})"
+    t0 = time.perf_counter()
+    for i in range(N):
+        k = i % DEPTH
+        loop.collect(k)
+        loop.submit(k, src[k])
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / N
 
 
-def submit(i):
-    k = i % DEPTH
-    if done[k] is not None:
-        done[k].synchronize()          # the slot's previous batch has left the GPU: its host buffers are free again
-    with torch.cuda.stream(streams[k]), torch.no_grad():
-        x_u8 = host_in[k].to(dev, non_blocking=True)
-        y = net(PL.feed_uint8(x_u8))
-        host_out[k].copy_(PL.to_uint8_hwc(y), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(streams[k])
-        done[k] = ev
-
-
-check_slots()
-for i in range(2 * DEPTH):
-    submit(i)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for i in range(N):
-    submit(i)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / N
+dt_pageable = timed([batch_u8] * DEPTH)          # batches in ordinary host memory: one staging memcpy per batch on the submitting thread
+dt = timed(pinned_u8)
 mb = 2 * B * S * S * 3 / 1e6
 print(f"e2e[{prec}] B={B} {S}x{S} uint8 in/out over PCIe, {DEPTH} batches in flight: {dt*1e3:.2f} ms/batch = {B/dt:.0f} img/s "
-      f"({mb/dt/1e3:.1f} GB/s of host traffic); process bound to the GPU's NUMA node: {'yes, ' + str(len(bound)) + ' CPUs' if bound else 'no'}")
+      f"({mb/dt/1e3:.1f} GB/s of host traffic; from pageable host batches {dt_pageable*1e3:.2f} ms = {B/dt_pageable:.0f} img/s); process bound to the GPU's NUMA node: {'yes, ' + str(len(bound)) + ' CPUs' if bound else 'no'}")
