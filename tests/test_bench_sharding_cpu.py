@@ -268,3 +268,36 @@ def test_routed_batch_is_dealt_by_task_two_ranks():
         assert not set(t0) & set(t1) and len(t0) + len(t1) == 9
         assert s0 + s1 == list(range(65)) and abs(len(s0) - len(s1)) <= 1     # chain mode: equal contiguous slices, labels play no part
         assert t == 1.5
+
+
+def _run_bench(extra_args, env_drop=("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (how the driver runs `--gpus 1`): the parent starts two ranks itself
+    (mdie_amd/launch.py), exactly one JSON line comes out, it says n_gpus 2, and the ranks held different batches.  `--rehearse` swaps
+    RCCL for gloo and the engine for a stub step; every line of the launch / rendezvous / fence / max-over-ranks plumbing is the real one."""
+    import json
+    r = _run_bench(["--gpus", "2", "--rehearse", "--steps", "3", "--warmup", "1", "--batch", "2", "--size", "16"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["rehearsal"] is True and rec["scaling"] == "weak"
+    assert rec["config"]["launcher"] == "self-launched children" and rec["config"]["distinct_rank_batches"] == 2
+    assert rec["config"]["global_batch"] == 4
+
+
+def test_self_launch_returns_the_worst_rank_exit_code(tmp_path):
+    """a rank that dies takes the job's exit code with it (and the surviving rank is not left behind)"""
+    sys.path.insert(0, ROOT)
+    from mdie_amd import launch as LA
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys\nsys.exit(7 if os.environ['RANK'] == '1' else 0)\n")
+    assert LA.self_launch([str(script)], 2) == 7
+    assert LA.needs_self_launch(2, env={}) and not LA.needs_self_launch(1, env={}) and not LA.needs_self_launch(8, env={"WORLD_SIZE": "8"})
+    e = LA.child_env(3, 8, 1234, base={})
+    assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_ADDR"], e["MASTER_PORT"]) == ("3", "3", "8", "127.0.0.1", "1234")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Training-step timing (BASELINE configs[2] shape: blur-style loss, 512x512, batch 8 per GPU), eager and as one hipGraph.
   python tools/bench_train.py [bf16|fp16|fp32] [B] [S] [loss terms, e.g. charbonnier:1,ssim:0.5] [eager|graph|both]
-  (under torchrun: one rank per GPU, bucketed RCCL all-reduce; the graph then holds forward + loss + backward and the
+  (`--gpus N` anywhere on the line: N ranks, one per GPU, started by this script itself; or under torchrun: one rank per GPU, bucketed RCCL all-reduce; the graph then holds forward + loss + backward and the
    exchange + Adam step follow the replay.  MDIE_DDP_SINGLE=1: a ONE-rank "nccl" group on a single GPU -- the whole
    hook -> bucket -> RCCL all-reduce -> finish path on HIP without a second device; the eager mode then also prints the step with
    the exchange left out and with the exchange AFTER backward: overlapped vs exposed communication time)
@@ -12,6 +12,13 @@ GEMMs of every convolution; `mdie_cdan_flops`); HBM bytes = 3 x the forward's fu
 per parameter per step (fp32 weight read, gradient write + read, Adam's two moments read + written, weight written)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--gpus" in sys.argv:      # `tools/bench_train.py --gpus N ...` with no launcher: become the parent of N ranks before anything touches the GPU
+    _i = sys.argv.index("--gpus")
+    _n = int(sys.argv[_i + 1])
+    del sys.argv[_i:_i + 2]
+    from mdie_amd import launch as _LA
+    if _LA.needs_self_launch(_n):
+        sys.exit(_LA.self_launch([os.path.abspath(__file__)] + sys.argv[1:], _n))
 import torch
 from models.cdan import CDAN
 from mdie_amd import host as H
