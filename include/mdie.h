@@ -58,7 +58,9 @@ typedef struct {
                        `tr` (decoder.final_dense's folded chain): channels == 8 with stride == 4 -- a HALF group: 4 stored channels
                        per pixel (the block's 3-channel base), read with the group's 16-byte load whose upper half is the next
                        pixel's bytes; the weights of channels 4..7 must be zero (they are: the base has 3 real channels) and the
-                       buffer readable 8 bytes past its last pixel.  Halves the base's bytes in all four launches of the chain. */
+                       buffer must extend 8 bytes past its last pixel, those bytes holding FINITE values (0 * NaN is NaN in the
+                       pre-activation and in the MFMA): mdie_up_add_dense0_fwd, the producer of such a buffer (base_stride 4),
+                       writes zeros there, so the caller only provides the room.  Halves the base's bytes in all four launches. */
 } mdie_seg;
 
 /* ---------------------------------------------------------------------------------
@@ -378,7 +380,8 @@ typedef struct {
   const float* x;              /* fp32 NCHW [B,3,H,W] */
   void* base; int base_channels;
   int base_stride;             /* elements between consecutive pixels of `base`; 0 = base_channels.  With `tr` (16-bit types) 4 is
-                                  accepted for base_channels == 8: only the first 4 channels of the group are stored (mdie_seg) */
+                                  accepted for base_channels == 8: only the first 4 channels of the group are stored, and 8 zero bytes are written behind the
+                                  last pixel of the buffer, which must have room for them (mdie_seg) */
   const void* weight;
   const float* pre_scale; const float* pre_shift;   /* >= 3 entries */
   const float* bias;           /* [16] */

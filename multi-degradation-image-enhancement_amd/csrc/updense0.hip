@@ -187,6 +187,9 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
         } else {   // half group (16-bit types): the 3 real channels and one zero, 8 bytes per pixel
           static_assert(E == 2 && BASE_ST == 4 && BASE_CH == 8, "half-group base: 16-bit types, 4 of 8 channels");
           *reinterpret_cast<uint2*>(dstb) = make_uint2(Half<T>::pack(o[0], o[1]), Half<T>::pack(o[2], 0.f));
+          // the consumers' 16-byte column load of the LAST pixel of the buffer reads 8 bytes behind it into zero-weighted channels:
+          // 0 * NaN is NaN, so those bytes are this kernel's to define (mdie_seg: the buffer is writable 8 bytes past its last pixel)
+          if (img == a.B - 1 && y0 + py == a.H && x0 + px == a.W) *reinterpret_cast<uint2*>(dstb + 8) = make_uint2(0u, 0u);
         }
         if constexpr (TR) {   // the transition's pre-activation of the stored base (f[] is already rounded to T)
           const float t0 = fmaxf(fmaf(f[0], tbs[0], tbb[0]), 0.f), t1 = fmaxf(fmaf(f[1], tbs[1], tbb[1]), 0.f), t2 = fmaxf(fmaf(f[2], tbs[2], tbb[2]), 0.f);

@@ -492,7 +492,7 @@ class Model:
         # (round 4: the side stream is opt-in, MDIE_TRAIN_WGRAD_STREAM=1 -- without it the graph is at least as fast at every size, 8.28 against
         #  8.30 ms at 8x512x512, and takes the ~5.8 ms of host work per eager step off the critical path altogether: auto = always)
         want_graph = (lambda x: mode == "1" or (mode == "auto" and (not T.WGRAD_STREAM or x.shape[0] * x.shape[2] * x.shape[3] <= 8 * 384 * 384)))
-        whole = mode != "0" and not distributed and not scaler.is_enabled()      # the Adam step rides in the graph too
+        whole = mode != "0" and not scaler.is_enabled()      # the Adam step rides in the graph too (with the gradient exchange in front of it when distributed)
         # (fused=True: torch's single-kernel Adam -- the same update as the reference's default foreach form, models/model.py:146,
         #  in 1 launch instead of 19: 0.28 -> 0.06 ms of a 10 ms step; CPU runs keep the default)
         opt = torch.optim.Adam(self.network.parameters(), lr=lr, capturable=whole, **({"fused": True} if self.device.type == "cuda" else {}))
@@ -501,67 +501,84 @@ class Model:
             # identical replicas: rank 0's parameters and buffers (the seed already makes them equal; this makes it certain)
             for t in list(self.network.parameters()) + list(self.network.buffers()):
                 dist.broadcast(t.data, src=0)
-        buckets = T.GradBuckets(self.network.parameters()) if distributed else None
-        hooks_on = buckets is not None
+        # Data parallel: the bucketed all-reduce ALWAYS overlaps backward (models/model.py:164-166 is the step being sharded).  In a captured
+        # step the collectives are branches of the graph (train.CapturedStep, `buckets=`); in an eager step they are issued by the buckets'
+        # hooks during backward.  There is no "exchange after a finished backward" on this path (round 4 ran five collectives behind the
+        # replay).  Which form a distributed step takes (MDIE_DDP_CAPTURE=auto): measured on a one-rank RCCL group, bf16, B = 8
+        # (profiles/r05c_ddp_forms.txt) -- 512x512: eager + hooks 8.69 ms, collectives inside the graph 8.89 (each of the five fork-joins
+        # costs the replay ~80 us); 256x256: eager 6.97 (host-bound), inside the graph 4.22.  So: captured while the step is launch-bound
+        # (fewer than 8 x 384 x 384 input pixels), eager + hooks above.  MDIE_DDP_CAPTURE=1 / 0 forces one form for every size.
+        n_buckets = int(os.environ.get("MDIE_DDP_BUCKETS", "4"))
+        buckets = T.GradBuckets(self.network.parameters(), n_buckets=n_buckets) if distributed else None
+        ddp_mode = os.environ.get("MDIE_DDP_CAPTURE", "auto")
+        if buckets is not None:
+            small = (lambda x: x.shape[0] * x.shape[2] * x.shape[3] < 8 * 384 * 384)
+            graph_ok = want_graph
+            want_graph = (lambda x: graph_ok(x) and (ddp_mode == "1" or (ddp_mode == "auto" and small(x))))
+        ddp_capture = True
+        self.exchange_mode = None if buckets is None else "overlapped: inside the captured step (launch-bound sizes), grad hooks on eager steps"
         best = float("inf")
         self.history = []
-        for epoch in range(n_epoch):
-            t0 = time.time()
-            self.network.train()
-            if hasattr(getattr(self.dataloader, "sampler", None), "set_epoch"):
-                self.dataloader.sampler.set_epoch(epoch)       # a different shard shuffle every epoch
-            sums, n = {}, 0
-            for inputs, targets in self.dataloader:
-                x, y = self._to_device(inputs), self._to_device(targets)
-                if want_graph(x):
-                    if hooks_on:
-                        buckets.remove()     # a replayed backward fires no hooks: the exchange runs after the replay (GradBuckets.exchange)
-                        hooks_on = False
-                    key = (tuple(x.shape), tuple(y.shape))
-                    if key not in captured:
-                        captured[key] = T.CapturedStep(self.network, losses, opt if whole else None, x, y,
-                                                       scale_fn=scaler.scale if scaler.is_enabled() else None)
-                    values = captured[key](x, y)
-                    if not whole:
-                        if buckets is not None:
-                            buckets.exchange()
-                        scaler.step(opt)
-                        scaler.update()
-                else:
-                    opt.zero_grad(set_to_none=True)
-                    out = self.network(x)
-                    total, values = losses(out, y)
-                    scaler.scale(total).backward()
-                    if buckets is not None:      # averaged gradients: RCCL all-reduce launched from the grad hooks during backward
-                        buckets.finish() if hooks_on else buckets.exchange()
-                    scaler.step(opt)         # (unscales, skips the step on inf/nan; plain opt.step() when disabled)
-                    scaler.update()
-                vals = values.cpu().tolist()  # one sync per step
-                for k, v in zip(losses.names + ["total"], vals):
-                    sums[k] = sums.get(k, 0.0) + v
-                n += 1
-            if distributed:   # epoch means over ALL ranks' batches, so every rank takes the same checkpoint decision
-                keys = sorted(sums)
-                tot = torch.tensor([sums[k] for k in keys] + [float(n)], dtype=torch.float64, device=self.device)
-                dist.all_reduce(tot)
-                sums, n = {k: float(v) for k, v in zip(keys, tot[:-1].tolist())}, int(tot[-1].item())
-            avg = {k: v / max(1, n) for k, v in sums.items()}
-            main_rank = not distributed or dist.get_rank() == 0
-            if avg["total"] < best:
-                best = avg["total"]
-                if main_rank:
-                    self.save_model(self.network)
-            self.history.append(avg)
-            if main_rank:
-                print(f"Epoch [{epoch + 1}/{n_epoch}] Train total: {avg['total']:.4f} | " +
-                      ", ".join(f"{k}: {v:.4f}" for k, v in avg.items() if k != "total") + f" | best: {best:.4f}")
-            if self.logger is not None and main_rank:
-                row = {"type": "epoch", "epoch": epoch + 1, "epoch_time_sec": time.time() - t0, "lr": lr, "best_loss_so_far": best}
-                row.update({f"loss_{k}": v for k, v in avg.items()})
-                self.logger.log("train", row)
-        if buckets is not None:
-            buckets.close()          # hooks off, and the training Functions stop writing gradients into this instance's buckets
+        try:
+            for epoch in range(n_epoch):
+                best = self._train_epoch(epoch, n_epoch, lr, losses, scaler, opt, captured, buckets, want_graph, whole, ddp_capture, distributed, best)
+        finally:
+            if buckets is not None:
+                buckets.close()      # hooks off and the training Functions stop writing gradients into this instance's buckets -- also when a step raised
         return self.history
+
+    def _train_epoch(self, epoch, n_epoch, lr, losses, scaler, opt, captured, buckets, want_graph, whole, ddp_capture, distributed, best):
+        import torch.distributed as dist
+        from . import train as T
+        t0 = time.time()
+        self.network.train()
+        if hasattr(getattr(self.dataloader, "sampler", None), "set_epoch"):
+            self.dataloader.sampler.set_epoch(epoch)       # a different shard shuffle every epoch
+        sums, n = {}, 0
+        for inputs, targets in self.dataloader:
+            x, y = self._to_device(inputs), self._to_device(targets)
+            if want_graph(x) and (buckets is None or ddp_capture):
+                key = (tuple(x.shape), tuple(y.shape))
+                if key not in captured:
+                    captured[key] = T.CapturedStep(self.network, losses, opt if whole else None, x, y,
+                                                   scale_fn=scaler.scale if scaler.is_enabled() else None, buckets=buckets)
+                values = captured[key](x, y)
+                if not whole:
+                    scaler.step(opt)
+                    scaler.update()
+            else:
+                opt.zero_grad(set_to_none=True)
+                out = self.network(x)
+                total, values = losses(out, y)
+                scaler.scale(total).backward()
+                if buckets is not None:      # averaged gradients: RCCL all-reduce launched from the grad hooks during backward
+                    buckets.finish()
+                scaler.step(opt)         # (unscales, skips the step on inf/nan; plain opt.step() when disabled)
+                scaler.update()
+            vals = values.cpu().tolist()  # one sync per step
+            for k, v in zip(losses.names + ["total"], vals):
+                sums[k] = sums.get(k, 0.0) + v
+            n += 1
+        if distributed:   # epoch means over ALL ranks' batches, so every rank takes the same checkpoint decision
+            keys = sorted(sums)
+            tot = torch.tensor([sums[k] for k in keys] + [float(n)], dtype=torch.float64, device=self.device)
+            dist.all_reduce(tot)
+            sums, n = {k: float(v) for k, v in zip(keys, tot[:-1].tolist())}, int(tot[-1].item())
+        avg = {k: v / max(1, n) for k, v in sums.items()}
+        main_rank = not distributed or dist.get_rank() == 0
+        if avg["total"] < best:
+            best = avg["total"]
+            if main_rank:
+                self.save_model(self.network)
+        self.history.append(avg)
+        if main_rank:
+            print(f"Epoch [{epoch + 1}/{n_epoch}] Train total: {avg['total']:.4f} | " +
+                  ", ".join(f"{k}: {v:.4f}" for k, v in avg.items() if k != "total") + f" | best: {best:.4f}")
+        if self.logger is not None and main_rank:
+            row = {"type": "epoch", "epoch": epoch + 1, "epoch_time_sec": time.time() - t0, "lr": lr, "best_loss_so_far": best}
+            row.update({f"loss_{k}": v for k, v in avg.items()})
+            self.logger.log("train", row)
+        return best
 
     def test(self):
         self.test_step()

@@ -83,9 +83,10 @@ class _LossFn(torch.autograd.Function):
             raise L.MdieError(f"fused_loss: 3-channel images only, got {ch}")
         arr = (L.LossTerm * len(terms))(*[L.LossTerm(L.LOSS_KINDS[n], float(w), float(a)) for n, w, a in terms])
         nws = L.lib.mdie_loss_workspace_bytes(B, H, W)
-        ws = torch.empty(nws, dtype=torch.uint8, device=p.device)
-        values = torch.empty(len(terms) + 1, dtype=torch.float32, device=p.device)
-        grad = torch.empty_like(p) if pred.requires_grad else None
+        from .train import _raw, _raw_like       # (uninitialised allocations of the training step: NaN-filled under MDIE_TRAIN_POISON=1)
+        ws = _raw(nws, dtype=torch.uint8, device=p.device)
+        values = _raw(len(terms) + 1, dtype=torch.float32, device=p.device)
+        grad = _raw_like(p) if pred.requires_grad else None
         L.check(L.lib.mdie_loss_fwd_bwd(B, H, W, p.data_ptr(), t.data_ptr(), arr, len(terms), values.data_ptr(),
                                         grad.data_ptr() if grad is not None else None, ws.data_ptr(), nws, _stream_ptr(p.device)),
                 "mdie_loss_fwd_bwd")

@@ -61,8 +61,37 @@ def _f32(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
 
 
+# Every uninitialised allocation of this file goes through _raw / _raw_like.  MDIE_TRAIN_POISON=1 (a debug switch, also settable as
+# train.POISON) fills each one before use -- NaN for floating point, 0xFF bytes for the uint8 workspaces (NaN when read as fp32 / bf16 /
+# fp16 partials, -1 as a count), 0x7F7F7F7F for integers -- so that a kernel that READS memory no launch of the step has written turns
+# the step's losses / gradients into NaN deterministically, whatever the allocator happens to hand back (round-3 finding 6: gradients
+# that depended on the schedule; allocator-address dependence is what the earlier poison -- two CBAM arenas only -- did not cover).
+POISON = __import__("os").environ.get("MDIE_TRAIN_POISON", "0") == "1"
+
+
+def _poison(t):
+    if t.numel():
+        if t.is_floating_point():
+            t.fill_(float("nan"))
+        elif t.dtype == torch.uint8:
+            t.fill_(0xFF)
+        else:
+            t.fill_(0x7F7F7F7F if t.dtype in (torch.int32, torch.int64) else 0x7F)
+    return t
+
+
+def _raw(*shape, **kw):
+    t = torch.empty(*shape, **kw)
+    return _poison(t) if POISON else t
+
+
+def _raw_like(x, **kw):
+    t = torch.empty_like(x, **kw)
+    return _poison(t) if POISON else t
+
+
 def _empty(dt, B, Cc, H, W, dev):
-    return torch.empty(B, Cc, H, W, dtype=E.TORCH_DTYPE[dt], device=dev, memory_format=torch.channels_last)
+    return _raw(B, Cc, H, W, dtype=E.TORCH_DTYPE[dt], device=dev, memory_format=torch.channels_last)
 
 
 class _PackPlan:
@@ -125,23 +154,29 @@ def _new_zero_arena(dev, n=4096):
 # writes straight into that parameter's slice of its flat all-reduce bucket, and the Function returns a fresh VIEW of the slice:
 # autograd's AccumulateGrad takes it over as `.grad` (one reference, the parameter's layout), so `.grad` IS the bucket memory
 # and the exchange moves no gradient in or out (round 3: 140 copies in + 140 back per step).  Only while `param.grad is None`
-# (zero_grad(set_to_none=True), what Model.train_step does): an existing .grad is accumulated into by autograd as usual.
+# (zero_grad(set_to_none=True), what Model.train_step does): an existing .grad is accumulated into by autograd as usual.  And only
+# ONCE per parameter per backward (GradBuckets.claim, keyed by the autograd graph task): when one backward produces two gradients of
+# one parameter (the network applied twice in one graph, weight sharing), `.grad` is still None at the second producer while the first
+# gradient -- the slice -- sits un-summed in autograd's input buffer; a second kernel writing the same slice would overwrite it and
+# autograd would add the slice to itself (2 x the second contribution).  The second sighting therefore gets a fresh tensor, autograd sums
+# the two, and the hook's copy path puts the sum into the slice.  Outside an engine-run backward (no graph task) nothing is claimed.
+# (`torch.autograd.grad` with a sink active returns views of bucket memory for sink-aware parameters: valid until the next backward.)
 _GRAD_SINK = None
 
 
 def _gout(param, shape, dev):
     """the tensor a kernel writes `param`'s gradient into: the parameter's bucket slice (as a fresh view) or a new tensor"""
     sink = _GRAD_SINK
-    if sink is not None and param is not None and param.grad is None:
+    if sink is not None and param is not None and param.grad is None and sink.claim(param):
         v = sink.view_of(param)
         if v is not None and tuple(v.shape) == tuple(shape):
             return v
-    return torch.empty(shape, dtype=torch.float32, device=dev)
+    return _raw(shape, dtype=torch.float32, device=dev)
 
 
 def _zero_grad_vec(n, dev, param=None):
     sink = _GRAD_SINK
-    if sink is not None and param is not None and param.grad is None:
+    if sink is not None and param is not None and param.grad is None and sink.claim(param):
         v = sink.zero_view_of(param)          # (a slice no kernel ever writes: zero since the bucket was made, all-reduced zeros stay zero)
         if v is not None and v.numel() == n:
             return v
@@ -164,11 +199,11 @@ def _pack(dt, w32, ks, transposed, cout, cin, cout_st=None, cin_st=None, split=N
         if hit is not None:
             return hit
     n = L.lib.mdie_conv_weight_bytes(dt, ks, cin_st, cout_st)
-    dst = torch.empty(n, dtype=torch.uint8, device=w32.device)
+    dst = _raw(n, dtype=torch.uint8, device=w32.device)
     job = L.PackJob(w32.data_ptr(), dst.data_ptr(), *args)
     L.check(L.lib.mdie_pack_conv_weight_job(dt, C.byref(job), _sp(w32.device)), "mdie_pack_conv_weight_job")
     if plan is not None and w32.data_ptr() in plan.param_ptrs:
-        plan.register(key, w32, torch.empty_like(dst), args)
+        plan.register(key, w32, _raw_like(dst), args)
     return dst
 
 
@@ -337,7 +372,7 @@ def _wgrad_launch(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre
     cin_st = sum(s.shape[1] for s in segs)
     dw = _gout(param, w_shape, dev)
     nws = L.lib.mdie_conv_wgrad_workspace_bytes(B, H, W, ks, cin_st, cout_st)
-    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    ws = _raw(nws, dtype=torch.uint8, device=dev)
     d = L.WgradDesc()
     d.dtype, d.B, d.H, d.W, d.ksize, d.transposed = dt, B, H, W, ks, int(transposed)
     d.nseg = len(segs)
@@ -361,7 +396,7 @@ class _Bn:
         ptr, c, st = _nhwc(t)
         B, _, H, W = t.shape
         nws = L.lib.mdie_bn_workspace_bytes(c)
-        ws = torch.empty(nws, dtype=torch.uint8, device=t.device)
+        ws = _raw(nws, dtype=torch.uint8, device=t.device)
         L.check(L.lib.mdie_bn_stats(dt, B * H * W, ptr, c, st, mean.data_ptr(), var.data_ptr(), ws.data_ptr(), nws, _sp(t.device)), "mdie_bn_stats")
 
     @staticmethod
@@ -372,13 +407,13 @@ class _Bn:
         ptr, c, st = _nhwc(t)
         B, _, H, W = t.shape
         dev = t.device
-        k = torch.empty(3, c_st, dtype=torch.float32, device=dev)
+        k = _raw(3, c_st, dtype=torch.float32, device=dev)
         d = L.BnStatsFoldDesc()
         d.dtype, d.N, d.C, d.stride = dt, B * H * W, c, st
         d.mean, d.var = mv[0, off:].data_ptr(), mv[1, off:].data_ptr()
         if partial is None:
             nws = L.lib.mdie_bn_workspace_bytes(c)
-            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+            ws = _raw(nws, dtype=torch.uint8, device=dev)
             d.x, d.workspace, d.workspace_bytes = ptr, ws.data_ptr(), nws
         else:
             d.x, d.workspace, d.workspace_bytes, d.n_partial = None, partial[0].data_ptr(), partial[0].numel() * partial[0].element_size(), partial[1]
@@ -392,7 +427,7 @@ class _Bn:
     @staticmethod
     def fold(c_st, c_real, split, gap, mean, var, bn, momentum, count, dev):
         """-> consts [3, c_st]: scale, shift, invstd; updates bn.running_* in place"""
-        k = torch.empty(3, c_st, dtype=torch.float32, device=dev)
+        k = _raw(3, c_st, dtype=torch.float32, device=dev)
         L.check(L.lib.mdie_bn_fold(c_st, c_real, split, gap, mean.data_ptr(), var.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), EPS, momentum,
                                    count, bn.running_mean.data_ptr(), bn.running_var.data_ptr(), k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr(),
                                    _sp(dev)), "mdie_bn_fold")
@@ -426,7 +461,7 @@ class _ConvBnFn(torch.autograd.Function):
         w32 = _f32(weight)
         y = _empty(dt, B, cout, H, W, dev)
         _conv_raw(dt, [x], _pack(dt, w32, 3, False, cout, cin, cout, cin_st), _f32(bias), 3, cout, y)
-        mv = torch.empty(2, cout, dtype=torch.float32, device=dev)
+        mv = _raw(2, cout, dtype=torch.float32, device=dev)
         k = _Bn.stats_fold(dt, y, mv, 0, cout, cout, cout, 0, bn, 0.1)
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         o = _empty(dt, B, cout, Ho, Wo, dev) if need_o else None
@@ -455,11 +490,11 @@ class _ConvBnFn(torch.autograd.Function):
         td = E.TORCH_DTYPE[dt]
         d_o = _cl(d_o.to(td)) if d_o is not None else None
         d_t = _cl(d_t.to(td)) if d_t is not None else None
-        dz = torch.empty_like(y)
+        dz = _raw_like(y)
         dgb = (_gout(ctx.gparams[0], (cout,), dev), _gout(ctx.gparams[1], (cout,), dev))
-        coef = torch.empty(2, cout, dtype=torch.float32, device=dev)
+        coef = _raw(2, cout, dtype=torch.float32, device=dev)
         nws = L.lib.mdie_bn_workspace_bytes(cout)
-        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        ws = _raw(nws, dtype=torch.uint8, device=dev)
         d = L.BnPoolBwdDesc()
         d.dtype, d.B, d.H, d.W, d.C, d.c_real = dt, B, H, W, cout, cout
         d.y, d.y_stride = y.data_ptr(), cout
@@ -495,7 +530,7 @@ class _DenseFn(torch.autograd.Function):
         # contiguous with its neighbours', so the layer that writes it, the statistics pass and every later reader move whole
         # cache lines (a 16-of-64 slice touches a quarter of each 128-byte line: the statistics pass ran at 1.7 TB/s)
         grow = [_empty(dt, B, 16, H, W, dev) for _ in range(4)]
-        mv = torch.empty(2, ct, dtype=torch.float32, device=dev)
+        mv = _raw(2, ct, dtype=torch.float32, device=dev)
         bn_of = lambda l: (getattr(blk.layers, str(l)) if l < 4 else blk.transition_layer)._modules["0"]
         # statistics once per segment (x, then each growth map as it is written), each pass followed in the same call by the
         # fold of the NEXT layer's BatchNorm over everything written so far
@@ -515,7 +550,7 @@ class _DenseFn(torch.autograd.Function):
                 cout_st = (cout + 15) // 16 * 16
                 packed = _pack(dt, w, 1, False, cout, cin_real, cout_st, cin_st, split=real_c, gap=gap)
                 out = _empty(dt, B, cout_st, H, W, dev)
-                y = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev) if sigmoid else None
+                y = _raw(B, 3, H, W, dtype=torch.float32, device=dev) if sigmoid else None
                 _conv_raw(dt, segs, packed, _pad_vec(params[4 * l + 3], cout_st), 1, cout_st, out, pre=(k[0], k[1]),
                           act=L.ACT_SIGMOID if sigmoid else L.ACT_NONE, out_nchw3=y)
                 consts.append(k)
@@ -541,13 +576,13 @@ class _DenseFn(torch.autograd.Function):
             L.check(L.lib.mdie_sigmoid_bwd_nchw3(dt, B, H, W, _f32(d_out).data_ptr(), y.data_ptr(), dz.data_ptr(), 16, _sp(dev)), "mdie_sigmoid_bwd_nchw3")
         else:
             dz = _cl(d_out.to(td))
-        gx, gg = torch.empty_like(x), [torch.empty_like(g) for g in grow]
+        gx, gg = _raw_like(x), [_raw_like(g) for g in grow]
         # 16-bit storage: a segment's gradient is the sum over its (up to five) consuming layers -- kept in fp32 until the
         # last consumer has added its part, then rounded ONCE into gx / gg (csrc/bn.hip bn_bwd_apply_kernel, acc32)
         acc32 = dt != L.F32 and ACC32
         if acc32:
-            sx = torch.empty(x.shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-            sg = [torch.empty(g.shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last) for g in grow]
+            sx = _raw(x.shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+            sg = [_raw(g.shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last) for g in grow]
         grads = [None] * 20
         # The gradient of a feature segment (the block input x, a growth map g_s) is the sum of the BatchNorm-ReLU backward
         # terms of every layer that consumed it.  Each layer's da (gradient w.r.t. its activated input) is written ONE PLANE PER
@@ -565,7 +600,7 @@ class _DenseFn(torch.autograd.Function):
             gsegs = [gx] + gg[:l]
             if l == 4:
                 cout, cout_st, ks, dy = w.shape[0], dz.shape[1], 1, dz
-                mean_dy = torch.empty(2, cout_st, dtype=torch.float32, device=dev)
+                mean_dy = _raw(2, cout_st, dtype=torch.float32, device=dev)
                 _Bn.stats(dt, dy, mean_dy[0], mean_dy[1])
                 grads[4 * l + 3] = torch.mul(mean_dy[0, :cout], N, out=_gout(ctx.params[4 * l + 3], (cout,), dev))   # the only bias here that is not followed by a BatchNorm
             else:
@@ -574,12 +609,12 @@ class _DenseFn(torch.autograd.Function):
             # gradient w.r.t. the activated input a = relu(bn(cat(segs)))
             planar = not acc32
             fuse = planar and BN_REDUCE_IN_DGRAD
-            da = torch.empty(cin_st // 16, N, 16, dtype=td, device=dev) if planar else _empty(dt, B, cin_st, H, W, dev)
+            da = _raw(cin_st // 16, N, 16, dtype=td, device=dev) if planar else _empty(dt, B, cin_st, H, W, dev)
             dgb = (_gout(ctx.params[4 * l], (cin_real,), dev), _gout(ctx.params[4 * l + 1], (cin_real,), dev))
-            coef = torch.empty(2, cin_st, dtype=torch.float32, device=dev)
+            coef = _raw(2, cin_st, dtype=torch.float32, device=dev)
             if fuse:    # the BatchNorm-ReLU backward sums come out of the input-gradient convolution's epilogue (mdie_conv_desc.bnred)
                 nslab = L.lib.mdie_conv_bnred_slabs(B, H, W, cin_st)
-                partial = torch.empty(nslab, 2, cin_st, dtype=torch.float32, device=dev)
+                partial = _raw(nslab, 2, cin_st, dtype=torch.float32, device=dev)
                 bnred = (segs, k[0], k[1], partial)
             else:
                 bnred = None
@@ -598,7 +633,7 @@ class _DenseFn(torch.autograd.Function):
                 L.check(L.lib.mdie_bn_bwd_finish(C.byref(f), _sp(dev)), "mdie_bn_bwd_finish")
             else:
                 nws = L.lib.mdie_bn_workspace_bytes(cin_st)
-                ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+                ws = _raw(nws, dtype=torch.uint8, device=dev)
                 d.dtype, d.N, d.nseg = dt, N, len(segs)
                 for i, (sgm, g) in enumerate(zip(segs, gsegs)):
                     ptr, c, st = _nhwc(sgm)
@@ -661,7 +696,7 @@ class _DeconvFn(torch.autograd.Function):
         w32 = _f32(weight)
         y = _empty(dt, B, cout_st, H, W, dev)
         _conv_raw(dt, [x], _pack(dt, w32, 3, True, cout, cin, cout_st, cin), _pad_vec(bias, cout_st), 3, cout_st, y)
-        mv = torch.empty(2, cout_st, dtype=torch.float32, device=dev)
+        mv = _raw(2, cout_st, dtype=torch.float32, device=dev)
         k = _Bn.stats_fold(dt, y, mv, 0, cout_st, cout, cout_st, 0, bn, 0.1)
         Ho, Wo = (2 * H, 2 * W) if up else (H, W)
         out = _empty(dt, B, cout_st, Ho, Wo, dev)
@@ -681,11 +716,11 @@ class _DeconvFn(torch.autograd.Function):
         B, _, H, W = x.shape
         dev, td = x.device, E.TORCH_DTYPE[dt]
         d_out = _cl(d_out.to(td))
-        dz = torch.empty_like(y)
+        dz = _raw_like(y)
         dgb = (_gout(ctx.gparams[0], (cout,), dev), _gout(ctx.gparams[1], (cout,), dev))
-        coef = torch.empty(2, cout_st, dtype=torch.float32, device=dev)
+        coef = _raw(2, cout_st, dtype=torch.float32, device=dev)
         nws = L.lib.mdie_bn_workspace_bytes(cout_st)
-        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        ws = _raw(nws, dtype=torch.uint8, device=dev)
         if up:
             d = L.BnUpBwdDesc()
             d.dout, d.dout_stride = d_out.data_ptr(), cout_st
@@ -816,7 +851,6 @@ def deconv_stage(dt, cv, bn, x, skip, up):
     return _DeconvFn.apply(x, cv.weight, cv.bias, bn.weight, bn.bias, skip, bn, dt, up)
 
 
-_DEBUG_POISON = None     # tools/race_hunt_train.py: byte value the CBAM workspaces are filled with (None: left as allocated)
 
 
 class _CbamFn(torch.autograd.Function):
@@ -826,18 +860,16 @@ class _CbamFn(torch.autograd.Function):
     def forward(ctx, x, mul, w1, b1, w2, b2, w7, gamma, beta, bn, dt):
         B, Cc, H, W = x.shape
         dev = x.device
-        f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        f32 = lambda *shape: _raw(*shape, dtype=torch.float32, device=dev)
         gate, pooled, comp, smap, bnc = f32(B, Cc), f32(B, 2, Cc), f32(B, H, W, 2), f32(B, H, W), f32(4)
-        amax = torch.empty(B, Cc, dtype=torch.int32, device=dev)
-        out = torch.empty_like(x)
+        amax = _raw(B, Cc, dtype=torch.int32, device=dev)
+        out = _raw_like(x)
         params = [_f32(p) for p in (w1, b1, w2, b2, w7, gamma, beta)]
         d = _CbamFn._desc(dt, x, mul, params, gate, amax, pooled, comp, smap, bnc)
         d.out, d.out_stride = out.data_ptr(), out.stride(3)
         d.running_mean, d.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
         nws = L.lib.mdie_cbam_train_workspace_bytes(B, H, W, Cc)
-        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        if _DEBUG_POISON is not None:
-            ws.fill_(_DEBUG_POISON)
+        ws = _raw(nws, dtype=torch.uint8, device=dev)
         d.workspace, d.workspace_bytes = ws.data_ptr(), nws
         L.check(L.lib.mdie_cbam_train_fwd(C.byref(d), _sp(dev)), "mdie_cbam_train_fwd")
         ctx.save_for_backward(x, mul, gate, amax, pooled, comp, smap, bnc, *params)
@@ -868,8 +900,8 @@ class _CbamFn(torch.autograd.Function):
         dev = x.device
         d_out = _cl(d_out.to(E.TORCH_DTYPE[dt]))
         d = _CbamFn._desc(dt, x, mul, params, gate, amax, pooled, comp, smap, bnc)
-        dx = torch.empty_like(x)
-        dmul = torch.empty_like(mul) if mul is not None else None
+        dx = _raw_like(x)
+        dmul = _raw_like(mul) if mul is not None else None
         grads = [_gout(pp, p.shape, dev) for pp, p in zip(ctx.pparams, params)]
         d.dout, d.dout_stride = d_out.data_ptr(), d_out.stride(3)
         d.dx, d.dx_stride = dx.data_ptr(), dx.stride(3)
@@ -877,9 +909,7 @@ class _CbamFn(torch.autograd.Function):
             d.dmul, d.dmul_stride = dmul.data_ptr(), dmul.stride(3)
         d.dw1, d.db1, d.dw2, d.db2, d.dw7, d.dgamma, d.dbeta = [g.data_ptr() for g in grads]
         nws = L.lib.mdie_cbam_train_workspace_bytes(B, H, W, Cc)
-        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        if _DEBUG_POISON is not None:
-            ws.fill_(_DEBUG_POISON)
+        ws = _raw(nws, dtype=torch.uint8, device=dev)
         d.workspace, d.workspace_bytes = ws.data_ptr(), nws
         L.check(L.lib.mdie_cbam_train_bwd(C.byref(d), _sp(dev)), "mdie_cbam_train_bwd")
         return (dx, dmul, *grads, None, None)
@@ -960,21 +990,33 @@ class CapturedStep:
     GradScaler.scale) is applied to the total loss before backward inside the graph -- the scaler's factor is a device
     tensor, so replays follow its updates.
 
-    Gradients: the captured backward writes into gradient tensors of the graph's private pool.  Each CapturedStep keeps
+    Data parallel (`buckets`: a GradBuckets): the gradient exchange is INSIDE the graph.  The buckets' post-accumulate hooks fire while
+    the backward is captured, so each bucket's all-reduce is recorded at the point of the backward where its last gradient has been
+    produced -- `torch.distributed`'s NCCL (= RCCL) process group forks its communication stream from the capturing stream there -- and
+    `finish()` records the join in front of the optimizer step: every replay overlaps the collectives with the rest of backward exactly as
+    an eager hook-driven step does, with no host work at all.  The eager warm-up steps run the same collectives (every rank builds its
+    CapturedStep at the same batch, so the calls match up across ranks).
+
+    Gradients: the captured backward writes into gradient tensors of the graph's private pool (or into the bucket slices).  Each CapturedStep keeps
     its own (`self.grads`) and re-points every `p.grad` at them after a replay, so whatever reads `p.grad` next -- the
     gradient exchange, `GradScaler.step`, an eager optimizer step -- sees THIS replay's gradients no matter which other
     shape was captured or which eager step (`zero_grad(set_to_none=True)`) ran in between."""
 
-    def __init__(self, net, losses, optimizer, x, t, warmup=2, scale_fn=None):
+    def __init__(self, net, losses, optimizer, x, t, warmup=2, scale_fn=None, buckets=None):
         dev = x.device
         self.net, self.losses, self.opt = net, losses, optimizer
         self.x, self.t = x.clone(), t.clone()
         self.params = [p for p in net.parameters() if p.requires_grad]
+        self.buckets = buckets
+        if buckets is not None:
+            buckets.attach()       # the hooks fire while the backward is being CAPTURED: each bucket's collective becomes a branch of the graph
 
         def fwd_bwd():
             total, values = losses(net(self.x), self.t)
             (scale_fn(total) if scale_fn is not None else total).backward()
             join_weight_gradients(dev)
+            if buckets is not None:
+                buckets.finish()   # the capturing stream joins the communication stream; .grad = the averaged slices
             return values
 
         targets = list(net.buffers())           # what a training-mode forward advances besides the parameters
@@ -1073,6 +1115,8 @@ class GradBuckets:
         self._pending = [len(b) for b in self.buckets]
         self._work = [None] * len(self.buckets)
         self._hooks = []
+        self._claim_task, self._claimed = None, set()
+        self.trace = None             # tests: a list that receives ("grad", bucket) per arriving gradient and ("launch", bucket) per collective issued
         self.copies_in = 0            # gradients that had to be copied into their slice (diagnostic: 0 on the engine's own training path)
         self.activate()
         self.attach()
@@ -1087,6 +1131,18 @@ class GradBuckets:
         self.remove()
         if _GRAD_SINK is self:
             _GRAD_SINK = None
+
+    def claim(self, p):
+        """True the first time parameter `p` asks for its slice inside the running backward (one autograd graph task)"""
+        task = _graph_task()
+        if task is None or task < 0:
+            return False
+        if self._claim_task != task:
+            self._claim_task, self._claimed = task, set()
+        if id(p) in self._claimed:
+            return False
+        self._claimed.add(id(p))
+        return True
 
     def _slice(self, p):
         w = self._where.get(p)
@@ -1131,6 +1187,8 @@ class GradBuckets:
         self._hooks = []
 
     def _launch(self, bi):
+        if self.trace is not None:
+            self.trace.append(("launch", bi))
         flat = self.flat[bi]
         side = _WGRAD_SIDE.get(flat.device) if (flat.is_cuda and _wgrad_side_this_step and WGRAD_STREAM) else None
         if side is not None:          # dW kernels of this bucket may be on the side stream: order the collective behind both streams
@@ -1142,6 +1200,8 @@ class GradBuckets:
 
     def _on_grad(self, p):
         bi, off = self._where[p]
+        if self.trace is not None:
+            self.trace.append(("grad", bi))
         if not self.is_view(p, p.grad):
             self.flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
             self._dirty.add(p)

@@ -202,7 +202,32 @@ def _sink_worker(rank, world, port, q):
             means.append(sum(parts) / world)
         out[step] = (all(views_before), all(buckets.is_view(p, p.grad) for p in params + [frozen_bias]),
                      all(torch.allclose(p.grad, m, atol=1e-6) for p, m in zip(params, means)), float(frozen_bias.grad.abs().max()))
-    q.put((rank, out, buckets.copies_in))
+    copies_two_steps = buckets.copies_in
+    # ---- one parameter, two gradients in ONE backward (the network applied twice in a graph, weight sharing): `.grad` is still None at
+    # the second producer while the first gradient -- the slice -- waits un-summed in autograd's input buffer.  The second sighting must
+    # get a fresh tensor (GradBuckets.claim); writing the slice again would make autograd add the slice to itself (2 x the second term)
+    for p in params + [frozen_bias]:
+        p.grad = None
+    xa, xb = xs[1], torch.randn(4, params[1].numel(), generator=g)
+    buckets.trace = []
+    (Scale.apply(xa, params[1]).sum() + 3.0 * Scale.apply(xb, params[1]).sum() + sum(Scale.apply(x, p).sum() for x, p in zip(xs, params))).backward()
+    trace = list(buckets.trace)
+    buckets.trace = None
+    twice_local = 2 * xa.sum(0) + 3.0 * xb.sum(0)
+    twice_ok_before = torch.allclose(params[1].grad, twice_local, atol=1e-5)
+    buckets.finish()
+    parts = [torch.zeros_like(twice_local) for _ in range(world)]
+    dist.all_gather(parts, twice_local)
+    twice_ok_after = torch.allclose(params[1].grad, sum(parts) / world, atol=1e-5) and buckets.is_view(params[1], params[1].grad)
+    # ---- overlap: the first bucket's collective is issued while later gradients are still to come (parameters are bucketed in reverse
+    # registration order; the last-registered parameters' gradients arrive first)
+    first_launch = next(i for i, e in enumerate(trace) if e[0] == "launch")
+    last_grad = max(i for i, e in enumerate(trace) if e[0] == "grad")
+    # ---- outside an engine-run backward nothing is claimed: a direct call gets a fresh tensor, never bucket memory
+    params[0].grad = None
+    direct = T._gout(params[0], params[0].shape, params[0].device)
+    q.put((rank, out, copies_two_steps, (twice_ok_before, twice_ok_after, first_launch < last_grad, len([e for e in trace if e[0] == "launch"]),
+                                         not buckets.is_view(params[0], direct))))
     buckets.close()
     assert T._GRAD_SINK is None
     dist.barrier()
@@ -223,11 +248,15 @@ def test_gradients_are_views_of_the_flat_buckets_two_ranks():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, out, copies in res:
+    for rank, out, copies, (twice_before, twice_after, launched_before_last_grad, n_launch, direct_is_fresh) in res:
         for step in (0, 1):
             views_before, views_after, mean_ok, zero_max = out[step]
             assert views_before and views_after and mean_ok and zero_max == 0.0
         assert copies == 2          # frozen_bias's autograd-made gradient, once per step; the four sink-aware gradients never
+        assert twice_before, "two gradients of one parameter in one backward: .grad must be their sum"
+        assert twice_after, "... and after the exchange the two-rank mean of that sum, living in the bucket"
+        assert launched_before_last_grad and n_launch >= 1, "the first bucket's all-reduce must be issued before the last gradient of backward arrives"
+        assert direct_is_fresh, "outside a backward _gout must not hand out bucket memory"
 
 
 def _routed_worker(rank, world, port, q):

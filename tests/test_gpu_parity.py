@@ -550,10 +550,11 @@ def test_transition_folded_into_its_producers(E, L, precision, shape):
 
     def run(fold, half=False):
         # half: the base stored as HALF a 16-byte group (4 channels per pixel, mdie_seg / base_stride: ABI 24) -- the chain's 16-byte column
-        # loads then read the NEXT pixel's bytes into channels 4..7, whose weights are zero (one spare pixel behind the buffer, filled with a
-        # large finite value: it must not reach any output)
+        # loads then read the NEXT pixel's bytes into channels 4..7, whose weights are zero.  The bytes behind the LAST pixel are the
+        # producer's to define (0 * NaN is NaN): the buffer -- spare pixel included -- starts as NaN, mdie_up_add_dense0_fwd must zero
+        # the 8 bytes its consumers will read, and nothing non-finite may reach an output
         bs_ = 4 if half else 8
-        base_buf = torch.full((B * H * W + 1, bs_), 3.0e4, device="cuda", dtype=td)
+        base_buf = torch.full((B * H * W + 1, bs_), float("nan"), device="cuda", dtype=td)
         base = base_buf[:B * H * W].view(B, H, W, bs_)
         gs = [torch.full((B, H, W, 16), -7.0, device="cuda", dtype=td) for _ in range(4)]
         y = torch.full((B, 3, H, W), -1.0, device="cuda")
@@ -611,6 +612,7 @@ def test_transition_folded_into_its_producers(E, L, precision, shape):
     base_f, gs_f, y_f = run(True)
     base_h, gs_h, y_h = run(True, half=True)
     assert torch.equal(base_h[..., :3], base_f[..., :3]) and (base_h[..., 3] == 0).all()
+    assert torch.isfinite(y_h).all(), "the NaN behind the half-group buffer's last pixel reached the output: its producer must zero those 8 bytes"
     assert torch.equal(y_h, y_f) and all(torch.equal(gs_h[l], gs_f[l]) for l in range(3)), "the half-group base must not change a bit"
     assert torch.equal(base_u, base_f)
     for l in range(3):
@@ -846,6 +848,37 @@ def test_thin_single_chunk_conv(E, L, prec, cin_segs, shape, pre):
     torch.cuda.synchronize()
     assert rel_to_max(out[..., 16:32], ref) <= {"fp32": 2e-5, "bf16": 8e-3, "fp16": 1e-3}[prec]
     assert (out[..., :16] == -7.0).all() and (out[..., 32:] == -7.0).all()     # nothing written outside the slice
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 40, 72), (3, 128, 160)])
+def test_forward_does_not_depend_on_what_the_workspace_held(E, prec, shape):
+    """The workspace arena is `torch.empty` and outlives plans: every byte a launch READS must have been written by an earlier launch of the
+    same forward.  The arena is filled with 0xFF (NaN in all three element types; as fp32 partials too) and then with 0x7F / 0x00 between
+    forwards: the outputs must be bit-identical and finite.  Covers the half-group base of decoder.final_dense (whose last 16-byte load
+    reads 8 bytes behind the last stored pixel: zero weights do not neutralise a NaN), pooled partials, the transition's fp32 partials and
+    every padding lane of the wide kernels.  Also: the per-launch byte model sums to mdie_cdan_algorithmic_bytes (bench.py reports a
+    mismatch instead of asserting it)."""
+    from oracle import params as P
+    sd = P.make_state_dict(42)
+    x, _ = P.lowlight_batch(33, *shape)
+    x = x.cuda()
+    eng = E.CdanEngine("cuda", prec).load(sd)
+    y0 = eng.forward(x, out=torch.empty_like(x)).clone()
+    outs = []
+    for fill in (0xFF, 0x7F, 0x00):
+        eng._ws.fill_(fill)
+        outs.append(eng.forward(x, out=torch.empty_like(x)).clone())
+    torch.cuda.synchronize()
+    assert torch.isfinite(y0).all()
+    for fill, y in zip((0xFF, 0x7F, 0x00), outs):
+        assert torch.isfinite(y).all(), f"workspace pre-filled with {fill:#x}: non-finite output"
+        assert torch.equal(y, y0), f"workspace pre-filled with {fill:#x}: the output changed"
+    from mdie_amd import lib as LL
+    _, ex = eng.forward(x, profile=True)
+    esz = 4 if prec == "fp32" else 2
+    alg = LL.lib.mdie_cdan_algorithmic_bytes(shape[0], shape[1], shape[2], esz)
+    assert abs(sum(b for _, b, _ in ex["launch_info"]) - alg) <= 1e-6 * alg
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
@@ -2460,7 +2493,54 @@ def test_ddp_one_rank_nccl_gradients_live_in_the_buckets(E, monkeypatch):
         torch.cuda.synchronize()
         assert buckets.copies_in == 0 and all(torch.equal(p.grad, b) for p, b in zip(net.parameters(), before))
         buckets.close()
+        del cap
+
+        # the exchange INSIDE the captured step (what host.Model.train runs under world > 1 at launch-bound sizes): the hooks fire while the
+        # backward is captured, each bucket's all-reduce is a branch of the graph, finish() is the join in front of the captured Adam step.
+        # Two replays on two batches: losses and parameters bit-identical to the captured step without any exchange (world size 1)
+        def captured(with_buckets):
+            torch.manual_seed(5)
+            net = CDAN(precision="bf16")
+            net.load_state_dict(sd, strict=True)
+            net = net.cuda().train()
+            opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=True)
+            bk = T.GradBuckets(net.parameters()) if with_buckets else None
+            cap = T.CapturedStep(net, losses, opt, x, t, buckets=bk)
+            vals = [cap(xb, tb).clone() for xb, tb in batches]
+            torch.cuda.synchronize()
+            res = (vals, [p.detach().clone() for p in net.parameters()],
+                   bk is None or (bk.copies_in == 0 and all(bk.is_view(p, p.grad) for p in net.parameters())))
+            if bk is not None:
+                bk.close()
+            del cap
+            return res
+        ref_c, got_c = captured(False), captured(True)
+        assert got_c[2], "in-graph exchange: a gradient was copied or .grad is not bucket memory"
+        assert all(torch.equal(u, v) for u, v in zip(got_c[0], ref_c[0])) and all(torch.equal(u, v) for u, v in zip(got_c[1], ref_c[1]))
+
+        # one parameter, two gradients in one backward (the network applied twice) with the sink active: the second sighting must not
+        # overwrite the slice the first, un-summed gradient lives in (GradBuckets.claim) -- gradients equal to the run without buckets
+        def twice(with_buckets):
+            net = CDAN(precision="bf16")
+            net.load_state_dict(sd, strict=True)
+            net = net.cuda().train()
+            net.dropout_p = 0.0
+            bk = T.GradBuckets(net.parameters()) if with_buckets else None
+            (x1, t1), (x2, t2) = batches
+            (torch.sqrt((net(x1) - t1) ** 2 + 1e-6).mean() + torch.sqrt((net(x2) - t2) ** 2 + 1e-6).mean()).backward()
+            if bk is not None:
+                bk.finish()
+            torch.cuda.synchronize()
+            g = [p.grad.clone() for p in net.parameters()]
+            if bk is not None:
+                bk.close()
+            return g
+        ga, gb = twice(False), twice(True)
+        bad = [i for i, (u, v) in enumerate(zip(ga, gb)) if not torch.equal(u, v)]
+        assert not bad, f"network applied twice under the gradient sink: {len(bad)} gradients differ from the run without buckets"
+        assert T._GRAD_SINK is None
     finally:
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -50,24 +50,26 @@ peak_tf = 157.3 if prec == "fp32" else 2500.0
 variants = [(m, "overlap") for m in modes]
 if dist is not None and "eager" in modes:
     variants += [("eager", "none"), ("eager", "after")]     # the same step without the exchange, and with it after backward (nothing overlapped)
+if dist is not None and "graph" in modes:
+    variants += [("graph", "none"), ("graph", "after")]     # round 4's form: the five collectives behind the replay
 for mode, comm in variants:
     torch.manual_seed(42)
     net = CDAN(precision=prec).cuda().train()
     scaler = torch.amp.GradScaler("cuda", enabled=prec == "fp16")
-    whole = mode == "graph" and dist is None and not scaler.is_enabled()
+    in_graph = mode == "graph" and comm == "overlap"         # the collectives are branches of the captured step (train.CapturedStep, buckets=)
+    whole = mode == "graph" and (dist is None or in_graph or comm == "none") and not scaler.is_enabled()
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=whole, fused=os.environ.get("ADAM_FUSED", "1") == "1")
     buckets = T.GradBuckets(net.parameters()) if (dist is not None and comm != "none") else None
     if buckets is not None and comm == "after":
         buckets.remove()
     if mode == "graph":
-        if buckets is not None:
-            buckets.remove()
-        cap = T.CapturedStep(net, losses, opt if whole else None, x, t, scale_fn=scaler.scale if scaler.is_enabled() else None)
+        cap = T.CapturedStep(net, losses, opt if whole else None, x, t, scale_fn=scaler.scale if scaler.is_enabled() else None,
+                             buckets=buckets if in_graph else None)
 
         def step():
             v = cap(x, t)
             if not whole:
-                if buckets is not None:
+                if buckets is not None and not in_graph:
                     buckets.exchange()
                 scaler.step(opt)
                 scaler.update()
@@ -93,7 +95,7 @@ for mode, comm in variants:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     if buckets is not None:
-        note = f" | exchange: {comm}, {len(buckets.buckets)} buckets, {buckets.copies_in} gradient copies into buckets over {n + 3} steps"
+        note = f" | exchange: {'overlapped' if comm == 'overlap' else comm}{' (inside the graph)' if mode == 'graph' and comm == 'overlap' else ''}, {len(buckets.buckets)} buckets, {buckets.copies_in} gradient copies into buckets over {n + 3} steps"
         buckets.close()
     else:
         note = " | no gradient exchange" if dist is not None else ""

@@ -1,4 +1,4 @@
-// Stream-capture probe for ROCm 7.2 / gfx950: which fork/join shapes survive hipStreamEndCapture?
+// Stream-capture probe for ROCm 7.2 / gfx950: which fork/join shapes survive hipStreamEndCapture -- and (round 5) hipGraphLaunch?
 // Background: capturing mdie_cdan_forward (which forks its encoder DenseBlocks onto side streams) from a stream that is
 // itself a fork inside a capture took the process down in hipStreamEndCapture (round 1, tools/bench_streams.py).  Each
 // variant below runs in its own child process (forked BEFORE any HIP call), so a crash in one is just a result line.
@@ -11,6 +11,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <thread>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("    %s -> %s\n", #x, hipGetErrorString(e_)); fflush(stdout); return 10; } } while (0)
@@ -133,6 +134,66 @@ static int twice(int mode, int destroy_side) {
   return 0;
 }
 
+// Round 4's hipGraphLaunch segfault (profiles/r04e_graph_replay_segfault.log): RoutedEngine's "groups" mode had captured ONE graph per
+// task group -- nine graphs of ~39 kernel nodes, each with the engine's fork-join expressed through hipStreamUpdateCaptureDependencies
+// -- and replayed them in a row on nine streams (torch.cuda.CUDAGraph.replay from worker threads).  The pure-HIP shape of that:
+//   threads = 0: the nine graphs launched round-robin from ONE host thread, 200 rounds;  threads = 1: nine host threads, one graph each.
+__global__ void inc(float* p, float v, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] += v; }
+
+static int nine(int threads) {
+  CK(hipSetDevice(0));
+  constexpr int G = 9, ROUNDS = 200;
+  hipStream_t st[G]; hipGraphExec_t ex[G]; float* buf[G];
+  size_t nodes = 0;
+  for (int g = 0; g < G; ++g) {
+    CK(hipStreamCreateWithFlags(&st[g], hipStreamNonBlocking));
+    CK(hipMalloc(&buf[g], (size_t)4 * N * sizeof(float)));
+    CK(hipMemset(buf[g], 0, (size_t)4 * N * sizeof(float)));
+  }
+  CK(hipDeviceSynchronize());
+  for (int g = 0; g < G; ++g) {
+    hipStream_t s = st[g];
+    float *m = buf[g], *b0 = buf[g] + N, *b1 = buf[g] + 2 * N, *b2 = buf[g] + 3 * N;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    for (int k = 0; k < 10; ++k) hipLaunchKernelGGL(inc, dim3(N / 256), dim3(256), 0, s, m, 1.f, N);
+    hipStreamCaptureStatus cs; unsigned long long id; hipGraph_t gr; const hipGraphNode_t* deps; size_t nd;
+    CK(hipStreamGetCaptureInfo_v2(s, &cs, &id, &gr, &deps, &nd));
+    std::vector<hipGraphNode_t> at_fork(deps, deps + nd), tails;
+    float* br[3] = {b0, b1, b2};
+    for (int b = 0; b < 3; ++b) {       // three side branches (the encoder DenseBlocks), each captured on s and then detached
+      for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(inc, dim3(N / 256), dim3(256), 0, s, br[b], (float)(b + 1), N);
+      CK(hipStreamGetCaptureInfo_v2(s, &cs, &id, &gr, &deps, &nd));
+      tails.insert(tails.end(), deps, deps + nd);
+      CK(hipStreamUpdateCaptureDependencies(s, at_fork.data(), at_fork.size(), hipStreamSetCaptureDependencies));
+    }
+    for (int k = 0; k < 9; ++k) hipLaunchKernelGGL(inc, dim3(N / 256), dim3(256), 0, s, m, 1.f, N);
+    CK(hipStreamUpdateCaptureDependencies(s, tails.data(), tails.size(), hipStreamAddCaptureDependencies));
+    for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(sum3, dim3(N / 256), dim3(256), 0, s, b0, b1, b2, m, N);   // m = 5 + 10 + 15 = 30 (after the join)
+    hipGraph_t graph;
+    CK(hipStreamEndCapture(s, &graph));
+    size_t nn = 0; CK(hipGraphGetNodes(graph, nullptr, &nn)); nodes = nn;
+    CK(hipGraphInstantiate(&ex[g], graph, nullptr, nullptr, 0));
+  }
+  printf("    nine graphs of %zu nodes instantiated\n", nodes); fflush(stdout);
+  // (the branch buffers accumulate over replays: a replay r leaves b = 5 (b+1) r, m = 30 r -- any lost dependency shows)
+  if (!threads) {
+    for (int r = 0; r < ROUNDS; ++r) for (int g = 0; g < G; ++g) CK(hipGraphLaunch(ex[g], st[g]));
+  } else {
+    std::vector<std::thread> th; int rc[G] = {};
+    for (int g = 0; g < G; ++g) th.emplace_back([&, g] { for (int r = 0; r < ROUNDS; ++r) if (hipGraphLaunch(ex[g], st[g]) != hipSuccess) { rc[g] = 1; return; } });
+    for (auto& t : th) t.join();
+    for (int g = 0; g < G; ++g) if (rc[g]) { printf("    hipGraphLaunch failed in thread %d\n", g); return 13; }
+  }
+  CK(hipDeviceSynchronize());
+  std::vector<float> h(N);
+  for (int g = 0; g < G; ++g) {
+    CK(hipMemcpy(h.data(), buf[g], N * sizeof(float), hipMemcpyDeviceToHost));
+    for (int j = 0; j < N; ++j) if (h[j] != 30.f * ROUNDS) { printf("    graph %d: wrong value %f at %d (want %f)\n", g, h[j], j, 30.f * ROUNDS); return 12; }
+  }
+  printf("    ok: %d rounds of nine replays, values right\n", ROUNDS);
+  return 0;
+}
+
 int main() {
   struct V { int outer, mode, nb; const char* what; } vs[] = {
     {0, 0, 1, "fork from the ORIGIN stream through a non-blocking side stream (what bench.py captures)"},
@@ -151,6 +212,15 @@ int main() {
     printf("[T%d] %s\n", k++, w.what); fflush(stdout);
     const pid_t pid = fork();
     if (pid == 0) { const int rc = twice(w.mode, w.destroy); fflush(stdout); _exit(rc); }
+    int st = 0; waitpid(pid, &st, 0);
+    if (WIFSIGNALED(st)) printf("    => KILLED by signal %d (%s)\n", WTERMSIG(st), strsignal(WTERMSIG(st)));
+    else printf("    => exit code %d\n", WEXITSTATUS(st));
+    fflush(stdout);
+  }
+  for (int threads = 0; threads < 2; ++threads) {
+    printf("[N%d] nine ~39-node graphs with capture-dependency fork-joins, replayed on nine streams from %s\n", threads, threads ? "NINE host threads" : "ONE host thread"); fflush(stdout);
+    const pid_t pid = fork();
+    if (pid == 0) { const int rc = nine(threads); fflush(stdout); _exit(rc); }
     int st = 0; waitpid(pid, &st, 0);
     if (WIFSIGNALED(st)) printf("    => KILLED by signal %d (%s)\n", WTERMSIG(st), strsignal(WTERMSIG(st)));
     else printf("    => exit code %d\n", WEXITSTATUS(st));
