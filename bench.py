@@ -178,24 +178,24 @@ def routed_labels(step, n, seed=0):
 
 
 def routed_main(args, rank, world, dev, dist, P):
-    """BASELINE configs[3]: classifier-routed mixed degradations.  One step = one global batch of --batch x N images; tasks are
-    dealt to ranks (engine.routed_shard), every rank holds only its tasks' weight sets and runs its images' task groups
-    concurrently (one stream and one enqueueing host thread per group); no data-path collective.  Labels are a stub router's (seeded, a different
-    grouping every step, 16 distinct batches cycled); the router network itself is timed by tools/bench_configs.py."""
+    """BASELINE configs[3]: classifier-routed mixed degradations.  One step = one global batch of --batch x N images, each image run with its
+    task's weights by ONE launch chain per rank (engine.RoutedEngine); no data-path collective.  --routed-shard slices (default): every
+    rank holds all nine weight sets (9 x 7 MB) and takes an equal contiguous slice of the batch whatever the labels; tasks: the TASKS are
+    dealt to ranks, a rank holds only its tasks' weight sets and an image follows its task (engine.routed_shard).  Labels are
+    a stub router's (seeded, a different grouping every step, 16 distinct batches cycled); the router network itself is timed by
+    tools/bench_configs.py."""
     from mdie_amd import engine as E
     B, S, n_lists = args.batch * world, args.size, 16
-    mode = args.routed_mode
-    eng = E.RoutedEngine(dev, args.precision, mode=mode)
-    # "chain": every rank holds all nine weight sets (9 x 7 MB) and takes an equal slice of the global batch -- one launch chain per
-    # rank whatever the labels.  "groups": tasks dealt to ranks, images follow their task (engine.routed_shard)
-    mine_tasks = sorted(ROUTED_TASKS) if mode == "chain" else [t for i, t in enumerate(sorted(ROUTED_TASKS)) if i % world == rank]
+    by_task = args.routed_shard == "tasks"
+    eng = E.RoutedEngine(dev, args.precision)
+    mine_tasks = [t for i, t in enumerate(sorted(ROUTED_TASKS)) if i % world == rank] if by_task else sorted(ROUTED_TASKS)
     for t in mine_tasks:
         eng.load_task(t, P.make_state_dict(100 + ROUTED_TASKS.index(t)))
     x_all, _ = P.lowlight_batch(2000, B, S, S)
     batches = []
     for k in range(n_lists):
         labels = routed_labels(k, B)
-        idx = E.routed_slice(B, rank, world) if mode == "chain" else E.routed_shard(labels, rank, world, ROUTED_TASKS)
+        idx = E.routed_shard(labels, rank, world, ROUTED_TASKS) if by_task else E.routed_slice(B, rank, world)
         batches.append((x_all[idx].to(dev), [labels[i] for i in idx]))
     it = [0]
 
@@ -217,10 +217,9 @@ def routed_main(args, rank, world, dev, dist, P):
                           "config": {"workload": f"BASELINE configs[3]: all config/*.json tasks as 9 seeded weight sets, {S}x{S}, global batch {B} labelled by a stub router "
                                                  f"(a different grouping every step), {args.precision} storage + fp32 accumulate",
                                      "global_batch": B,
-                                     "parallelism": (f"{world} rank(s), each holds all 9 weight sets and an equal slice of the batch, no collective" if mode == "chain"
-                                                     else f"tasks dealt to {world} rank(s), images follow their task, no collective"),
-                                     "launch": ("eager, ONE launch chain per rank-batch: every kernel looks up its image's weight set (mdie_cdan_fwd_desc.blob_delta)"
-                                                if mode == "chain" else "eager, one stream + one enqueueing host thread per task group"),
+                                     "parallelism": (f"tasks dealt to {world} rank(s), images follow their task, no collective" if by_task
+                                                     else f"{world} rank(s), each holds all 9 weight sets and an equal slice of the batch, no collective"),
+                                     "launch": "eager, ONE launch chain per rank-batch: every kernel looks up its image's weight set (mdie_cdan_fwd_desc.blob_delta)",
                                      "runtime": getattr(args, "runtime", None)}}))
     if dist is not None:
         dist.destroy_process_group()
@@ -231,7 +230,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--routed-mode", choices=["chain", "groups"], default="chain", help="--workload routed: one launch chain (default) or task groups on streams")
+    ap.add_argument("--routed-shard", choices=["slices", "tasks"], default="slices", help="--workload routed under N ranks: equal slices of the batch (default) or tasks dealt to ranks")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])

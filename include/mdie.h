@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 24
+#define MDIE_ABI_VERSION 25
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1,
        MDIE_F16 = 2 /* IEEE half: the reference's mixed-precision dtype (torch.cuda.amp.autocast, models/model.py:15,159) */ };
@@ -293,28 +293,6 @@ typedef struct {
   int64_t numel;
 } mdie_tensor;
 
-/* ---------------------------------------------------------------------------------
- * Fused decoder tail:  y = sigmoid( DenseBlock(3,3,16,4)( bilinear_x2(lo) + x ) )
- * = F.interpolate + torch.add (models/cdan.py:153-154), decoder.final_dense (:119,156;
- * layer recipes :41-53) and nn.Sigmoid (:157) in one kernel; the four growth maps stay in LDS.
- *   lo : NHWC [B,H/2,W/2,lo_stride] (channels 0..2 used), or NULL for a plain DenseBlock(3,..)
- *   x,y: fp32 NCHW [B,3,H,W]
- *   params: device copy of mdie_tail_pack_params(prefix = the DenseBlock's state_dict prefix,
- *           e.g. "decoder.final_dense"; "" for a bare block)
- * --------------------------------------------------------------------------------- */
-typedef struct {
-  int dtype;
-  int B, H, W;
-  const void* lo;  int lo_stride;
-  const float* x;
-  float* y;
-  const void* params;
-} mdie_tail_desc;
-
-size_t mdie_tail_param_bytes(int dtype);
-int mdie_tail_pack_params(int dtype, const mdie_tensor* tensors, int n, const char* prefix, void* dst, size_t dst_bytes);
-int mdie_tail_fwd(const mdie_tail_desc* d, void* stream);
-
 /* out[B,2H,2W,C] = bilinear_x2(lo[B,H,W,C]) + skip  (F.interpolate(scale_factor=2, 'bilinear',
  * align_corners=False) + torch.add, models/cdan.py:137-138,145-146,153-154) */
 int mdie_upsample2x_add(int dtype, int B, int H, int W, int C, const void* lo, int lo_stride,
@@ -440,7 +418,8 @@ typedef struct {
                                    persistent kernels reload their weights where the offset changes along their run of tiles). */
 } mdie_cdan_fwd_desc;
 
-enum { MDIE_FWD_FUSED_TAIL = 1 /* run upsample + final_dense + sigmoid as ONE launch (mdie_tail_fwd) instead of 7 */,
+enum { /* 1: was MDIE_FWD_FUSED_TAIL (the whole decoder tail as one launch, round 1): 517 us against 387 for the chain it replaced,
+          removed in round 5 (ABI 25) */
        MDIE_FWD_SERIAL = 2     /* keep the encoder DenseBlocks in line with the main chain (no side streams, no graph branches) */,
        MDIE_FWD_GENERAL_TAIL = 4 /* decoder.final_dense as the general chain (3x3 layers, then the 1x1 launch) also where the transition
                                     could be folded into its producers (mdie_tr_fuse): the form fp32 and ragged extents always take */,
@@ -450,7 +429,7 @@ enum { MDIE_FWD_FUSED_TAIL = 1 /* run upsample + final_dense + sigmoid as ONE la
                                    section 8, round 4) */ };
 
 enum { MDIE_K_LAYOUT = 0, MDIE_K_CONV3 = 1, MDIE_K_CONV1 = 2, MDIE_K_CBAM_POOL = 3, MDIE_K_CBAM_GATE = 4,
-       MDIE_K_CBAM_CHANPOOL = 5, MDIE_K_CBAM_SPATIAL = 6, MDIE_K_UPSAMPLE = 7, MDIE_K_TAIL = 8, MDIE_K_COUNT = 9 };
+       MDIE_K_CBAM_CHANPOOL = 5, MDIE_K_CBAM_SPATIAL = 6, MDIE_K_UPSAMPLE = 7, MDIE_K_COUNT = 8 };
 
 int mdie_cdan_forward(const mdie_cdan_fwd_desc* d, void* stream);
 

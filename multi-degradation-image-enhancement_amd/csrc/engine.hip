@@ -96,7 +96,6 @@ struct BlobLayout {
   ConvBlob conv[CV_COUNT];
   CbamBlob cbam[CB_COUNT];
   size_t fl0_w;  // decoder.final_dense layer 0 once more, im2col-packed (k = tap*3 + c) for mdie_up_add_dense0_fwd
-  size_t tail;   // mdie_tail_pack_params("decoder.final_dense")
   size_t total;
 };
 
@@ -130,7 +129,6 @@ static BlobLayout blob_layout(int dtype) {
     L.cbam[i].bn = take(2 * sizeof(float));
   }
   L.fl0_w = take(first_weight_bytes(dtype, 16));
-  L.tail = take(mdie_tail_param_bytes(dtype));
   L.total = off;
   return L;
 }
@@ -350,7 +348,7 @@ extern "C" int mdie_cdan_pack_params(int dtype, const mdie_tensor* tensors, int 
     float bn[2] = {sc[0], sh[0]};
     memcpy(blob + L.cbam[i].bn, bn, 8);
   }
-  return mdie_tail_pack_params(dtype, tensors, n, "decoder.final_dense", blob + L.tail, mdie_tail_param_bytes(dtype));
+  return MDIE_OK;
 }
 
 extern "C" size_t mdie_cdan_workspace_bytes(int dtype, int B, int H, int W) {
@@ -789,7 +787,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     RUN(run_conv(c, "dec.conv4", CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
   }
   bool half_base = false;
-  if (!(d->flags & MDIE_FWD_FUSED_TAIL)) {
+  {
     // bilinear x2 + x (x read from its fp32 NCHW planes), final_dense, sigmoid written straight to NCHW
     // upsample + x and final_dense layer 0 in one launch (csrc/updense0.hip); then layers 1..3 and the transition.
     // 16-bit types on pictures of whole 16x16 tiles: the transition (BN -> ReLU -> Conv1x1 67 -> 3 -> sigmoid) is FOLDED into the
@@ -864,18 +862,6 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     } else {
       RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID, d->y, true));
     }
-  } else {
-    mdie_tail_desc t{};
-    t.dtype = d->dtype; t.B = B; t.H = H; t.W = W;
-    t.lo = c.ws + P.t4lo.off; t.lo_stride = P.t4lo.C;
-    t.x = d->x; t.y = d->y; t.params = c.params + c.L.tail;
-    const int from = notes.mark();
-    RUN(mdie_tail_fwd(&t, stream));                                                 // all of the above, one launch
-    if (notes.on()) {   // booked with what the general chain moves and computes (the fused launch moves less)
-      double el = 9.0 * 3 * PX / 4 + (3 + 64) * PX + 3 * PX, par = 67.0 * 3 + 3 + 2 * 67, fl = 2.0 * 67 * 3 * PX;
-      for (int l = 0; l < 4; ++l) { const double cin = 3 + 16.0 * l; el += cin * PX + 16 * PX; par += cin * 16 * 9 + 16 + 2 * cin; fl += 2.0 * cin * 16 * 9 * PX; }
-      notes.note(from, "up4+x+final_dense+sigmoid (fused tail)", el, par, fl);
-    }
   }
 #undef RUN
   if (d->taps) {
@@ -886,7 +872,6 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
     tap(MDIE_TAP_DEC1, P.u1, h3, w3); tap(MDIE_TAP_DEC2, P.u2, h2, w2); tap(MDIE_TAP_DEC3, P.u3, h1, w1);
     tap(MDIE_TAP_DEC4, P.t4, H, W);
     if (half_base) d->taps[MDIE_TAP_DEC4] = mdie_tap{c.ws + P.t4.off, 4, 4, H, W};   // (the folded chain stores 4 of the base group's 8 channels)
-    if (d->flags & MDIE_FWD_FUSED_TAIL) d->taps[MDIE_TAP_DEC4].ptr = nullptr;  // never materialised when fused
   }
   return MDIE_OK;
 }
@@ -926,7 +911,6 @@ extern "C" int mdie_cdan_forward(const mdie_cdan_fwd_desc* d, void* stream) {
                "mdie_cdan_forward: H, W must be multiples of 8 (three 2x2 pools + three x2 upsamples with skip adds), got %dx%d", d->H, d->W);
   MDIE_REQUIRE(d->params && d->x && d->y && d->workspace, "mdie_cdan_forward: null pointer");
   MDIE_REQUIRE((((uintptr_t)d->params | (uintptr_t)d->workspace) & 255) == 0, "mdie_cdan_forward: params/workspace must be 256-byte aligned");
-  MDIE_REQUIRE(!d->blob_delta || !(d->flags & MDIE_FWD_FUSED_TAIL), "mdie_cdan_forward: blob_delta (several weight sets) does not combine with MDIE_FWD_FUSED_TAIL");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (!d->launch_ms) return forward_impl(d, s);
 

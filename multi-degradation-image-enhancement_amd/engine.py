@@ -102,11 +102,11 @@ class CdanEngine:
             self._ws_key = key
         return self._ws
 
-    def _flags(self, fused_tail, general_tail=False, fused_cbam3=False):
-        return ((L.FWD_FUSED_TAIL if fused_tail else 0) | (0 if self.use_side_streams else L.FWD_SERIAL) | (L.FWD_GENERAL_TAIL if general_tail else 0)
+    def _flags(self, general_tail=False, fused_cbam3=False):
+        return ((0 if self.use_side_streams else L.FWD_SERIAL) | (L.FWD_GENERAL_TAIL if general_tail else 0)
                 | (L.FWD_FUSED_CBAM3 if fused_cbam3 else 0))
 
-    def forward(self, x, out=None, want_taps=False, profile=False, fused_tail=False, general_tail=False, fused_cbam3=False):
+    def forward(self, x, out=None, want_taps=False, profile=False, general_tail=False, fused_cbam3=False):
         """x: float32 NCHW [B,3,H,W] on this engine's GPU -> float32 NCHW [B,3,H,W]."""
         if self.params is None:
             raise L.MdieError("CdanEngine.forward before load(state_dict)")
@@ -120,13 +120,13 @@ class CdanEngine:
             # the plain path goes through the registered operator (torch.ops.mdie.cdan_forward, ops.py)
             from . import ops  # noqa: F401  (registers the library)
             aux = self._aux.value if (self.use_side_streams and self._aux) else 0
-            return torch.ops.mdie.cdan_forward(x, self.params, ws, self.dtype, aux or 0, self._flags(fused_tail, general_tail, fused_cbam3))
+            return torch.ops.mdie.cdan_forward(x, self.params, ws, self.dtype, aux or 0, self._flags(general_tail, fused_cbam3))
         y = out if out is not None else torch.empty_like(x)
         d = L.CdanFwdDesc()
         d.dtype, d.B, d.H, d.W = self.dtype, B, H, W
         d.params, d.x, d.y = self.params.data_ptr(), x.data_ptr(), y.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-        d.flags = self._flags(fused_tail, general_tail, fused_cbam3)
+        d.flags = self._flags(general_tail, fused_cbam3)
         d.aux = self._aux if self.use_side_streams else None
         taps = (L.Tap * len(L.TAP_NAMES))() if want_taps else None
         if taps is not None:
@@ -182,28 +182,21 @@ class RoutedEngine:
     (the reference trains one CDAN per config/*.json), every image labelled with its task by a router
     (mdie_amd/router.py; classification/train_multilabel_classifier.py:251-253 for the thresholds).
 
-    mode "chain" (default): ONE launch chain over the whole batch.  The task weight sets are rows of one device table; the batch is
-    ordered by task and every kernel of the chain looks up its image's row through `mdie_cdan_fwd_desc.blob_delta` (a device array of
-    byte offsets, one per image) -- 39 launches per batch whatever the grouping, the side branches on the engine's aux streams as
-    in CdanEngine.  mode "groups" (round 3 / early round 4, kept for the A/B in tools/bench_configs.py): images grouped by task, one
-    39-launch chain per group on its own stream, the groups enqueued by one host thread each (`threads`) -- host-bound at
-    9 x 39 launches; a hipGraph per (task, group size) was slower still and took the process down once (gpurun_out/r04e/tests.log).
-    Both modes are bit-identical to per-task engines (tests/test_gpu_parity.py::test_routed_*): a kernel is chosen by (layer, map)
-    alone and the several-weight-sets variants keep the arithmetic order of the plain ones."""
+    ONE launch chain over the whole batch.  The task weight sets are rows of one device table; the batch is ordered by task and every
+    kernel of the chain looks up its image's row through `mdie_cdan_fwd_desc.blob_delta` (a device array of byte offsets, one per image)
+    -- 39 launches per batch whatever the grouping, the side branches on the engine's aux streams as in CdanEngine.  Bit-identical to
+    per-task engines (tests/test_gpu_parity.py::test_routed_*): a kernel is chosen by (layer, map) alone and the several-weight-sets
+    variants keep the arithmetic order of the plain ones.
+    (Rounds 3-4 also had a "groups" mode -- one 39-launch chain per task group on its own stream, enqueued by one host thread each:
+    16 k against 27 k images/s, and its per-group hipGraph variant took the process down once (profiles/r04e_graph_replay_segfault.log).
+    Removed in round 5: the chain serves every grouping, from ONE host thread.)"""
 
-    def __init__(self, device, precision="bf16", threads=True, mode=None):
+    def __init__(self, device, precision="bf16"):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.MdieError(f"RoutedEngine needs a GPU device, got {self.device} (no CPU fallback)")
         self.dtype = dtype_id(precision)
         self.blobs = {}
-        self._streams = []
-        self._slots = None           # (capacity, H, W, x_slots, y_slots, {task: workspace}, {task: index})
-        self.threads = threads
-        self._pool = None
-        self.mode = mode or os.environ.get("MDIE_ROUTED_MODE", "chain")
-        if self.mode not in ("chain", "groups"):
-            raise L.MdieError(f"RoutedEngine mode {self.mode!r}: 'chain' or 'groups'")
         self._table = None           # (rows [ntask, stride] uint8, {task: row})
         self._ws = None
         self._aux = C.c_void_p(0)
@@ -220,7 +213,6 @@ class RoutedEngine:
 
     def load_task(self, task, state_dict):
         self.blobs[task] = pack_checkpoint(state_dict, self.dtype).to(self.device)
-        self._slots = None
         self._table = None
         return self
 
@@ -273,37 +265,6 @@ class RoutedEngine:
         out.index_copy_(0, meta[0], ys)
         return out
 
-    def _ensure_slots(self, B, H, W):
-        sl = self._slots
-        if sl is not None and sl[0] >= B and sl[1] == H and sl[2] == W and set(sl[5]) == set(self.blobs):
-            return sl
-        self._slots = None
-        n = L.lib.mdie_cdan_workspace_bytes(self.dtype, B, H, W)
-        if n == 0:
-            raise L.MdieError(f"unsupported input extent {B}x3x{H}x{W}: H and W must be multiples of 8")
-        tasks = sorted(self.blobs, key=str)
-        xs = torch.empty(len(tasks) * B, 3, H, W, dtype=torch.float32, device=self.device)
-        ys = torch.empty_like(xs)
-        ws = {t: torch.empty(n, dtype=torch.uint8, device=self.device) for t in tasks}      # (a stream-ordered allocation: earlier users of a
-        self._slots = (B, H, W, xs, ys, ws, {t: i for i, t in enumerate(tasks)})             #  replaced buffer finish before it is recycled)
-        return self._slots
-
-    def _launch_group(self, task, n, H, W, x_ptr, y_ptr, ws, stream_ptr):
-        d = L.CdanFwdDesc()
-        d.dtype, d.B, d.H, d.W = self.dtype, n, H, W
-        d.params, d.x, d.y = self.blobs[task].data_ptr(), x_ptr, y_ptr
-        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-        d.flags, d.aux = 0, None
-        L.check(L.lib.mdie_cdan_forward(C.byref(d), stream_ptr), "mdie_cdan_forward")
-
-    def _workers(self, n):
-        if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
-            self._pool = ThreadPoolExecutor(max_workers=16, thread_name_prefix="mdie-routed",
-                                            initializer=lambda: torch.cuda.set_device(dev))      # HIP's current device is per thread
-        return self._pool
-
     def forward(self, x, labels):
         """x: float32 NCHW [B,3,H,W] on the GPU; labels: B task keys (host side; None = pass through).  Returns [B,3,H,W] in input order."""
         _require_gpu(x, "RoutedEngine.forward")
@@ -315,57 +276,9 @@ class RoutedEngine:
             raise L.MdieError(f"RoutedEngine.forward: no weights loaded for task(s) {missing}")
         B, _, H, W = x.shape
         x = x.to(torch.float32).contiguous()
-        if self.mode == "chain":
-            routed = [i for i, t in enumerate(labels) if t is not None]
-            with torch.cuda.device(self.device):
-                return self._chain(x, labels, routed) if routed else x.clone()
+        routed = [i for i, t in enumerate(labels) if t is not None]
         with torch.cuda.device(self.device):
-            cap_B, _, _, xs, ys, wss, tindex = self._ensure_slots(B, H, W)
-            counts, slot, routed = {}, [], []
-            for i, t in enumerate(labels):
-                if t is None:
-                    continue
-                j = counts.get(t, 0)
-                counts[t] = j + 1
-                slot.append(tindex[t] * cap_B + j)         # task t's images sit at rows t * capacity ... of the slot buffers
-                routed.append(i)
-            out = torch.empty_like(x)
-            if len(routed) < B:                           # the router found no degradation: those images pass through unchanged
-                out.copy_(x)
-            if not routed:
-                return out
-            main = torch.cuda.current_stream(self.device)
-            slot_t = torch.tensor(slot, device=self.device)
-            src = x if len(routed) == B else x.index_select(0, torch.tensor(routed, device=self.device))
-            xs.index_copy_(0, slot_t, src)
-            groups = sorted(counts.items(), key=lambda kv: str(kv[0]))
-            while len(self._streams) < len(groups):
-                self._streams.append(torch.cuda.Stream(self.device))
-            fork = torch.cuda.Event()
-            fork.record(main)
-            esz = 3 * H * W * 4
-            jobs = []
-            for (task, n), st in zip(groups, self._streams):
-                base = tindex[task] * cap_B * esz
-                st.wait_event(fork)
-                jobs.append((task, n, H, W, xs.data_ptr() + base, ys.data_ptr() + base, wss[task], st.cuda_stream))
-            if self.threads and len(jobs) > 1:
-                futs = [self._workers(len(jobs)).submit(self._launch_group, *j) for j in jobs]
-                for f in futs:
-                    f.result()                            # (re-raises a launch error of that group)
-            else:
-                for j in jobs:
-                    self._launch_group(*j)
-            for st in self._streams[:len(groups)]:
-                done = torch.cuda.Event()
-                done.record(st)
-                main.wait_event(done)
-            res = ys.index_select(0, slot_t)
-            if len(routed) == B:
-                out = res
-            else:
-                out.index_copy_(0, torch.tensor(routed, device=self.device), res)
-        return out
+            return self._chain(x, labels, routed) if routed else x.clone()
 
 
 # ---- thin per-op wrappers (used by the parity tests; same entry points the plan calls) -----------------------------
@@ -486,27 +399,3 @@ def _tensor_array(state_dict):
         keep.append(a)
         entries.append(L.Tensor(name.encode(), a.ctypes.data, a.size))
     return (L.Tensor * len(entries))(*entries), len(entries), keep
-
-
-def pack_tail(state_dict, dtype, prefix=""):
-    """DenseBlock(3,3,16,4) checkpoint entries under `prefix` -> packed blob for mdie_tail_fwd (CPU uint8)."""
-    n = L.lib.mdie_tail_param_bytes(dtype)
-    blob = torch.zeros(n, dtype=torch.uint8)
-    arr, cnt, keep = _tensor_array(state_dict)
-    L.check(L.lib.mdie_tail_pack_params(dtype, arr, cnt, prefix.encode(), blob.data_ptr(), n), "mdie_tail_pack_params")
-    return blob
-
-
-def tail_fwd(x, params, *, dtype, lo=None):
-    """x: fp32 NCHW [B,3,H,W]; lo: NHWC [B,H/2,W/2,C>=3] or None; -> sigmoid(DenseBlock(up2(lo)+x)) fp32 NCHW."""
-    _require_gpu(x, "tail_fwd")
-    x = x.contiguous()
-    B, _, H, W = x.shape
-    y = torch.empty_like(x)
-    d = L.TailDesc()
-    d.dtype, d.B, d.H, d.W = dtype, B, H, W
-    d.lo = _ptr(lo)
-    d.lo_stride = lo.stride(2) if lo is not None else 0
-    d.x, d.y, d.params = x.data_ptr(), y.data_ptr(), params.data_ptr()
-    L.check(L.lib.mdie_tail_fwd(C.byref(d), _stream_ptr(x.device)), "mdie_tail_fwd")
-    return y

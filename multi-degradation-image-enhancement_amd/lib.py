@@ -12,16 +12,15 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 24
+ABI_VERSION = 25
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
-FWD_FUSED_TAIL = 1
 FWD_SERIAL = 2
 FWD_GENERAL_TAIL = 4
 FWD_FUSED_CBAM3 = 8
 LOSS_KINDS = {"mse": 0, "l1": 1, "charbonnier": 2, "ssim": 3, "gradient_l1": 4}
 
 TAP_NAMES = ("skip0", "skip1", "skip2", "dense0", "dense1", "dense2", "enc", "bott", "dec1", "dec2", "dec3", "dec4")
-KERNEL_KINDS = ("layout", "conv3x3", "conv1x1", "cbam_pool", "cbam_gate", "cbam_chanpool", "cbam_spatial", "upsample_add", "tail")
+KERNEL_KINDS = ("layout", "conv3x3", "conv1x1", "cbam_pool", "cbam_gate", "cbam_chanpool", "cbam_spatial", "upsample_add")
 
 
 class MdieError(RuntimeError):
@@ -166,12 +165,6 @@ class Tensor(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
 
 
-class TailDesc(C.Structure):
-    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
-                ("lo", C.c_void_p), ("lo_stride", C.c_int), ("x", C.c_void_p), ("y", C.c_void_p),
-                ("params", C.c_void_p)]
-
-
 class PpOp(C.Structure):
     _fields_ = [("kind", C.c_int), ("param", C.c_float)]
 
@@ -216,9 +209,6 @@ SIGNATURES = {
     "mdie_cbam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mdie_cbam_fwd": (C.c_int, [C.POINTER(CbamDesc), C.c_void_p]),
     "mdie_cbam_channel_only_fwd": (C.c_int, [C.POINTER(CbamDesc), C.c_void_p]),
-    "mdie_tail_param_bytes": (C.c_size_t, [C.c_int]),
-    "mdie_tail_pack_params": (C.c_int, [C.c_int, C.POINTER(Tensor), C.c_int, C.c_char_p, C.c_void_p, C.c_size_t]),
-    "mdie_tail_fwd": (C.c_int, [C.POINTER(TailDesc), C.c_void_p]),
     "mdie_upsample2x_add": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mdie_upsample2x_add_pool": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

@@ -45,19 +45,11 @@ if what == "routed":
     def step(e):
         e.forward(x, lists[k[0] % len(lists)])
         k[0] += 1
-    dtc = timed(lambda: step(eng), n=48)                 # mode "chain": one launch chain, per-image weight-set lookup
-    thr = E.RoutedEngine("cuda", prec, mode="groups")
-    serial = E.RoutedEngine("cuda", prec, threads=False, mode="groups")
-    for i, t in enumerate(tasks):
-        thr.load_task(t, P.make_state_dict(100 + i))
-        serial.load_task(t, P.make_state_dict(100 + i))
-    dt = timed(lambda: step(thr), n=48)
-    dte = timed(lambda: step(serial), n=32)
+    dtc = timed(lambda: step(eng), n=48)                 # one launch chain, per-image weight-set lookup
     one = E.CdanEngine("cuda", prec).load(P.make_state_dict(100))
     dt1 = timed(lambda: one.forward(x))
-    print(f"routed[{prec}] 9 tasks, B=32 256x256, a different grouping every batch: {dtc*1e3:.2f} ms/batch = {32/dtc:.0f} img/s as ONE launch chain (weight set looked up per image); "
-          f"{dt*1e3:.2f} ms = {32/dt:.0f} img/s as nine task groups enqueued by one host thread each; "
-          f"{dte*1e3:.2f} ms = {32/dte:.0f} img/s enqueued one after the other (round 3's form)  (single weight set, eager: {dt1*1e3:.2f} ms = {32/dt1:.0f} img/s)")
+    print(f"routed[{prec}] 9 tasks, B=32 256x256, a different grouping every batch: {dtc*1e3:.2f} ms/batch = {32/dtc:.0f} img/s as ONE launch chain (weight set looked up per image)"
+          f"  (single weight set, eager: {dt1*1e3:.2f} ms = {32/dt1:.0f} img/s)")
 else:
     eng = E.CdanEngine("cuda", prec).load(P.make_state_dict(42))
     for B in (1, 4):

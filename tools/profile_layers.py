@@ -9,7 +9,6 @@ from mdie_amd import synthetic as P
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 256
-fused = os.environ.get("FUSED_TAIL", "0") == "1"
 general = os.environ.get("GENERAL_TAIL", "0") == "1"    # decoder.final_dense as the general chain (no transition folding)
 net = CDAN(precision=prec)
 net.load_state_dict(P.make_state_dict(42), strict=True)
@@ -18,11 +17,11 @@ x, _ = P.lowlight_batch(1, B, S, S)
 x = x.cuda()
 eng = net._engine(x.device)
 for _ in range(3):
-    eng.forward(x, fused_tail=fused, general_tail=general)
+    eng.forward(x, general_tail=general)
 acc = None
 reps = 5
 for _ in range(reps):
-    _, ex = eng.forward(x, profile=True, fused_tail=fused, general_tail=general)
+    _, ex = eng.forward(x, profile=True, general_tail=general)
     ms = [m for _, m in ex["launches"]]
     acc = ms if acc is None else [a + b for a, b in zip(acc, ms)]
 kinds = [k for k, _ in ex["launches"]]
