@@ -268,21 +268,6 @@ typedef struct {
 size_t mdie_cbam_workspace_bytes(int B, int H, int W, int C);
 int mdie_cbam_fwd(const mdie_cbam_desc* d, void* stream);
 
-/* CBAM whose output feeds ONE 3x3 convolution with 16 stored outputs and nothing else: decoder stage 4 of the network,
- *   out = act((conv3x3(CBAM(x) * mul) * post_scale + post_shift))        (models/cdan.py:148-152: cbam3, `out *= denses[0]`, conv4 + bn4 + ReLU)
- * Passes 1-3 run as in mdie_cbam_fwd; pass 4 is not a launch of its own: the convolution forms x * gate * s * mul while it
- * stages its input patches (csrc/conv_gated.hip), so the gated tensor is never written.  16-bit dtypes, cbam.C a multiple of
- * 32 up to 64, `mul` given; results are bit-identical to mdie_cbam_fwd followed by mdie_conv_fwd.  cbam.out is not used. */
-typedef struct {
-  mdie_cbam_desc cbam;
-  const void* weight;        /* mdie_pack_conv_weight layout, cin_stored = cbam.C, cout_stored = 16 */
-  const float* post_scale;   /* [16] */
-  const float* post_shift;   /* [16] */
-  int act;                   /* MDIE_ACT_* */
-  void* out; int out_stride; /* [B,H,W,>=16] NHWC */
-} mdie_cbam_conv_desc;
-int mdie_cbam_conv_applicable(int dtype, int H, int W, int C, int cout_stored, int x_stride, int mul_stride, int has_mul);
-int mdie_cbam_conv_fwd(const mdie_cbam_conv_desc* d, void* stream);
 /* the same pipeline stopped after pass 2 + channel scaling only (for stage-wise parity tests) */
 int mdie_cbam_channel_only_fwd(const mdie_cbam_desc* d, void* stream);
 
@@ -422,11 +407,8 @@ enum { /* 1: was MDIE_FWD_FUSED_TAIL (the whole decoder tail as one launch, roun
           removed in round 5 (ABI 25) */
        MDIE_FWD_SERIAL = 2     /* keep the encoder DenseBlocks in line with the main chain (no side streams, no graph branches) */,
        MDIE_FWD_GENERAL_TAIL = 4 /* decoder.final_dense as the general chain (3x3 layers, then the 1x1 launch) also where the transition
-                                    could be folded into its producers (mdie_tr_fuse): the form fp32 and ragged extents always take */,
-       MDIE_FWD_FUSED_CBAM3 = 8 /* cbam3's last pass as the staging prologue of decoder.conv4 (mdie_cbam_conv_fwd: one launch, the gated
-                                   tensor never written; bit-identical to the two launches) where it applies (16-bit types, no `taps`).
-                                   NOT the default: measured 68-69 us against 41 + 27 for the two launches at B = 32, 256x256 (DESIGN.md
-                                   section 8, round 4) */ };
+                                    could be folded into its producers (mdie_tr_fuse): the form fp32 and ragged extents always take */
+       /* 8: was MDIE_FWD_FUSED_CBAM3 (cbam3's last pass fused into decoder.conv4, round 4): 68 us against 41 + 27, removed in round 5 */ };
 
 enum { MDIE_K_LAYOUT = 0, MDIE_K_CONV3 = 1, MDIE_K_CONV1 = 2, MDIE_K_CBAM_POOL = 3, MDIE_K_CBAM_GATE = 4,
        MDIE_K_CBAM_CHANPOOL = 5, MDIE_K_CBAM_SPATIAL = 6, MDIE_K_UPSAMPLE = 7, MDIE_K_COUNT = 8 };

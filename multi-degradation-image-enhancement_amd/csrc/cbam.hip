@@ -451,13 +451,8 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static int nslab_for(int H, int W) { const int n = cdiv(H * W, POOL_MIN_SLAB), m = pool_max_slabs(H, W); return n < m ? n : m; }
 
-}  // namespace mdie
-#include "conv_common.hpp"
-namespace mdie {
-// conv_gated.hip: pass 4 fused into the 16-output 3x3 convolution that consumes the CBAM's output
-
 template <typename T>
-static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream, const mdie_cbam_conv_desc* fuse = nullptr) {
+static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
   constexpr int VEC = Traits<T>::VEC;
   CbamArgs a{};
   a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C;
@@ -518,21 +513,7 @@ static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream, c
     else { set_error("mdie_cbam_fwd: C = %d too wide", d->C); return MDIE_EINVAL; }
     MDIE_LAUNCH_CHECK("cbam_chanpool");
   }
-  if (fuse) {   // pass 4 rides on the consuming convolution's staging
-    GatedArgs g{};
-    g.B = d->B; g.H = d->H; g.W = d->W; g.C = d->C;
-    g.x = a.x; g.x_stride = a.x_stride; g.mul = a.mul; g.mul_stride = a.mul_stride;
-    g.gate = a.gate; g.map = a.map; g.w7 = a.w7; g.bn = a.bn;
-    g.weight = reinterpret_cast<const char*>(fuse->weight);
-    g.nchunk = d->C / Traits<T>::KC;
-    g.e = EpiArgs{};
-    g.e.H = d->H; g.e.W = d->W; g.e.post_scale = fuse->post_scale; g.e.post_shift = fuse->post_shift; g.e.act = fuse->act; g.e.pool = 0;
-    g.e.out = reinterpret_cast<char*>(fuse->out); g.e.out_stride = fuse->out_stride; g.e.out_gs = 16;
-#ifdef EXP_GSTAMPS
-    g.e.residual = reinterpret_cast<const char*>(d->out);    // (stamps build: cbam.out, unused by this entry, carries the stamp buffer)
-#endif
-    return launch_conv_gated(Traits<T>::DT, g, stream);
-  } else {
+  {
     const size_t lds = (size_t)(d->C + 2 * 22 * 22 + 256 + 100) * sizeof(float);
     // 1 KiB-per-pixel tensors (C >= 256) sit at 32x32 in this network: 16x16 tiles would give 128 blocks
     const int ts = d->C >= 256 ? 8 : 16;
@@ -578,26 +559,6 @@ extern "C" int mdie_cbam_fwd(const mdie_cbam_desc* d, void* stream) {
   if (int e = check_cbam(d)) return e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   MDIE_SWITCH_T(d->dtype, return run_cbam<T>(d, true, s));
-}
-
-extern "C" int mdie_cbam_conv_applicable(int dtype, int H, int W, int C, int cout_stored, int x_stride, int mul_stride, int has_mul) {
-  return mdie::dtype_valid(dtype) && mdie::conv_gated_applicable(dtype, H, W, C, cout_stored, x_stride, mul_stride, has_mul != 0) ? 1 : 0;
-}
-
-extern "C" int mdie_cbam_conv_fwd(const mdie_cbam_conv_desc* f, void* stream) {
-  using namespace mdie;
-  MDIE_REQUIRE(f != nullptr, "mdie_cbam_conv_fwd: null descriptor");
-  const mdie_cbam_desc* d = &f->cbam;
-  if (int e = check_cbam(d, false)) return e;
-  MDIE_REQUIRE(!d->blob_delta, "mdie_cbam_conv_fwd: one weight set only (no blob_delta)");
-  MDIE_REQUIRE(f->weight && f->post_scale && f->post_shift && f->out && f->out_stride >= 16 && f->out_stride % 4 == 0 && ((uintptr_t)f->out & 15) == 0 &&
-               ((uintptr_t)f->weight & 15) == 0, "mdie_cbam_conv_fwd: convolution side: null pointer / out_stride %d / alignment", f->out_stride);
-  MDIE_REQUIRE(f->act == MDIE_ACT_NONE || f->act == MDIE_ACT_RELU || f->act == MDIE_ACT_SIGMOID, "mdie_cbam_conv_fwd: act %d", f->act);
-  MDIE_REQUIRE(conv_gated_applicable(d->dtype, d->H, d->W, d->C, 16, d->x_stride, d->mul_stride, d->mul != nullptr),
-               "mdie_cbam_conv_fwd: needs a 16-bit dtype, C in {32, 64}, a multiplicand and a picture of < 4 M pixels (got dtype %d, C %d, %dx%d)", d->dtype, d->C, d->H, d->W);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d->dtype == MDIE_BF16) return run_cbam<bf16>(d, true, s, f);
-  return run_cbam<f16>(d, true, s, f);
 }
 
 extern "C" int mdie_cbam_channel_only_fwd(const mdie_cbam_desc* d, void* stream) {

@@ -381,22 +381,6 @@ int launch_conv_thin(int dtype, const ConvArgs& a, hipStream_t stream, const mdi
 // the four waves of a workgroup, barrier-free chunk loop.  Chosen by (layer, map) only, never by the batch.
 bool conv_ksplit_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw3);
 int launch_conv_ksplit(int dtype, ConvArgs& a, hipStream_t stream);
-// conv_gated.hip: CBAM's last pass (x * gate * s * mul) fused into the staging of the 16-output 3x3 convolution that consumes
-// it (mdie_cbam_conv_fwd; cbam.hip runs passes 1-3 and then launches this)
-struct GatedArgs {
-  int B, H, W, C;              // input extent (= output extent), gated tensor's channels (multiple of 32, <= 64)
-  const char* x; int x_stride;
-  const char* mul; int mul_stride;
-  const float* gate;           // [B][C]
-  const float* map;            // [B][H][W][2] (max, mean) of x * gate
-  const float* w7;             // [2][7][7]
-  const float* bn;             // [2] folded BatchNorm(1)
-  const char* weight;          // packed 3x3 weights, cout_stored = 16
-  int nchunk, tiles_x, tiles_y;
-  EpiArgs e;
-};
-int launch_conv_gated(int dtype, const GatedArgs& g, hipStream_t stream);
-bool conv_gated_applicable(int dtype, int H, int W, int C, int cout_stored, int x_stride, int mul_stride, bool has_mul);
 // conv_planar.hip: conv_kernel with the output written one plane per 16 channels (no activation, pooling, residual): the input
 // gradients of the DenseBlock layers in training
 int launch_conv_planar(int dtype, ConvArgs& a, int ksize, hipStream_t stream);

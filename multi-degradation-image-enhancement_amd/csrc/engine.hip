@@ -563,38 +563,6 @@ static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, con
   return rc;
 }
 
-// cbam3 + decoder.conv4 (+ bn4 + ReLU): the CBAM's last pass rides on the convolution's staging (csrc/conv_gated.hip)
-static int run_cbam_conv(const Ctx& c, const Plan& P, int id, int conv_id, int H, int W, const Buf& x, const Buf& mul, const Buf& out, int pooled_slabs) {
-  const CbamBlob& o = c.L.cbam[id];
-  const int from = c.notes ? c.notes->mark() : 0;
-  mdie_cbam_conv_desc f{};
-  mdie_cbam_desc& d = f.cbam;
-  d.dtype = c.dtype; d.B = c.B; d.H = H; d.W = W; d.C = arch(c.dtype).cbam[id].C;
-  d.x = c.ws + x.off; d.x_stride = x.C;
-  d.w1 = reinterpret_cast<const float*>(c.params + o.w1); d.b1 = reinterpret_cast<const float*>(c.params + o.b1);
-  d.w2 = reinterpret_cast<const float*>(c.params + o.w2); d.b2 = reinterpret_cast<const float*>(c.params + o.b2);
-  d.w7 = reinterpret_cast<const float*>(c.params + o.w7);
-  d.bn = reinterpret_cast<const float*>(c.params + o.bn);
-  d.mul = c.ws + mul.off; d.mul_stride = mul.C;
-  d.workspace = c.ws + P.cbam_ws; d.workspace_bytes = P.cbam_ws_bytes;
-  if (pooled_slabs > 0) { d.pool_partial = reinterpret_cast<const float*>(c.ws + P.pool_ws); d.pool_slabs = pooled_slabs; }
-  f.weight = c.params + c.L.conv[conv_id].w;
-  f.post_scale = reinterpret_cast<const float*>(c.params + c.L.conv[conv_id].post_scale);
-  f.post_shift = reinterpret_cast<const float*>(c.params + c.L.conv[conv_id].post_shift);
-  f.act = MDIE_ACT_RELU;
-  f.out = c.ws + out.off; f.out_stride = out.C;
-  const int rc = mdie_cbam_conv_fwd(&f, c.stream);
-  if (c.notes && c.notes->on()) {
-    c.notes->cbam(from, "cbam3", d.C, (double)H * W, true, "d1");
-    // the fused launch carries the spatial pass's share AND the convolution's (the model counts the gated tensor's write and
-    // re-read; the launch no longer moves them)
-    const ConvSpec& s = arch(c.dtype).conv[conv_id];
-    const double p = (double)H * W;
-    c.notes->add(c.notes->mark() - 1, "cbam3.spatial*d1+dec.conv4", s.cin * p + s.cout * p, (double)s.cin * s.cout * 9 + s.cout + 2.0 * s.cout, 2.0 * s.cin * s.cout * 9 * p);
-  }
-  return rc;
-}
-
 static int run_up(const Ctx& c, const Plan& P, const char* label, int H, int W, const Buf& lo, const Buf& skip, const Buf& out) {
   // the upsampled + skip tensor feeds a CBAM: reduce it for the channel gate while writing it
   if (ablated(label)) return MDIE_OK;
@@ -773,19 +741,10 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   RUN(run_conv(c, "dec.conv3", CV_D3, h2, w2, {P.u2}, P.t3lo, MDIE_ACT_RELU, 0, nullptr));
   RUN(run_up(c, P, "up3+skip0+pool", h2, w2, P.t3lo, P.o[0], P.t3));
   RUN(join_dense(0));
-  // cbam3's output feeds decoder.conv4 and nothing else, so the CBAM's last pass can be the convolution's staging prologue and the
-  // gated tensor never written (mdie_cbam_conv_fwd, bit-identical to the two launches).  Built and measured in round 4: 68-69 us
-  // against 41.2 + 26.5 us for the two launches -- the fused kernel's staging reads HALF lines (a 64-byte K chunk of a 128-byte
-  // pixel per load, twice, with an 18x18 halo) of two tensors plus 18 KB of weights per 256 pixels and sits on the vector memory
-  // path (tools/stamp_gated.py: 8 k cycles to issue a tile's loads, 10 k for a round trip); what it saves in HBM bytes
-  // (134 MB written + 170 MB re-read) it gives back there.  Opt-in (MDIE_FWD_FUSED_CBAM3), never with `taps`.
-  const bool fuse3 = !d->taps && !d->blob_delta && (d->flags & MDIE_FWD_FUSED_CBAM3) && mdie_cbam_conv_applicable(d->dtype, h1, w1, 64, P.t4lo.C, P.t3.C, P.d[0].C, 1);
-  if (fuse3) {
-    RUN(run_cbam_conv(c, P, CB_3, CV_D4, h1, w1, P.t3, P.d[0], P.t4lo, mdie_pool_slabs(h1, w1)));
-  } else {
-    RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3, mdie_pool_slabs(h1, w1)));
-    RUN(run_conv(c, "dec.conv4", CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
-  }
+  // (cbam3's last pass as decoder.conv4's staging prologue -- mdie_cbam_conv_fwd, rounds 4 -- measured 68-69 us against 41 + 27 for the two
+  //  launches and was removed in round 5; profiles/LEDGER.md has the stamps and what a form that could win would look like)
+  RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3, mdie_pool_slabs(h1, w1)));
+  RUN(run_conv(c, "dec.conv4", CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
   bool half_base = false;
   {
     // bilinear x2 + x (x read from its fp32 NCHW planes), final_dense, sigmoid written straight to NCHW

@@ -102,11 +102,10 @@ class CdanEngine:
             self._ws_key = key
         return self._ws
 
-    def _flags(self, general_tail=False, fused_cbam3=False):
-        return ((0 if self.use_side_streams else L.FWD_SERIAL) | (L.FWD_GENERAL_TAIL if general_tail else 0)
-                | (L.FWD_FUSED_CBAM3 if fused_cbam3 else 0))
+    def _flags(self, general_tail=False):
+        return (0 if self.use_side_streams else L.FWD_SERIAL) | (L.FWD_GENERAL_TAIL if general_tail else 0)
 
-    def forward(self, x, out=None, want_taps=False, profile=False, general_tail=False, fused_cbam3=False):
+    def forward(self, x, out=None, want_taps=False, profile=False, general_tail=False):
         """x: float32 NCHW [B,3,H,W] on this engine's GPU -> float32 NCHW [B,3,H,W]."""
         if self.params is None:
             raise L.MdieError("CdanEngine.forward before load(state_dict)")
@@ -120,13 +119,13 @@ class CdanEngine:
             # the plain path goes through the registered operator (torch.ops.mdie.cdan_forward, ops.py)
             from . import ops  # noqa: F401  (registers the library)
             aux = self._aux.value if (self.use_side_streams and self._aux) else 0
-            return torch.ops.mdie.cdan_forward(x, self.params, ws, self.dtype, aux or 0, self._flags(general_tail, fused_cbam3))
+            return torch.ops.mdie.cdan_forward(x, self.params, ws, self.dtype, aux or 0, self._flags(general_tail))
         y = out if out is not None else torch.empty_like(x)
         d = L.CdanFwdDesc()
         d.dtype, d.B, d.H, d.W = self.dtype, B, H, W
         d.params, d.x, d.y = self.params.data_ptr(), x.data_ptr(), y.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-        d.flags = self._flags(general_tail, fused_cbam3)
+        d.flags = self._flags(general_tail)
         d.aux = self._aux if self.use_side_streams else None
         taps = (L.Tap * len(L.TAP_NAMES))() if want_taps else None
         if taps is not None:

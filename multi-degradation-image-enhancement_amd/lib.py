@@ -16,7 +16,6 @@ ABI_VERSION = 25
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_SERIAL = 2
 FWD_GENERAL_TAIL = 4
-FWD_FUSED_CBAM3 = 8
 LOSS_KINDS = {"mse": 0, "l1": 1, "charbonnier": 2, "ssim": 3, "gradient_l1": 4}
 
 TAP_NAMES = ("skip0", "skip1", "skip2", "dense0", "dense1", "dense2", "enc", "bott", "dec1", "dec2", "dec3", "dec4")
@@ -155,12 +154,6 @@ class CbamDesc(C.Structure):
                 ("pool_partial", C.c_void_p), ("pool_slabs", C.c_int), ("blob_delta", C.c_void_p)]
 
 
-class CbamConvDesc(C.Structure):
-    """mdie_cbam_conv_desc: CBAM whose last pass rides on the 16-output 3x3 convolution that consumes it (include/mdie.h)"""
-    _fields_ = [("cbam", CbamDesc), ("weight", C.c_void_p), ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int),
-                ("out", C.c_void_p), ("out_stride", C.c_int)]
-
-
 class Tensor(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
 
@@ -264,8 +257,6 @@ SIGNATURES = {
     "mdie_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mdie_loss_fwd_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(LossTerm), C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
-    "mdie_cbam_conv_applicable": (C.c_int, [C.c_int] * 8),
-    "mdie_cbam_conv_fwd": (C.c_int, [C.POINTER(CbamConvDesc), C.c_void_p]),
     "mdie_last_error": (C.c_char_p, []),
     "mdie_abi_version": (C.c_int, []),
 }

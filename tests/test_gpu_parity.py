@@ -850,31 +850,6 @@ def test_forward_does_not_depend_on_what_the_workspace_held(E, prec, shape):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("shape", [(2, 64, 64), (3, 72, 104), (8, 256, 256)])
-def test_cbam_spatial_fused_into_its_convolution(E, prec, shape):
-    """mdie_cbam_conv_fwd (csrc/conv_gated.hip): cbam3's last pass -- x * gate * sigmoid(bn(conv7x7(map))) * dense1, models/cbam.py:72-82 and
-    `out *= denses[0]`, models/cdan.py:149 -- formed while decoder.conv4 (:150-152) stages its input, the gated tensor never written.
-    The whole network with the fused launch (MDIE_FWD_FUSED_CBAM3, opt-in: it measured no faster) against the same network with the
-    two launches: bit-identical outputs (one rounding of the same fp32 product, the same MFMA order); ragged tiles and border
-    padding included."""
-    from oracle import params as P
-    sd = P.make_state_dict(42)
-    x, _ = P.lowlight_batch(21, *shape)
-    x = x.cuda()
-    eng = E.CdanEngine("cuda", prec).load(sd)
-    y_fused = eng.forward(x, out=torch.empty_like(x), fused_cbam3=True)
-    y_two = eng.forward(x, out=torch.empty_like(x))
-    torch.cuda.synchronize()
-    assert torch.equal(y_fused, y_two)
-    _, ex = eng.forward(x, profile=True, fused_cbam3=True)
-    labels = [l for l, _, _ in ex["launch_info"]]
-    assert "cbam3.spatial*d1+dec.conv4" in labels and "dec.conv4" not in labels
-    _, ex2 = eng.forward(x, profile=True)
-    assert "dec.conv4" in [l for l, _, _ in ex2["launch_info"]]                            # the default path: two launches (the faster form, DESIGN.md section 8)
-    assert abs(sum(b for _, b, _ in ex["launch_info"]) - sum(b for _, b, _ in ex2["launch_info"])) < 1.0   # the model's bytes are booked either way
-
-
-@pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("cin_segs,shape,act", [([128], (3, 32, 32), "none"), ([128, 16], (2, 40, 40), "none"), ([256, 16, 16], (5, 32, 32), "none"),
                                                 ([256, 16, 16, 16], (2, 27, 21), "relu"), ([128, 16, 16, 16, 16], (1, 48, 33), "none"),
                                                 ([256, 128, 64, 48], (2, 16, 24), "none")])
