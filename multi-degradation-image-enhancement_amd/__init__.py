@@ -9,7 +9,7 @@ import os as _os
 # Kernel arguments in DEVICE memory (HIP_FORCE_DEV_KERNARG=1; the runtime's default keeps them in host memory, read over PCIe by the first
 # waves of every launch).  This engine's launches carry descriptors of a few hundred bytes and a forward is 39 of them back to back:
 # measured on one MI355X box, alternating processes, 28.8 -> 30.8 k images/s eager, 29.0 -> 30.9 k as a hipGraph, routed 26.4 -> 28.3 k
-# (profiles/r04r_dev_kernarg_ab.txt).  The HIP runtime reads the variable when it initialises -- on the first HIP
+# (profiles/LEDGER.md (rounds 1-4) section 5, profiles/r04r_dev_kernarg_ab.txt).  The HIP runtime reads the variable when it initialises -- on the first HIP
 # call, not at import -- so a default set here takes effect as long as the package is imported before the process touches the GPU
 # (bench.py, run.py, tests/conftest.py and __graft_entry__ also set it first thing); an explicit setting in the environment wins.
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")

@@ -728,7 +728,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply2_kernel(const BnBwdAr
 //     g = sum_j scale_j * (da_j * [x * scale_j + shift_j > 0]) - sum_j scale_j * k2_j - xhat * sum_j scale_j * k3_j
 // with ONE rounding to the element type instead of five.  The x part of a layer's da is the contiguous prefix [0, C) of each of
 // its rows (>= 32 bytes, 128-512 for the encoder blocks), so the five streams are read in whole sectors -- unlike the growth
-// segments, 32-byte slices in the middle of those rows, for which the same idea measured SLOWER and which
+// segments, 32-byte slices in the middle of those rows, for which the same idea measured SLOWER (profiles/LEDGER.md (rounds 1-4) section 5b) and which
 // keep the per-layer pass.
 struct BnMultiArgs {
   long N; int C;

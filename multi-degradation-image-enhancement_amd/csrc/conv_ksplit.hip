@@ -3,7 +3,7 @@
 //
 // Why a third kernel.  conv_kernel runs these layers as a fork-join per 32-channel K chunk: all four waves of a workgroup stage one
 // chunk (two barriers, an LDS write -> read turn-around), then each wave issues 9 (8x8 tile) or 36 (16x16) MFMAs -- 144..576 matrix
-// cycles inside a 3.1 k-cycle iteration, 8..10 iterations in a row (tools/stamp_conv.py, DESIGN.md section 4 finding 8): 16-21 us
+// cycles inside a 3.1 k-cycle iteration, 8..10 iterations in a row (tools/stamp_conv.py, profiles/LEDGER.md (rounds 1-4) section 4 finding 8): 16-21 us
 // for 19 MB.  Deeper prefetch, a table of segment addresses, a K split over WORKGROUPS (partial slabs + a reduce launch) all measured
 // null or worse: the chain itself is the cost.  Here the K axis is split over the four WAVES of a workgroup instead:
 //   * wave w owns K chunks w, w + 4, ... of the layer and the WHOLE 8x8-pixel tile (4 subtiles x 16 outputs, 36 MFMAs per chunk):
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_ksplit_kernel(const Conv
 
   // ---- staging geometry of this lane: unit u = lane + 64 it -> patch pixel u >> 2, K group q = lane & 3 ----
   // Every load and every LDS write below is UNCONDITIONAL (a branch around one makes the compiler's s_waitcnt pass fall back to
-  // vmcnt(0) in the middle of the load cluster -- DESIGN.md section 4, gfx950 finding 2): a unit outside the picture reads a valid
+  // vmcnt(0) in the middle of the load cluster -- profiles/LEDGER.md (rounds 1-4) section 4, gfx950 finding 2): a unit outside the picture reads a valid
   // (clamped) pixel and is zeroed by a select before the LDS write; the lanes without a pixel in the last iteration (100 patch
   // pixels = 6 * 16 + 4) write into the 128 unused bytes at the end of their plane.
   // One register per unit: low half = pixel index inside the image (clamped), high half = LDS byte offset inside `mine`; `inside`
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_ksplit_kernel(const Conv
   // One step = stage the chunk that has landed, issue the next chunk's loads (when the wave has one), 36 MFMAs.  The loop runs the
   // steps that HAVE a successor -- its prefetch is unconditional -- and the last step stands behind it: a prefetch under
   // `if (chunk + 4 < nchunk)` inside the loop meets the not-taken path in a phi, and the compiler answers that with
-  // s_waitcnt vmcnt(0) right behind the loads (DESIGN.md section 4, gfx950 finding 3): this chunk's MFMAs would wait for the
+  // s_waitcnt vmcnt(0) right behind the loads (profiles/LEDGER.md (rounds 1-4) section 4, gfx950 finding 3): this chunk's MFMAs would wait for the
   // NEXT chunk's data.
   auto stage = [&]() __attribute__((always_inline)) {
     // pre-activation (BN + ReLU; zero padding stays zero) and LDS write of this wave's patch

@@ -6,7 +6,7 @@
 // input, C_l = c0 + 16 l channels per pixel).  Interleaved [pixel][C_l] rows make such a slice 32 bytes out of 64-600: adding the
 // terms layer by layer (round 1-2: read x, da, the running sum; write the sum -- 4 passes over C_l channels per layer, 1.6 ms of a
 // 10.9 ms step at 512x512, B = 8) moves 2.3x the bytes of forming every segment's gradient ONCE from all its consumers, and
-// gathering the slices out of interleaved rows measured slower still.  With da stored plane by plane every
+// gathering the slices out of interleaved rows measured slower still (profiles/LEDGER.md (rounds 1-4) section 5b).  With da stored plane by plane every
 // slice is a dense [pixels][16] stream, and mdie_bn_bwd_apply_multi reads x, each consumer's plane and writes the sum once.
 //
 // The kernels are conv_kernel's template (conv_kernel.hpp) with PLANAR = true: same staging, same MFMA order, the plain epilogue

@@ -840,13 +840,13 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
 extern "C" int mdie_aux_create(void** out) {
   MDIE_REQUIRE(out != nullptr, "mdie_aux_create: null argument");
   Aux* a = new Aux();
-  bool ok = true;
-  for (int i = 0; i < 3; ++i) {
-    ok = ok && hipStreamCreateWithFlags(&a->side[i], hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&a->fork[i], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&a->join[i], hipEventDisableTiming) == hipSuccess;
+  hipError_t err = hipSuccess;
+  for (int i = 0; i < 3 && err == hipSuccess; ++i) {
+    err = hipStreamCreateWithFlags(&a->side[i], hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&a->fork[i], hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&a->join[i], hipEventDisableTiming);
   }
-  if (!ok) { set_error("mdie_aux_create: HIP stream/event creation failed"); delete a; return MDIE_ELAUNCH; }
+  if (err != hipSuccess) { set_error("mdie_aux_create: HIP stream/event creation failed: %s", hipGetErrorString(err)); delete a; return MDIE_ELAUNCH; }
   *out = a;
   return MDIE_OK;
 }

@@ -267,7 +267,7 @@ def bind_to_gpu_numa(device_index=0):
     """Keep this process on the CPUs of the NUMA node its GPU hangs off (MDIE_NUMA_BIND=0 turns it off).
     A two-socket MI355X host gives a process CPUs of both sockets; where its threads happen to run decides on which node pinned host
     buffers are first touched, and a batch that crosses the socket link on its way to PCIe moves at half the rate -- the PCIe-inclusive
-    serving rate was bimodal by process, 26 k or 13.7 k images/s on one box (tools/bench_e2e.py).  The node comes from the
+    serving rate was bimodal by process, 26 k or 13.7 k images/s on one box (tools/bench_e2e.py, profiles/LEDGER.md (rounds 1-4) section 7).  The node comes from the
     device's PCI address (torch's device properties -> /sys/bus/pci/devices/<bdf>/local_cpulist); the binding is the intersection with
     the CPUs the process is allowed.  Returns the CPU set bound to, or None when nothing was changed (no sysfs entry, no GPU, a single
     node, an empty intersection, or switched off) -- never raises: placement is speed, not correctness."""

@@ -6,6 +6,11 @@ export the ABI version this file was written for, importing this module raises.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: torch brings its own libamdhip64; the engine must bind to THAT runtime.  Loaded before torch, this
+#                library pulls the system's /opt/rocm runtime into the process, torch then loads its bundled one beside it, and the
+#                library's streams / events belong to a runtime torch's tensors do not live in (mdie_aux_create failed with exactly
+#                that when __graft_entry__.build() imported this module ahead of `import torch`: gpurun_out/r05d/smoke.log)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  # MDIE_LIB: experimental builds only
 

@@ -283,9 +283,10 @@ def _pad_vec(v, n):
 # WGRAD_STREAM_MIN_PIXELS input pixels, never under capture.
 # WHY IT IS OFF BY DEFAULT (round 4).  In round 3 one box showed, in 4 of 12 rounds of three steps at 8x512x512, the bottleneck
 # CBAM's channel-gate MLP gradients (and what is downstream of them) differing from the single-stream schedule.  Those gradients
-# are computed entirely on the MAIN stream (cbt_bwd3 -> cbt_gate_bwd -> cbt_gate_final); the cause was not found: DESIGN.md
-# section 4 finding 6 lists what reading the kernels' ISA, the host-side fork and a hardware probe (tools/pkfma_probe.hip) exclude.
-# Until it is explained the default training schedule is the single stream.
+# are computed entirely on the MAIN stream (cbt_bwd3 -> cbt_gate_bwd -> cbt_gate_final); the cause was not found: profiles/LEDGER.md
+# (rounds 1-4 section 4, finding 6; round 5) lists what reading the kernels' ISA, the host-side fork, a hardware probe
+# (tools/pkfma_probe.hip) and a NaN poison of every uninitialised allocation of the step (MDIE_TRAIN_POISON, round 5) exclude.
+# The default training schedule is the single stream; this switch is EXPERIMENTAL.
 WGRAD_STREAM = __import__("os").environ.get("MDIE_TRAIN_WGRAD_STREAM", "0") == "1"
 WGRAD_STREAM_MIN_PIXELS = 8 * 384 * 384
 _wgrad_side_this_step = False  # forward_train decides per step

@@ -179,7 +179,7 @@ def test_custom_torch_ops_are_registered_and_have_no_cpu_kernel():
 def test_shipped_code_objects_pass_the_isa_guard():
     """tools/isa_guard.py on the library the tests load: NO kernel reads a VGPR pair through the op_sel / op_sel_hi modifiers of a
     packed-f32 instruction -- the form that returned wrong values with MFMAs in flight on the CU, inside one kernel in round 2 and
-    across kernels (MFMA-free CBAM backward next to the weight-gradient kernels on a second stream) in round 3, DESIGN.md section 4
+    across kernels (MFMA-free CBAM backward next to the weight-gradient kernels on a second stream) in round 3, profiles/LEDGER.md (rounds 1-4) section 4
     finding 6 -- and no kernel of the library spills registers to scratch."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -2352,7 +2352,7 @@ def test_side_stream_weight_gradients_equal_main_stream(E, precision, shape, mon
 
     b = run(False)
     names = [n for n, _ in CDAN().named_parameters()]
-    a = run(True)      # ONCE: a test is not a hunt (the opt-in schedule's open finding: DESIGN.md section 4, finding 6)
+    a = run(True)      # ONCE: a test is not a hunt (the opt-in schedule's open finding: profiles/LEDGER.md (rounds 1-4) section 4, finding 6)
     assert all(torch.equal(u, v) for u, v in zip(a[0], b[0]))
     bad = [n for n, u, v in zip(names, a[1], b[1]) if not torch.equal(u, v)]
     assert not bad, f"parameters differ: {bad[:6]}"

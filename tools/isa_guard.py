@@ -9,7 +9,7 @@ a register pair feeds both results, or the halves are exchanged), scratch instru
 
 Why.  Round 2 found `v_pk_fma_f32 ... op_sel:[0,1,1]` / `op_sel_hi:[1,0,0]` returning wrong values in lanes 48..63 in the
 epilogue of conv_first_pool_kernel -- a kernel that also issues MFMAs -- while another kernel shared the CU; the ISA of the
-failing and the passing build is under profiles/r03_pkfma_*.txt and the analysis in DESIGN.md section 4 (finding 6): every
+failing and the passing build is under profiles/r03_pkfma_*.txt and the analysis in profiles/LEDGER.md (rounds 1-4) section 4 (finding 6): every
 documented MFMA -> VALU wait-state rule is met with margin in both builds, so the mechanism is NOT explained.  Round 3 then saw
 the same thing ACROSS kernels: the MFMA-free backward kernels of cbam_train.hip (10-49 such forms each), bit-reproducible on
 one stream, gave different gradients in one training step out of three once the weight-gradient MFMA kernels ran beside them on

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the numbers in DESIGN.md come from, in one pass on a one-GPU MI355X box:  tools/measure_all.sh <tag>
+# Everything the numbers in DESIGN.md and profiles/LEDGER.md come from, in one pass on a one-GPU MI355X box:  tools/measure_all.sh <tag>
 # writes gpurun_out/<tag>/ ; copy what is to be kept into profiles/ afterwards (tools/collect_profiles.py <tag>).
 # rocprofv3 runs take the program itself after `--` (python3 ...), PMC passes are separate from each other and from --stats.
 set -u
