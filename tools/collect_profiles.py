@@ -38,7 +38,7 @@ with open(os.path.join(dst, f"{pre}_configs.txt"), "w") as f:
             "# PCIe-inclusive and batches-in-flight serving rates: output lines of tools/bench_train.py, bench_configs.py, bench_e2e.py,\n"
             "# bench_inflight.py on one MI355X (tools/measure_all.sh)\n")
     for name in ("configs_large_fp16", "configs_large_bf16", "configs_routed_bf16", "train_bf16_b8_512", "train_bf16_b8_256", "train_fp16_b8_512", "train_fp16_b8_256",
-                 "e2e_bf16", "inflight_bf16", "train_ddp1_bf16_b8_512", "train_host_enqueue", "configs_routed_groups_bf16"):
+                 "e2e_bf16", "inflight_bf16", "train_ddp1_bf16_b8_512", "train_ddp1_bf16_b8_256", "train_host_enqueue"):
         p = os.path.join(src, name + ".txt")
         if os.path.exists(p):
             f.write("".join(l for l in open(p) if "amdgpu.ids" not in l))

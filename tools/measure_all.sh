@@ -36,8 +36,8 @@ run conv_microbench python tools/bench_conv.py bf16 conv2 conv3 conv4 dec1 dec2 
 # what each stage costs the step (needs libmdie_hip_ablate.so: `tools/ablate.sh build` before the gpurun call)
 [ -f "$ROOT/multi-degradation-image-enhancement_amd/libmdie_hip_ablate.so" ] && run ablate_bf16 python tools/ablate.py bf16 3
 run train_host_enqueue python tools/host_time_train.py bf16 8 512
-run configs_routed_groups_bf16 python bench.py --workload routed --routed-mode groups
-run train_ddp1_bf16_b8_512 env MDIE_DDP_SINGLE=1 python tools/bench_train.py bf16 8 512 charbonnier:1,ssim:0.5 eager
+run train_ddp1_bf16_b8_512 env MDIE_DDP_SINGLE=1 python tools/bench_train.py bf16 8 512 charbonnier:1,ssim:0.5 both
+run train_ddp1_bf16_b8_256 env MDIE_DDP_SINGLE=1 python tools/bench_train.py bf16 8 256 charbonnier:1,ssim:0.5 both
 run bench_routed python bench.py --workload routed
 fi
 if [ "$PART" = benches ]; then echo "done (benches): $(ls "$OUT" | wc -l) files"; exit 0; fi
