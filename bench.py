@@ -404,7 +404,10 @@ def main():
                                   f"seeded random-init weights, synthetic low-light images resident in HBM",
                       "global_batch": B * world, "parallelism": f"batch-parallel x{world}, no collective",
                       "launch": (f"eager (one host call, {sum(v[0] for v in prof.values())} launches)" if graph is None else "hipGraph replay") + (", chosen in warmup" if args.launch == "auto" else ""),
-                      "runtime": args.runtime},
+                      "runtime": args.runtime,
+                      # encoder.conv4 runs on one of two bit-identical kernels, timed once per shape in the first (untimed) step: conv_wide, or
+                      # conv_kernel, which shares its CUs with the DenseBlock branches (mdie_amd/engine.py: CdanEngine.tune)
+                      "conv4_kernel": getattr(eng, "tuned", {"share_cu": eng.share_cu})},
            "roofline": roofline}
 
     if not args.no_extra and world == 1:

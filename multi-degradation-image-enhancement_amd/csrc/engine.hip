@@ -488,8 +488,25 @@ static bool ablated(const char* label) {
 static inline bool ablated(const char*) { return false; }
 #endif
 
+#ifdef EXP_SCHED   // schedule-exploration builds only (tools/sched_sweep.py): per-layer kernel choice and fork points from the environment
+static bool exp_listed(const char* var, const char* label) {
+  const char* v = getenv(var);
+  if (!v || !label) return false;
+  const size_t n = strlen(label);
+  for (const char* p = v; (p = strstr(p, label)); p += n)
+    if ((p == v || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
+  return false;
+}
+static int exp_fork_pos(int block, int dflt) {      // MDIE_EXP_FORK = "p1,p2,p3": where dense1 / dense2 / dense3 start
+  const char* v = getenv("MDIE_EXP_FORK");
+  if (!v) return dflt;
+  int p[3] = {-1, -1, -1};
+  sscanf(v, "%d,%d,%d", &p[0], &p[1], &p[2]);
+  return p[block] >= 0 ? p[block] : dflt;
+}
+#endif
 static int run_conv(const Ctx& c, const char* label, int id, int H, int W, std::initializer_list<Buf> in, const Buf& out, int act, int pool,
-                    const Buf* residual, float* out_nchw3 = nullptr, float* pool_partial = nullptr, const mdie_tr_fuse* tr = nullptr) {
+                    const Buf* residual, float* out_nchw3 = nullptr, float* pool_partial = nullptr, const mdie_tr_fuse* tr = nullptr, bool share_cu = false) {
   const ConvSpec& s = arch(c.dtype).conv[id];
   if (ablated(label)) return MDIE_OK;
   const int from = c.notes ? c.notes->mark() : 0;
@@ -513,6 +530,10 @@ static int run_conv(const Ctx& c, const char* label, int id, int H, int W, std::
   d.pool_partial = pool_partial;
   d.tr = tr;
   d.blob_delta = c.delta;
+  d.share_cu = share_cu ? 1 : 0;
+#ifdef EXP_SCHED
+  if (getenv("MDIE_EXP_NOWIDE")) d.share_cu = label && exp_listed("MDIE_EXP_NOWIDE", label);
+#endif
   const int rc = mdie_conv_fwd(&d, c.stream);
   if (c.notes && label && !tr) {
     const double pin = (double)H * W;
@@ -715,9 +736,28 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   // dense3 is needed first (cbam1) and stays where it was; dense1 and dense2 start after conv4 and run beside the bottleneck CBAM,
   // dec.conv1 and the decoder's small kernels: 30.2 k -> 31.0 k images/s (+2.6 %; all three after conv4 +2.3 %, only dense1 late
   // +2.2 %, all after the bottleneck +1 %, all three in line on ONE side stream -2 %; stream priorities: nothing).
+#ifdef EXP_SCHED
+  // fork positions: 0 after conv1, 1 after conv2, 2 after conv3, 3 after conv4, 4 after the bottleneck, 5 after dec.conv1 (dense1 / dense2 only),
+  // 6 after cbam1, 7 after dec.conv2, 8 after up2 (dense1 only), 9 after cbam2, 10 after dec.conv3
+  const int fpos[3] = {exp_fork_pos(0, 3), exp_fork_pos(1, 3), exp_fork_pos(2, 2)};
+  const int fhh[3] = {h1, h2, h3}, fww[3] = {w1, w2, w3};
+  auto fork_here = [&](int pos) -> int {
+    for (int k = 2; k >= 0; --k) if (fpos[k] == pos) if (int rc = side_dense(k, fhh[k], fww[k])) return rc;
+    return MDIE_OK;
+  };
+#define FORK_AT(p) RUN(fork_here(p))
+#else
+#define FORK_AT(p)
+#endif
+  FORK_AT(0);
   RUN(run_conv(c, "enc.conv2+pool", CV_E2, h1, w1, {P.o[0]}, P.o[1], MDIE_ACT_RELU, 1, nullptr));
+  FORK_AT(1);
   RUN(run_conv(c, "enc.conv3+pool", CV_E3, h2, w2, {P.o[1]}, P.o[2], MDIE_ACT_RELU, 1, nullptr));
+#ifdef EXP_SCHED
+  FORK_AT(2);
+#else
   RUN(side_dense(2, h3, w3));
+#endif
   // the two CBAMs at the deep end pool tensors a 64-wide convolution has just written: that convolution emits the
   // per-tile channel sums / maxima itself (one slab per tile), unless the picture is so large that a gate would
   // have to fold more than MDIE_POOL_SLABS_MAX of them
@@ -725,20 +765,33 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   const int te = mdie_conv_tile(B, h3, w3, 512), td = mdie_conv_tile(B, h3, w3, 256);
   const int slabs_e = cdiv(h3, te) * cdiv(w3, te), slabs_d = cdiv(h3, td) * cdiv(w3, td);
   const bool fuse_e = slabs_e <= MDIE_POOL_SLABS_MAX, fuse_d = slabs_d <= MDIE_POOL_SLABS_MAX;
-  RUN(run_conv(c, fuse_e ? "enc.conv4+pool-stats" : "enc.conv4", CV_E4, h3, w3, {P.o[2]}, P.e, MDIE_ACT_RELU, 0, nullptr, nullptr, fuse_e ? pool_buf : nullptr));
+  // (MDIE_FWD_SHARE_CU_CONV4: the one layer whose kernel choice moves the step -- dense3 runs beside it, dense1 / dense2 start behind it)
+  RUN(run_conv(c, fuse_e ? "enc.conv4+pool-stats" : "enc.conv4", CV_E4, h3, w3, {P.o[2]}, P.e, MDIE_ACT_RELU, 0, nullptr, nullptr, fuse_e ? pool_buf : nullptr, nullptr,
+               (d->flags & MDIE_FWD_SHARE_CU_CONV4) != 0));
+#ifdef EXP_SCHED
+  FORK_AT(3);
+#else
   RUN(side_dense(1, h2, w2));
   RUN(side_dense(0, h1, w1));
+#endif
   // bottleneck, models/cdan.py:173
   RUN(run_cbam_stage(c, P, CB_BOTT, h3, w3, P.e, nullptr, P.bott, fuse_e ? slabs_e : 0));
+  FORK_AT(4);
   // Decoder.forward, models/cdan.py:126-159
   RUN(run_conv(c, fuse_d ? "dec.conv1+skip2+pool-stats" : "dec.conv1+skip2", CV_D1, h3, w3, {P.bott}, P.t1, MDIE_ACT_RELU, 0, &P.o[2], nullptr, fuse_d ? pool_buf : nullptr));   // convT+BN+ReLU, + skip2
+  FORK_AT(5);
   RUN(join_dense(2));
   RUN(run_cbam_stage(c, P, CB_1, h3, w3, P.t1, &P.d[2], P.u1, fuse_d ? slabs_d : 0));  // cbam1, *= dense3
+  FORK_AT(6);
   RUN(run_conv(c, "dec.conv2", CV_D2, h3, w3, {P.u1}, P.t2lo, MDIE_ACT_RELU, 0, nullptr));
+  FORK_AT(7);
   RUN(run_up(c, P, "up2+skip1+pool", h3, w3, P.t2lo, P.o[1], P.t2));                    // bilinear x2 + skip1
+  FORK_AT(8);
   RUN(join_dense(1));
   RUN(run_cbam_stage(c, P, CB_2, h2, w2, P.t2, &P.d[1], P.u2, mdie_pool_slabs(h2, w2)));
+  FORK_AT(9);
   RUN(run_conv(c, "dec.conv3", CV_D3, h2, w2, {P.u2}, P.t3lo, MDIE_ACT_RELU, 0, nullptr));
+  FORK_AT(10);
   RUN(run_up(c, P, "up3+skip0+pool", h2, w2, P.t3lo, P.o[0], P.t3));
   RUN(join_dense(0));
   // (cbam3's last pass as decoder.conv4's staging prologue -- mdie_cbam_conv_fwd, rounds 4 -- measured 68-69 us against 41 + 27 for the two

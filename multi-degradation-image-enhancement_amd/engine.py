@@ -5,6 +5,7 @@ operation of the path runs in libmdie_hip.so.
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 import torch
@@ -60,6 +61,21 @@ def pack_checkpoint(state_dict, dtype):
     return blob
 
 
+# encoder.conv4 on the kernel that shares its CUs (MDIE_FWD_SHARE_CU_CONV4) or on conv_wide: bit-identical, and which one makes the STEP
+# faster depends on the box -- measured round 5 (profiles/r05m_sched_sweep.txt, r05n_*): -30 us of 1052 on one box, -2 % on a second,
+# +10 us of 1007 on a third, the fastest.  conv_wide is the denser matrix kernel and runs alone on its CU; on boxes whose clock
+# management pulls it down further, the three DenseBlock branches queueing behind it cost more than the 9 us the other kernel loses
+# alone.  So the choice is TIMED, once per (device, element type, batch shape) and process: CdanEngine.tune.
+# MDIE_SHARE_CU_CONV4 = auto (default) | 0 | 1 fixes it.
+_SHARE_CU = {}
+
+
+def _share_cu_eligible(dtype, B, H, W):
+    """conv_wide takes encoder.conv4 only for 16-bit types, maps of whole 32x16 tiles and at least 96 items (csrc/conv_wide.hip)"""
+    h, w = H // 8, W // 8
+    return dtype != L.F32 and H % 8 == 0 and W % 8 == 0 and h % 16 == 0 and w % 32 == 0 and B * (h // 16) * (w // 32) * 8 >= 96
+
+
 class CdanEngine:
     """Eval-mode CDAN forward on one GPU.  One instance per (device, precision) AND per forward in flight: the engine owns
     one workspace and one set of side streams, so two forwards that may overlap (issued on different streams) need two
@@ -74,9 +90,52 @@ class CdanEngine:
         self._ws = None
         self._ws_key = None
         self.use_side_streams = os.environ.get("MDIE_SIDE_STREAMS", "1") != "0"
+        mode = os.environ.get("MDIE_SHARE_CU_CONV4", "auto")
+        self.share_cu = None if mode == "auto" else (mode == "1")      # None: timed per batch shape (tune)
         self._aux = C.c_void_p(0)
         with torch.cuda.device(self.device):
             L.check(L.lib.mdie_aux_create(C.byref(self._aux)), "mdie_aux_create")
+
+    def tune(self, x, rounds=4, steps=40):
+        """Decide, for x's batch shape, which of the two bit-identical kernels encoder.conv4 runs on: `rounds` alternating rounds of
+        `steps` eager forwards each, the first round discarded (about a third of a second at B = 32, 256x256, once per shape and
+        process; synchronises the device).  The runs must be LONG: what separates the two forms is how far the clock management
+        pulls the matrix-dense kernel down under sustained load -- rounds of 8 forwards picked the wrong one on a box where 50-step
+        runs differ by 1.6 % the other way (gpurun_out/r05o).  Returns the decision; nothing is timed under stream capture (the untuned
+        default -- conv_wide -- is used and NOT remembered)."""
+        B, _, H, W = x.shape
+        key = (self.device.index, self.dtype, B, H, W, self.use_side_streams)
+        if self.share_cu is not None:
+            return self.share_cu
+        if key in _SHARE_CU:
+            return _SHARE_CU[key]
+        if not self.use_side_streams or not _share_cu_eligible(self.dtype, B, H, W):
+            _SHARE_CU[key] = False
+            return False
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        y = torch.empty_like(x, dtype=torch.float32)
+        times = {False: [], True: []}
+        with torch.no_grad():
+            for flag in (False, True):
+                self.share_cu = flag
+                for _ in range(3):
+                    self.forward(x, out=y)
+            for _ in range(rounds):
+                for flag in (False, True):
+                    self.share_cu = flag
+                    torch.cuda.synchronize(self.device)
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        self.forward(x, out=y)
+                    torch.cuda.synchronize(self.device)
+                    times[flag].append(time.perf_counter() - t0)
+        self.share_cu = None
+        med = {f: sorted(t[1:])[(len(t) - 1) // 2] for f, t in times.items()}       # (median of the rounds behind the first)
+        best = med[True] < med[False]
+        _SHARE_CU[key] = best
+        self.tuned = {"shape": (B, H, W), "conv_wide_us": round(med[False] / steps * 1e6, 1), "shared_cu_us": round(med[True] / steps * 1e6, 1), "share_cu": best}
+        return best
 
     def __del__(self):
         try:
@@ -102,8 +161,9 @@ class CdanEngine:
             self._ws_key = key
         return self._ws
 
-    def _flags(self, general_tail=False):
-        return (0 if self.use_side_streams else L.FWD_SERIAL) | (L.FWD_GENERAL_TAIL if general_tail else 0)
+    def _flags(self, general_tail=False, share_cu=False):
+        return ((0 if self.use_side_streams else L.FWD_SERIAL) | (L.FWD_GENERAL_TAIL if general_tail else 0)
+                | (L.FWD_SHARE_CU_CONV4 if share_cu else 0))
 
     def forward(self, x, out=None, want_taps=False, profile=False, general_tail=False):
         """x: float32 NCHW [B,3,H,W] on this engine's GPU -> float32 NCHW [B,3,H,W]."""
@@ -115,17 +175,18 @@ class CdanEngine:
         x = x.to(torch.float32).contiguous()
         B, _, H, W = x.shape
         ws = self._workspace(B, H, W)
+        share = self.share_cu if self.share_cu is not None else self.tune(x)
         if out is None and not want_taps and not profile:
             # the plain path goes through the registered operator (torch.ops.mdie.cdan_forward, ops.py)
             from . import ops  # noqa: F401  (registers the library)
             aux = self._aux.value if (self.use_side_streams and self._aux) else 0
-            return torch.ops.mdie.cdan_forward(x, self.params, ws, self.dtype, aux or 0, self._flags(general_tail))
+            return torch.ops.mdie.cdan_forward(x, self.params, ws, self.dtype, aux or 0, self._flags(general_tail, share))
         y = out if out is not None else torch.empty_like(x)
         d = L.CdanFwdDesc()
         d.dtype, d.B, d.H, d.W = self.dtype, B, H, W
         d.params, d.x, d.y = self.params.data_ptr(), x.data_ptr(), y.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-        d.flags = self._flags(general_tail)
+        d.flags = self._flags(general_tail, share)
         d.aux = self._aux if self.use_side_streams else None
         taps = (L.Tap * len(L.TAP_NAMES))() if want_taps else None
         if taps is not None:

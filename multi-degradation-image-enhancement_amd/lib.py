@@ -17,10 +17,11 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 25
+ABI_VERSION = 26
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_SERIAL = 2
 FWD_GENERAL_TAIL = 4
+FWD_SHARE_CU_CONV4 = 16
 LOSS_KINDS = {"mse": 0, "l1": 1, "charbonnier": 2, "ssim": 3, "gradient_l1": 4}
 
 TAP_NAMES = ("skip0", "skip1", "skip2", "dense0", "dense1", "dense2", "enc", "bott", "dec1", "dec2", "dec3", "dec4")
@@ -58,7 +59,7 @@ class ConvDesc(C.Structure):
                 ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int), ("pool", C.c_int),
                 ("residual", C.c_void_p), ("res_stride", C.c_int), ("out", C.c_void_p), ("out_stride", C.c_int),
                 ("out_nchw3", C.c_void_p), ("pool_partial", C.c_void_p), ("tr", C.POINTER(TrFuse)), ("out_group_stride", C.c_long),
-                ("bnred", C.POINTER(BnReduceFuse)), ("blob_delta", C.c_void_p)]
+                ("bnred", C.POINTER(BnReduceFuse)), ("blob_delta", C.c_void_p), ("share_cu", C.c_int)]
 
 
 class WgradDesc(C.Structure):
