@@ -208,3 +208,44 @@ def test_numa_binding_helper_is_inert_without_a_gpu(monkeypatch):
     assert 1 <= n <= len(os.sched_getaffinity(0))
     import torch
     assert H.cap_cpu_threads() <= max(n, 1) or torch.get_num_threads() <= n
+
+
+def test_ctypes_descriptors_match_the_header_layout():
+    """lib.py mirrors include/mdie.h by hand: a field appended in one and not in the other shifts everything behind it.  The structs the
+    engine passes most are checked against a C compiler's view of the header (gcc is in the image; no GPU involved)."""
+    import subprocess
+    import tempfile
+    import mdie_amd.lib as L
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "mdie.h"\nint main(void) {\n'
+    checks = {"mdie_conv_desc": (L.ConvDesc, ["dtype", "ksize", "cin", "weight", "out", "tr", "out_group_stride", "bnred", "blob_delta", "share_cu"]),
+              "mdie_seg": (L.Seg, ["ptr", "channels", "stride"]),
+              "mdie_tr_fuse": (L.TrFuse, ["weight", "c0", "partial_out", "act", "out_nchw3"])}
+    for name, (_, fields) in checks.items():
+        src += f'  printf("{name} %zu", sizeof({name}));\n'
+        for f in fields:
+            src += f'  printf(" %zu", offsetof({name}, {f}));\n'
+        src += '  printf("\\n");\n'
+    src += "  return 0;\n}\n"
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, "layout.c"), os.path.join(d, "layout")
+        with open(c, "w") as fh:
+            fh.write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    import ctypes as C
+    for line in out.splitlines():
+        name, size, *offs = line.split()
+        cls, fields = checks[name]
+        assert C.sizeof(cls) == int(size), (name, C.sizeof(cls), size)
+        for f, o in zip(fields, offs):
+            py = {"in": "inp"}.get(f, f)
+            assert getattr(cls, py).offset == int(o), (name, f, getattr(cls, py).offset, o)
+
+
+def test_conv4_kernel_choice_is_only_timed_where_conv_wide_applies():
+    import mdie_amd.engine as E
+    import mdie_amd.lib as L
+    assert E._share_cu_eligible(L.BF16, 32, 256, 256) and E._share_cu_eligible(L.F16, 8, 256, 256) and E._share_cu_eligible(L.BF16, 4, 1024, 1024)
+    assert not E._share_cu_eligible(L.F32, 32, 256, 256)          # fp32 never takes conv_wide
+    assert not E._share_cu_eligible(L.BF16, 2, 64, 64)            # the 8x8 map is no whole 32x16 tile
+    assert not E._share_cu_eligible(L.BF16, 1, 256, 256)          # 16 items: conv_wide declines below 96
