@@ -26,8 +26,9 @@ def main():
     import mdie_amd.train as T
     from models.cdan import CDAN
     from oracle import params as P
+    from mdie_amd import launch as LA      # (a port the kernel hands out: the 29500 range is where every torch job on a shared host looks first)
     if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29500 + os.getpid() % 2000}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{LA.free_port()}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         sd = P.make_state_dict(42)
         batches = [tuple(v.cuda() for v in P.lowlight_batch(31 + i, 2, 64, 64)) for i in range(2)]

@@ -10,6 +10,14 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """a rendezvous port the kernel hands out (a fixed 29500-range port collides with other torch jobs on a shared host)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -28,7 +36,7 @@ def _worker(rank, world, port, q):
 def test_two_rank_timing_and_sharding():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -72,7 +80,7 @@ def test_bucketed_gradient_allreduce_two_ranks():
     """SURVEY.md 8e / fixture c-4 semantics: after the exchange every rank holds the MEAN of the per-shard gradients."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -103,7 +111,7 @@ def test_driver_shards_the_dataset_under_torchrun_env():
     """`run.py` under torchrun: every rank joins the group and reads a disjoint shard; together they cover the dataset"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_loader_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -145,7 +153,7 @@ def test_gradbuckets_deliver_the_reference_two_shard_mean():
     gradients of the real parameter set; after GradBuckets' bucketed all-reduce every rank holds their mean."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 35500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_ddp_fixture_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -240,7 +248,7 @@ def test_gradients_are_views_of_the_flat_buckets_two_ranks():
     only gradient ever copied in is the one an ordinary autograd node produced, and every rank ends with the two-shard mean."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 37500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_sink_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -283,7 +291,7 @@ def test_routed_batch_is_dealt_by_task_two_ranks():
     own weight sets), un-routed images are spread; the step time is the max over ranks.  No collective on the data path."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 39500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_routed_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

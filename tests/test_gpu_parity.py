@@ -2400,7 +2400,8 @@ def test_ddp_one_rank_nccl_gradients_live_in_the_buckets(E, monkeypatch):
     the average of one).  Also with the weight gradients on their side stream, and for a replayed CapturedStep + exchange()."""
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ddp_one_rank_gpu.py")], capture_output=True, text=True, timeout=600)
-    assert "DDP-ONE-RANK-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    if "DDP-ONE-RANK-OK" not in r.stdout:
+        pytest.fail("tests/ddp_one_rank_gpu.py did not finish its checks (rc %d)\n--- stdout\n%s\n--- stderr\n%s" % (r.returncode, r.stdout[-3000:], r.stderr[-8000:]), pytrace=False)
     if "DDP-TEARDOWN-OK" not in r.stdout or r.returncode != 0:
         import warnings
         warnings.warn(f"one-rank RCCL checks passed, but the child's process-group teardown did not end cleanly (rc {r.returncode}): {r.stderr[-500:]}")

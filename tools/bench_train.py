@@ -37,7 +37,9 @@ dist = None
 if world > 1 or os.environ.get("MDIE_DDP_SINGLE") == "1":
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    if "MASTER_PORT" not in os.environ:
+        from mdie_amd import launch as _LA2
+        os.environ["MASTER_PORT"] = str(_LA2.free_port())
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 x, t = P.lowlight_batch(100 + rank, B, S, S)
 x, t = x.cuda(), t.cuda()
