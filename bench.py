@@ -405,9 +405,9 @@ def main():
                       "global_batch": B * world, "parallelism": f"batch-parallel x{world}, no collective",
                       "launch": (f"eager (one host call, {sum(v[0] for v in prof.values())} launches)" if graph is None else "hipGraph replay") + (", chosen in warmup" if args.launch == "auto" else ""),
                       "runtime": args.runtime,
-                      # encoder.conv4 runs on one of two bit-identical kernels, timed once per shape in the first (untimed) step: conv_wide, or
-                      # conv_kernel, which shares its CUs with the DenseBlock branches (mdie_amd/engine.py: CdanEngine.tune)
-                      "conv4_kernel": getattr(eng, "tuned", {"share_cu": eng.share_cu})},
+                      # encoder.conv4 runs in one of three bit-identical forms, timed once per shape in the first (untimed) step: how long it
+                      # holds its CUs while the DenseBlock branches wait for them (mdie_amd/engine.py: CdanEngine.tune)
+                      "conv4_form": getattr(eng, "tuned", {"form": eng.share_cu})},
            "roofline": roofline}
 
     if not args.no_extra and world == 1:

@@ -133,11 +133,13 @@ typedef struct {
                                     parameter pointer of this descriptor (weight, pre_* / post_* vectors, the members of `tr`): all
                                     parameter blobs of one architecture share one layout (mdie_cdan_pack_params), so one offset per image
                                     selects its weight set.  NULL: one weight set.  Not with out_group_stride / bnred (training). */
-  int share_cu;            /* 0: the library's choice of kernel.  1: among kernels that are bit-identical for this layer, take the one that leaves
-                              room for OTHER workgroups on its CUs -- conv_kernel (three ~50 KB workgroups per CU) instead of conv_wide (one
-                              workgroup per CU holding 154 of its 160 KB of LDS).  Slower alone (encoder.conv4: 89 against 80 us), faster for
-                              the step on boxes whose clock management pulls the matrix-dense kernel down while DenseBlock workgroups wait for
-                              a CU (round 5: -30 us of 1052 on one box, +10 of 1007 on another; the host tunes it per box, ABI 26). */
+  int share_cu;            /* How the layer treats the CUs it runs on, among forms that are BIT-IDENTICAL for it (ABI 26).  0: the library's choice -- for
+                              the wide layers conv_wide as ONE persistent workgroup per CU, which holds the CU and all of its LDS until the launch
+                              ends: kernels of a side branch queue behind the whole layer.  2: conv_wide with twice the workgroups, each with half
+                              the run of items -- every CU returns to the dispatcher half way (2 us slower alone; encoder.conv4: -29 ... -34 us for
+                              the step, the DenseBlock branches slip in).  1: conv_kernel instead (three ~50 KB workgroups per CU; 89 against 80 us
+                              alone; -14 ... -30 us for the step on some boxes, +10 on the fastest).  Which form makes the STEP fastest depends on
+                              the box (how far its clock management pulls the matrix-dense kernel down): the host times them (CdanEngine.tune). */
 } mdie_conv_desc;
 
 /* The BatchNorm-ReLU backward SUMS fused into the input-gradient convolution of a DenseBlock layer (training).  The convolution's
@@ -414,7 +416,8 @@ enum { /* 1: was MDIE_FWD_FUSED_TAIL (the whole decoder tail as one launch, roun
        MDIE_FWD_GENERAL_TAIL = 4 /* decoder.final_dense as the general chain (3x3 layers, then the 1x1 launch) also where the transition
                                     could be folded into its producers (mdie_tr_fuse): the form fp32 and ragged extents always take */,
        MDIE_FWD_SHARE_CU_CONV4 = 16 /* encoder.conv4 with mdie_conv_desc.share_cu = 1: the layer the three DenseBlock branches run beside.  Results are
-                                       bit-identical either way; which is faster depends on the box (CdanEngine.tune times both) */
+                                       bit-identical either way; which is faster depends on the box (CdanEngine.tune times the forms) */,
+       MDIE_FWD_YIELD_CU_CONV4 = 32 /* encoder.conv4 with mdie_conv_desc.share_cu = 2 (wins over 16 when both are set) */
        /* 8: was MDIE_FWD_FUSED_CBAM3 (cbam3's last pass fused into decoder.conv4, round 4): 68 us against 41 + 27, removed in round 5 */ };
 
 enum { MDIE_K_LAYOUT = 0, MDIE_K_CONV3 = 1, MDIE_K_CONV1 = 2, MDIE_K_CBAM_POOL = 3, MDIE_K_CBAM_GATE = 4,

@@ -633,8 +633,8 @@ static int dispatch_conv(const mdie_conv_desc* d, hipStream_t stream) {
     return launch_conv_planar(Traits<T>::DT, a, d->ksize, stream);
   }
   MDIE_REQUIRE(!d->bnred, "mdie_conv_fwd: bnred rides on the planar output (out_group_stride)");
-  if (!d->share_cu)   // (share_cu: conv_kernel below -- bit-identical, leaves LDS and registers for other workgroups on the CU)
-  if (conv_wide_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr)) return launch_conv_wide(Traits<T>::DT, a, stream);
+  // (share_cu = 1: conv_kernel below -- bit-identical, leaves LDS and registers for other workgroups on the CU; 2: conv_wide in shorter runs)
+  if (d->share_cu != 1 && conv_wide_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr)) return launch_conv_wide(Traits<T>::DT, a, stream, d->share_cu == 2);
   if (d->tr) {   // the block's transition folded into this layer: conv_thin_kernel only (csrc/conv_thin.hip)
     MDIE_REQUIRE(conv_thin_applicable(Traits<T>::DT, a, d->ksize, d->out_nchw3 != nullptr, true),
                  "mdie_conv_fwd: tr needs a 16-bit 3x3 layer with pre-activation, 16 outputs, <= 56 stored input channels and H, W multiples of 16");

@@ -372,7 +372,7 @@ __device__ __forceinline__ void conv_epilogue(const EpiArgs& e, const float4 (&e
 // conv_wide.hip: LDS-DMA staged 3x3 convolution for wide layers (>= 64 channels in and out); MDIE_OK, or MDIE_EINVAL when
 // the shape is not one it handles (the caller then uses conv_kernel)
 bool conv_wide_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw3);
-int launch_conv_wide(int dtype, ConvArgs& a, hipStream_t stream);
+int launch_conv_wide(int dtype, ConvArgs& a, hipStream_t stream, bool yield_cu = false);   // yield_cu: twice the workgroups, each with half the items (mdie_conv_desc.share_cu = 2)
 // conv_thin.hip: persistent, register-prefetched 3x3 convolution for pre-activated 16-output layers with <= 64 stored input
 // channels on full 16x16 tiles (decoder.final_dense)
 bool conv_thin_applicable(int dtype, const ConvArgs& a, int ksize, bool has_nchw3, bool any_batch = false);

@@ -24,6 +24,10 @@
 // 64-byte zero page instead (nn.Conv2d's zero padding).
 // The epilogue is conv.hip's (conv_common.hpp): affine + ReLU, residual, 2x2 max-pool, CBAM pooling partials -- results are
 // bit-identical to conv_kernel's (same MFMA order per output element: chunks, then taps, in sequence).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include "conv_common.hpp"
 
 namespace mdie {
@@ -390,7 +394,7 @@ static int launch_wide_t(WideArgs& w, hipStream_t stream) {
   return MDIE_OK;
 }
 
-int launch_conv_wide(int dtype, ConvArgs& a, hipStream_t stream) {
+int launch_conv_wide(int dtype, ConvArgs& a, hipStream_t stream, bool yield_cu) {
   WideArgs w{};
   static int cus = 0;
   if (!cus) {
@@ -407,6 +411,22 @@ int launch_conv_wide(int dtype, ConvArgs& a, hipStream_t stream) {
   w.items = a.B * w.tiles_x * w.tiles_y * a.n_tiles;
   w.per_xcd = cdiv(w.items, 8);
   w.wgs_per_xcd = w.per_xcd < cus / 8 ? w.per_xcd : cus / 8;      // one persistent workgroup per CU at most
+  // yield_cu (mdie_conv_desc.share_cu = 2): twice as many workgroups, each with half the run of items.  A persistent workgroup holds its CU
+  // -- and all of its LDS -- until the LAUNCH ends, so the kernels of a side branch (the encoder DenseBlocks beside encoder.conv4) queue
+  // behind the whole layer; with two shorter runs per CU the dispatcher gets every CU back half way and the branch's workgroups slip in.
+  // 2 us slower alone (the stage ring restarts once more per CU), -29 ... -34 us for the step on the boxes where it was swept.
+  if (yield_cu) { const int cap = (cus / 8) * 2; w.wgs_per_xcd = w.per_xcd < cap ? w.per_xcd : cap; }
+#ifdef EXP_SCHED   // schedule-exploration builds only (tools/sched_sweep.py): MDIE_EXP_WIDE_WGS="<cin>x<cout>:<m>,..." -- m x as many workgroups as CUs
+                   // for that layer (each with 1/m of the items: a CU is handed back to the dispatcher between them instead of held to the end)
+  if (const char* v = getenv("MDIE_EXP_WIDE_WGS")) {
+    char key[32];
+    snprintf(key, sizeof key, "%dx%d:", a.cin, a.cout);
+    if (const char* q = strstr(v, key)) {
+      const int m = atoi(q + strlen(key));
+      if (m > 1) { const int cap = (cus / 8) * m; w.wgs_per_xcd = w.per_xcd < cap ? w.per_xcd : cap; }
+    }
+  }
+#endif
   // (fewer workgroups with several items each -- the next item's first DMA under the previous item's epilogue -- measured for the layers
   //  that have one item per CU: dec.conv2 24.5 -> 38.1 us, dec.conv3 24.9 -> 35.3 us on 128 workgroups x 2 items: profiles/r05e_ab_wide_two_items.txt)
   if (dtype == MDIE_BF16) return launch_wide_t<bf16>(w, stream);

@@ -506,7 +506,7 @@ static int exp_fork_pos(int block, int dflt) {      // MDIE_EXP_FORK = "p1,p2,p3
 }
 #endif
 static int run_conv(const Ctx& c, const char* label, int id, int H, int W, std::initializer_list<Buf> in, const Buf& out, int act, int pool,
-                    const Buf* residual, float* out_nchw3 = nullptr, float* pool_partial = nullptr, const mdie_tr_fuse* tr = nullptr, bool share_cu = false) {
+                    const Buf* residual, float* out_nchw3 = nullptr, float* pool_partial = nullptr, const mdie_tr_fuse* tr = nullptr, int share_cu = 0) {
   const ConvSpec& s = arch(c.dtype).conv[id];
   if (ablated(label)) return MDIE_OK;
   const int from = c.notes ? c.notes->mark() : 0;
@@ -530,7 +530,7 @@ static int run_conv(const Ctx& c, const char* label, int id, int H, int W, std::
   d.pool_partial = pool_partial;
   d.tr = tr;
   d.blob_delta = c.delta;
-  d.share_cu = share_cu ? 1 : 0;
+  d.share_cu = share_cu;
 #ifdef EXP_SCHED
   if (getenv("MDIE_EXP_NOWIDE")) d.share_cu = label && exp_listed("MDIE_EXP_NOWIDE", label);
 #endif
@@ -767,7 +767,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
   const bool fuse_e = slabs_e <= MDIE_POOL_SLABS_MAX, fuse_d = slabs_d <= MDIE_POOL_SLABS_MAX;
   // (MDIE_FWD_SHARE_CU_CONV4: the one layer whose kernel choice moves the step -- dense3 runs beside it, dense1 / dense2 start behind it)
   RUN(run_conv(c, fuse_e ? "enc.conv4+pool-stats" : "enc.conv4", CV_E4, h3, w3, {P.o[2]}, P.e, MDIE_ACT_RELU, 0, nullptr, nullptr, fuse_e ? pool_buf : nullptr, nullptr,
-               (d->flags & MDIE_FWD_SHARE_CU_CONV4) != 0));
+               (d->flags & MDIE_FWD_YIELD_CU_CONV4) ? 2 : (d->flags & MDIE_FWD_SHARE_CU_CONV4) ? 1 : 0));
 #ifdef EXP_SCHED
   FORK_AT(3);
 #else

@@ -61,12 +61,14 @@ def pack_checkpoint(state_dict, dtype):
     return blob
 
 
-# encoder.conv4 on the kernel that shares its CUs (MDIE_FWD_SHARE_CU_CONV4) or on conv_wide: bit-identical, and which one makes the STEP
-# faster depends on the box -- measured round 5 (profiles/r05m_sched_sweep.txt, r05n_*): -30 us of 1052 on one box, -2 % on a second,
-# +10 us of 1007 on a third, the fastest.  conv_wide is the denser matrix kernel and runs alone on its CU; on boxes whose clock
-# management pulls it down further, the three DenseBlock branches queueing behind it cost more than the 9 us the other kernel loses
-# alone.  So the choice is TIMED, once per (device, element type, batch shape) and process: CdanEngine.tune.
-# MDIE_SHARE_CU_CONV4 = auto (default) | 0 | 1 fixes it.
+# How encoder.conv4 treats its CUs -- three BIT-IDENTICAL forms (include/mdie.h: mdie_conv_desc.share_cu):
+#   0  conv_wide, one persistent workgroup per CU: fastest alone, but it holds every CU (and all of its LDS) until the layer ends, and the
+#      DenseBlock branches that run beside the layer queue behind it;
+#   2  conv_wide in two shorter runs per CU: every CU goes back to the dispatcher half way (MDIE_FWD_YIELD_CU_CONV4);
+#   1  conv_kernel: three ~50 KB workgroups per CU, 9 us slower alone (MDIE_FWD_SHARE_CU_CONV4).
+# Which makes the STEP fastest depends on the box -- round 5, tools/sched_sweep.py, profiles/r05m_sched_sweep.txt, r05u_*: form 2 -29 ... -34 us
+# of 1045 on two boxes, form 1 -30 us of 1052 on a third and +10 of 1007 on the fastest one.  So the choice is TIMED, once per (device,
+# element type, batch shape) and process: CdanEngine.tune.  MDIE_SHARE_CU_CONV4 = auto (default) | 0 | 1 | 2 fixes it.
 _SHARE_CU = {}
 
 
@@ -91,18 +93,17 @@ class CdanEngine:
         self._ws_key = None
         self.use_side_streams = os.environ.get("MDIE_SIDE_STREAMS", "1") != "0"
         mode = os.environ.get("MDIE_SHARE_CU_CONV4", "auto")
-        self.share_cu = None if mode == "auto" else (mode == "1")      # None: timed per batch shape (tune)
+        self.share_cu = None if mode == "auto" else int(mode)          # None: timed per batch shape (tune); 0 / 1 / 2: the form
         self._aux = C.c_void_p(0)
         with torch.cuda.device(self.device):
             L.check(L.lib.mdie_aux_create(C.byref(self._aux)), "mdie_aux_create")
 
     def tune(self, x, rounds=4, steps=40):
-        """Decide, for x's batch shape, which of the two bit-identical kernels encoder.conv4 runs on: `rounds` alternating rounds of
-        `steps` eager forwards each, the first round discarded (about a third of a second at B = 32, 256x256, once per shape and
-        process; synchronises the device).  The runs must be LONG: what separates the two forms is how far the clock management
-        pulls the matrix-dense kernel down under sustained load -- rounds of 8 forwards picked the wrong one on a box where 50-step
-        runs differ by 1.6 % the other way (gpurun_out/r05o).  Returns the decision; nothing is timed under stream capture (the untuned
-        default -- conv_wide -- is used and NOT remembered)."""
+        """Decide, for x's batch shape, which of the three bit-identical forms encoder.conv4 runs in (above): `rounds` alternating rounds of
+        `steps` eager forwards per form, the first round discarded (about half a second at B = 32, 256x256, once per shape and
+        process; synchronises the device).  The runs must be LONG: what separates the forms is how the chip behaves under sustained
+        load -- rounds of 8 forwards picked the wrong one on a box where 50-step runs differ by 1.6 % the other way
+        (gpurun_out/r05o).  Returns the form (0, 1 or 2); nothing is timed under stream capture (form 0 is used and NOT remembered)."""
         B, _, H, W = x.shape
         key = (self.device.index, self.dtype, B, H, W, self.use_side_streams)
         if self.share_cu is not None:
@@ -110,31 +111,34 @@ class CdanEngine:
         if key in _SHARE_CU:
             return _SHARE_CU[key]
         if not self.use_side_streams or not _share_cu_eligible(self.dtype, B, H, W):
-            _SHARE_CU[key] = False
-            return False
+            _SHARE_CU[key] = 0
+            return 0
         if torch.cuda.is_current_stream_capturing():
-            return False
+            return 0
         y = torch.empty_like(x, dtype=torch.float32)
-        times = {False: [], True: []}
+        forms = (0, 2, 1)
+        times = {f: [] for f in forms}
         with torch.no_grad():
-            for flag in (False, True):
-                self.share_cu = flag
+            for f in forms:
+                self.share_cu = f
                 for _ in range(3):
                     self.forward(x, out=y)
             for _ in range(rounds):
-                for flag in (False, True):
-                    self.share_cu = flag
+                for f in forms:
+                    self.share_cu = f
                     torch.cuda.synchronize(self.device)
                     t0 = time.perf_counter()
                     for _ in range(steps):
                         self.forward(x, out=y)
                     torch.cuda.synchronize(self.device)
-                    times[flag].append(time.perf_counter() - t0)
+                    times[f].append(time.perf_counter() - t0)
         self.share_cu = None
         med = {f: sorted(t[1:])[(len(t) - 1) // 2] for f, t in times.items()}       # (median of the rounds behind the first)
-        best = med[True] < med[False]
+        best = min(forms, key=lambda f: med[f])
         _SHARE_CU[key] = best
-        self.tuned = {"shape": (B, H, W), "conv_wide_us": round(med[False] / steps * 1e6, 1), "shared_cu_us": round(med[True] / steps * 1e6, 1), "share_cu": best}
+        self.tuned = {"shape": (B, H, W), "form": best, "us_per_step": {"0 conv_wide, one run per CU": round(med[0] / steps * 1e6, 1),
+                                                                         "2 conv_wide, two runs per CU": round(med[2] / steps * 1e6, 1),
+                                                                         "1 conv_kernel": round(med[1] / steps * 1e6, 1)}}
         return best
 
     def __del__(self):
@@ -161,9 +165,9 @@ class CdanEngine:
             self._ws_key = key
         return self._ws
 
-    def _flags(self, general_tail=False, share_cu=False):
+    def _flags(self, general_tail=False, share_cu=0):
         return ((0 if self.use_side_streams else L.FWD_SERIAL) | (L.FWD_GENERAL_TAIL if general_tail else 0)
-                | (L.FWD_SHARE_CU_CONV4 if share_cu else 0))
+                | (L.FWD_SHARE_CU_CONV4 if share_cu == 1 else L.FWD_YIELD_CU_CONV4 if share_cu == 2 else 0))
 
     def forward(self, x, out=None, want_taps=False, profile=False, general_tail=False):
         """x: float32 NCHW [B,3,H,W] on this engine's GPU -> float32 NCHW [B,3,H,W]."""

@@ -821,32 +821,34 @@ def test_thin_single_chunk_conv(E, L, prec, cin_segs, shape, pre):
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(32, 256, 256), (8, 256, 256), (2, 256, 512), (3, 64, 64)])
-def test_conv4_on_the_cu_sharing_kernel_is_bit_identical(E, L, prec, shape):
-    """MDIE_FWD_SHARE_CU_CONV4 (mdie_conv_desc.share_cu): encoder.conv4 + BN + ReLU with the pooling partials of the bottleneck CBAM
-    (models/cdan.py:95-96, models/cbam.py:41,44) on conv_kernel instead of conv_wide.  The host picks between the two by TIMING them
-    (CdanEngine.tune), so they must agree bit for bit in the output and in every stage tap -- also where conv_wide does not apply and the
-    flag changes nothing (3 x 64 x 64).  And tune() must come back with a decision it remembers."""
+def test_conv4_forms_are_bit_identical(E, L, prec, shape):
+    """mdie_conv_desc.share_cu / MDIE_FWD_SHARE_CU_CONV4 / MDIE_FWD_YIELD_CU_CONV4: encoder.conv4 + BN + ReLU with the pooling partials of
+    the bottleneck CBAM (models/cdan.py:95-96, models/cbam.py:41,44) as conv_wide with one run of items per CU, with two shorter runs, or
+    on conv_kernel.  The host picks between the three by TIMING them (CdanEngine.tune), so they must agree bit for bit in the output
+    and in every stage tap -- also where conv_wide does not apply and the flags change nothing (3 x 64 x 64).  And tune() must come
+    back with a decision it remembers."""
     from oracle import params as P
     sd = P.make_state_dict(42)
     x, _ = P.lowlight_batch(44, *shape)
     x = x.cuda()
     eng = E.CdanEngine("cuda", prec).load(sd)
     outs = {}
-    for flag in (False, True):
-        eng.share_cu = flag
+    for form in (0, 1, 2):
+        eng.share_cu = form
         y, ex = eng.forward(x, want_taps=True)
-        outs[flag] = (y.clone(), {k: v.clone() for k, v in ex["taps"].items()})
+        outs[form] = (y.clone(), {k: v.clone() for k, v in ex["taps"].items()})
     torch.cuda.synchronize()
-    assert torch.equal(outs[False][0], outs[True][0])
-    for k in outs[False][1]:
-        assert torch.equal(outs[False][1][k], outs[True][1][k]), k
+    for form in (1, 2):
+        assert torch.equal(outs[0][0], outs[form][0]), form
+        for k in outs[0][1]:
+            assert torch.equal(outs[0][1][k], outs[form][1][k]), (form, k)
     eng.share_cu = None
     d1 = eng.tune(x)
     d2 = eng.tune(x)
-    assert d1 == d2 and isinstance(d1, bool)
-    assert torch.equal(eng.forward(x), outs[False][0])
+    assert d1 == d2 and d1 in (0, 1, 2)
+    assert torch.equal(eng.forward(x), outs[0][0])
     if not E._share_cu_eligible(eng.dtype, *shape):
-        assert d1 is False
+        assert d1 == 0
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])

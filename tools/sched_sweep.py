@@ -14,7 +14,7 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 configs = [tuple(l.split()) for l in sys.stdin.read().splitlines() if l.strip() and not l.startswith("#")]
-configs = [("-", "-")] + [c for c in configs if c != ("-", "-")]
+configs = [("-", "-")] + [c for c in configs if tuple(c) != ("-", "-")]
 net = CDAN(precision=prec)
 net.load_state_dict(P.make_state_dict(42), strict=True)
 net = net.eval().cuda()
@@ -25,7 +25,7 @@ ys = [torch.empty_like(x) for _ in configs]
 
 
 def setenv(c):
-    for var, v in (("MDIE_EXP_NOWIDE", c[0]), ("MDIE_EXP_FORK", c[1])):
+    for var, v in (("MDIE_EXP_NOWIDE", c[0]), ("MDIE_EXP_FORK", c[1]), ("MDIE_EXP_WIDE_WGS", c[2] if len(c) > 2 else "-")):
         if v == "-":
             os.environ.pop(var, None)
         else:
@@ -54,4 +54,4 @@ print(f"# {prec} B=32 256x256 eager, {rounds} interleaved rounds of {steps} step
 print(f"# {'conv_kernel instead of conv_wide':44s} {'fork d1,d2,d3':14s} {'step us':>8s} {'vs default':>10s}  same bits   rounds")
 for c, t, y in zip(configs, res, ys):
     m = sorted(t)[len(t) // 2]
-    print(f"  {c[0]:44s} {c[1]:14s} {m:8.1f} {m - base:+10.1f}  {str(bool(torch.equal(y, ys[0]))):9s}   " + " ".join(f"{v:.1f}" for v in t))
+    print(f"  {(c[0] + (' wgs ' + c[2] if len(c) > 2 else '')):44s} {c[1]:14s} {m:8.1f} {m - base:+10.1f}  {str(bool(torch.equal(y, ys[0]))):9s}   " + " ".join(f"{v:.1f}" for v in t))
