@@ -179,6 +179,9 @@ static int launch_conv1x1_stream(ConvArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)a.nchunk * 4 * (NCS * 16) * 16 + (size_t)2 * a.nchunk * KC * sizeof(float);
   int gx = 512 / a.n_tiles;                     // ~2 resident workgroups per CU, each walking many tiles
   if (gx < 64) gx = 64;
+#ifdef EXP_SCHED   // schedule-exploration builds only (tools/sched_sweep.py): MDIE_EXP_STREAM_WGS = m -- m x as many, m x shorter-lived workgroups
+  if (const char* v = getenv("MDIE_EXP_STREAM_WGS")) { const int m = atoi(v); if (m > 1) gx *= m; }
+#endif
   if (gx > tiles_total) gx = tiles_total;
   const dim3 grid(gx, a.n_tiles);
   TimedLaunch tl(MDIE_K_CONV1);

@@ -103,7 +103,7 @@ class CdanEngine:
         `steps` eager forwards per form, the first round discarded (about half a second at B = 32, 256x256, once per shape and
         process; synchronises the device).  The runs must be LONG: what separates the forms is how the chip behaves under sustained
         load -- rounds of 8 forwards picked the wrong one on a box where 50-step runs differ by 1.6 % the other way
-        (gpurun_out/r05o).  Returns the form (0, 1 or 2); nothing is timed under stream capture (form 0 is used and NOT remembered)."""
+        (gpurun_out/r05o).  Returns the form (0, 1 or 2); nothing is timed under stream capture (form 2 is used and NOT remembered)."""
         B, _, H, W = x.shape
         key = (self.device.index, self.dtype, B, H, W, self.use_side_streams)
         if self.share_cu is not None:
@@ -114,7 +114,7 @@ class CdanEngine:
             _SHARE_CU[key] = 0
             return 0
         if torch.cuda.is_current_stream_capturing():
-            return 0
+            return 2          # (untimed: the form that was never slower than form 0 by more than its 2 us alone, and up to 3 % faster)
         y = torch.empty_like(x, dtype=torch.float32)
         forms = (0, 2, 1)
         times = {f: [] for f in forms}
@@ -316,7 +316,7 @@ class RoutedEngine:
         d.dtype, d.B, d.H, d.W = self.dtype, n, H, W
         d.params, d.x, d.y = rows.data_ptr(), xs.data_ptr(), ys.data_ptr()
         d.workspace, d.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
-        d.flags, d.aux = 0, self._aux
+        d.flags, d.aux = (L.FWD_YIELD_CU_CONV4 if _share_cu_eligible(self.dtype, n, H, W) else 0), self._aux      # (untimed default: CdanEngine.tune)
         d.blob_delta = meta[1].data_ptr()
         L.check(L.lib.mdie_cdan_forward(C.byref(d), _stream_ptr(self.device)), "mdie_cdan_forward")
         self._keep = (meta, xs)          # (alive until the next call: the chain reads them asynchronously)
