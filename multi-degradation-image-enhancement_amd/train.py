@@ -347,7 +347,7 @@ def join_weight_gradients(dev):
 def _wgrad(dt, segs, dy, w_shape, ks, transposed, cin, cout, cout_st, pre=None, split=None, gap=0, param=None):
     """dW in the parameter's layout from the convolution's input segments and dy (stored cout_st channels)."""
     dev = dy.device
-    if (_wgrad_side_this_step and WGRAD_STREAM and (_wgrad_hooks_active == 0 or (_GRAD_SINK is not None and _GRAD_SINK.view_of(param) is not None))
+    if (_wgrad_side_this_step and WGRAD_STREAM and _wgrad_hooks_active == 0 and _GRAD_SINK is None     # (experimental schedule: never together with a gradient exchange)
             and param is not None and param.grad is None
             and not torch.is_grad_enabled()                                                                                   # create_graph: the gradient is cloned / differentiated on the main stream
             and not getattr(param, "_backward_hooks", None) and not getattr(param, "_post_accumulate_grad_hooks", None)     # a hook would read the gradient during backward
@@ -1077,9 +1077,8 @@ class GradBuckets:
     `.grad` at its slice.  A gradient that did not come from a sink-aware producer (any other autograd node, an existing
     `.grad` that autograd accumulated into) is copied into its slice by the hook -- the old path, still correct.
 
-    The weight-gradient side stream (train._wgrad, opt-in) stays usable: a bucket's all-reduce is issued from the side stream
-    after that stream has waited for the main one, so it is ordered behind both the dW kernels and the main stream's
-    BatchNorm / CBAM gradients of the bucket.
+    The weight-gradient side stream (train._wgrad, opt-in, EXPERIMENTAL: its round-3 finding has no cause) is never taken while a
+    GradBuckets is active: a data-parallel step runs the single-stream schedule.
 
     `exchange()` serves steps whose backward fired no hooks (a replayed CapturedStep): the captured kernels have written into
     the same slices (the sink was active at capture time), so it is the five all-reduces and nothing else."""
