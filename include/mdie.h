@@ -417,7 +417,9 @@ enum { /* 1: was MDIE_FWD_FUSED_TAIL (the whole decoder tail as one launch, roun
                                     could be folded into its producers (mdie_tr_fuse): the form fp32 and ragged extents always take */,
        MDIE_FWD_SHARE_CU_CONV4 = 16 /* encoder.conv4 with mdie_conv_desc.share_cu = 1: the layer the three DenseBlock branches run beside.  Results are
                                        bit-identical either way; which is faster depends on the box (CdanEngine.tune times the forms) */,
-       MDIE_FWD_YIELD_CU_CONV4 = 32 /* encoder.conv4 with mdie_conv_desc.share_cu = 2 (wins over 16 when both are set) */
+       MDIE_FWD_YIELD_CU_CONV4 = 32 /* encoder.conv4 with mdie_conv_desc.share_cu = 2 (wins over 16 when both are set) */,
+       MDIE_FWD_LATE_DENSE1 = 64    /* the dense1 branch (needed last, by cbam3) starts behind decoder.conv1 instead of behind encoder.conv4: a schedule,
+                                       not arithmetic -- bit-identical; another candidate of CdanEngine.tune */
        /* 8: was MDIE_FWD_FUSED_CBAM3 (cbam3's last pass fused into decoder.conv4, round 4): 68 us against 41 + 27, removed in round 5 */ };
 
 enum { MDIE_K_LAYOUT = 0, MDIE_K_CONV3 = 1, MDIE_K_CONV1 = 2, MDIE_K_CBAM_POOL = 3, MDIE_K_CBAM_GATE = 4,

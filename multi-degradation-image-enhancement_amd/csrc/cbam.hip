@@ -452,7 +452,7 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 static int nslab_for(int H, int W) { const int n = cdiv(H * W, POOL_MIN_SLAB), m = pool_max_slabs(H, W); return n < m ? n : m; }
 
 template <typename T>
-static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
+static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream, cbam_hook_fn before_last = nullptr, void* hook_ctx = nullptr) {
   constexpr int VEC = Traits<T>::VEC;
   CbamArgs a{};
   a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C;
@@ -514,6 +514,8 @@ static int run_cbam(const mdie_cbam_desc* d, bool spatial, hipStream_t stream) {
     MDIE_LAUNCH_CHECK("cbam_chanpool");
   }
   {
+    // (the last pass is the only one that reads `mul`: a caller whose multiplicand comes from another stream joins it HERE)
+    if (before_last) if (int rc = before_last(hook_ctx)) return rc;
     const size_t lds = (size_t)(d->C + 2 * 22 * 22 + 256 + 100) * sizeof(float);
     // 1 KiB-per-pixel tensors (C >= 256) sit at 32x32 in this network: 16x16 tiles would give 128 blocks
     const int ts = d->C >= 256 ? 8 : 16;
@@ -553,6 +555,15 @@ extern "C" size_t mdie_cbam_workspace_bytes(int B, int H, int W, int C) {
   return align256((size_t)B * nslab_for(H, W) * 2 * C * sizeof(float)) + align256((size_t)B * C * sizeof(float)) +
          align256((size_t)B * H * W * 2 * sizeof(float));
 }
+
+namespace mdie {
+// mdie_cbam_fwd with a hook run between the channel-pool pass and the spatial pass (engine.hip: the join of the DenseBlock branch whose
+// output is this CBAM's multiplicand -- models/cdan.py:133,141,149 -- so that the branch has the first passes' time to finish)
+int cbam_fwd_hooked(const mdie_cbam_desc* d, hipStream_t stream, cbam_hook_fn before_last, void* ctx) {
+  if (int e = check_cbam(d)) return e;
+  MDIE_SWITCH_T(d->dtype, return run_cbam<T>(d, true, stream, before_last, ctx));
+}
+}  // namespace mdie
 
 extern "C" int mdie_cbam_fwd(const mdie_cbam_desc* d, void* stream) {
   using namespace mdie;

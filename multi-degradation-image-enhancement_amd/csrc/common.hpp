@@ -242,4 +242,8 @@ struct TimedLaunch {
   ~TimedLaunch() { if (t) t->end(); }
 };
 
+// cbam.hip: mdie_cbam_fwd with a hook between its channel-pool pass and its last pass (used by engine.hip)
+typedef int (*cbam_hook_fn)(void* ctx);
+int cbam_fwd_hooked(const mdie_cbam_desc* d, hipStream_t stream, cbam_hook_fn before_last, void* ctx);
+
 }  // namespace mdie

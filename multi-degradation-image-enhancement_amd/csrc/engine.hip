@@ -560,7 +560,7 @@ static int run_dense(const Ctx& c, int block, int H, int W, const Buf& base, con
 
 // pooled_slabs > 0: the producer of x already wrote that many pooling partials per image into the plan's pool buffer
 static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, const Buf& x, const Buf* mul, const Buf& out,
-                          int pooled_slabs = 0) {
+                          int pooled_slabs = 0, cbam_hook_fn before_last = nullptr, void* hook_ctx = nullptr) {
   const CbamBlob& o = c.L.cbam[id];
   { static const char* const nm[4] = {"bott", "cbam1", "cbam2", "cbam3"}; if (id >= 0 && id < 4 && ablated(nm[id])) return MDIE_OK; }
   const int from = c.notes ? c.notes->mark() : 0;
@@ -576,7 +576,7 @@ static int run_cbam_stage(const Ctx& c, const Plan& P, int id, int H, int W, con
   d.workspace = c.ws + P.cbam_ws; d.workspace_bytes = P.cbam_ws_bytes;
   if (pooled_slabs > 0) { d.pool_partial = reinterpret_cast<const float*>(c.ws + P.pool_ws); d.pool_slabs = pooled_slabs; }
   d.blob_delta = c.delta;
-  const int rc = mdie_cbam_fwd(&d, c.stream);
+  const int rc = before_last ? cbam_fwd_hooked(&d, c.stream, before_last, hook_ctx) : mdie_cbam_fwd(&d, c.stream);
   if (c.notes) {
     static const char* const names[4] = {"bott", "cbam1", "cbam2", "cbam3"}, * const muls[4] = {"", "d3", "d2", "d1"};
     c.notes->cbam(from, names[id], d.C, (double)H * W, mul != nullptr, muls[id]);
@@ -771,32 +771,49 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
 #ifdef EXP_SCHED
   FORK_AT(3);
 #else
+  // dense2 starts here; dense1 -- the largest block and the one needed last (cbam3) -- here too, or behind dec.conv1 (MDIE_FWD_LATE_DENSE1: 1-4 us
+  // less for the step with the two-run form of conv4 on every box where it was swept; the host times it with the other forms)
+  const bool late_dense1 = (d->flags & MDIE_FWD_LATE_DENSE1) != 0;
   RUN(side_dense(1, h2, w2));
-  RUN(side_dense(0, h1, w1));
+  if (!late_dense1) RUN(side_dense(0, h1, w1));
 #endif
   // bottleneck, models/cdan.py:173
   RUN(run_cbam_stage(c, P, CB_BOTT, h3, w3, P.e, nullptr, P.bott, fuse_e ? slabs_e : 0));
   FORK_AT(4);
   // Decoder.forward, models/cdan.py:126-159
   RUN(run_conv(c, fuse_d ? "dec.conv1+skip2+pool-stats" : "dec.conv1+skip2", CV_D1, h3, w3, {P.bott}, P.t1, MDIE_ACT_RELU, 0, &P.o[2], nullptr, fuse_d ? pool_buf : nullptr));   // convT+BN+ReLU, + skip2
+#ifdef EXP_SCHED
   FORK_AT(5);
-  RUN(join_dense(2));
-  RUN(run_cbam_stage(c, P, CB_1, h3, w3, P.t1, &P.d[2], P.u1, fuse_d ? slabs_d : 0));  // cbam1, *= dense3
+#else
+  if (late_dense1) RUN(side_dense(0, h1, w1));
+#endif
+  // (a DenseBlock branch COULD be joined in front of the last pass of the CBAM that multiplies with it -- the gate and channel-pool passes do
+  //  not read it -- through cbam_fwd_hooked: built in round 5, -0.5 % ... 0 on a fast box; kept as an exploration switch)
+  struct JoinCtx { Branches* br; int k; } jc[3] = {{&br, 0}, {&br, 1}, {&br, 2}};
+  cbam_hook_fn join_hook = nullptr;
+#ifdef EXP_SCHED   // schedule-exploration builds only: MDIE_EXP_LATE_JOIN=1 (measured on a fast box: -0.5 % ... 0, the CBAM's first passes then run against the branch)
+  if (getenv("MDIE_EXP_LATE_JOIN")) join_hook = [](void* p) -> int { JoinCtx* j = static_cast<JoinCtx*>(p); return j->br->join(j->k); };
+#endif
+  if (!join_hook) RUN(join_dense(2));
+  RUN(run_cbam_stage(c, P, CB_1, h3, w3, P.t1, &P.d[2], P.u1, fuse_d ? slabs_d : 0, join_hook, &jc[2]));  // cbam1, *= dense3
+  RUN(join_dense(2));      // (no-op when joined already)
   FORK_AT(6);
   RUN(run_conv(c, "dec.conv2", CV_D2, h3, w3, {P.u1}, P.t2lo, MDIE_ACT_RELU, 0, nullptr));
   FORK_AT(7);
   RUN(run_up(c, P, "up2+skip1+pool", h3, w3, P.t2lo, P.o[1], P.t2));                    // bilinear x2 + skip1
   FORK_AT(8);
+  if (!join_hook) RUN(join_dense(1));
+  RUN(run_cbam_stage(c, P, CB_2, h2, w2, P.t2, &P.d[1], P.u2, mdie_pool_slabs(h2, w2), join_hook, &jc[1]));
   RUN(join_dense(1));
-  RUN(run_cbam_stage(c, P, CB_2, h2, w2, P.t2, &P.d[1], P.u2, mdie_pool_slabs(h2, w2)));
   FORK_AT(9);
   RUN(run_conv(c, "dec.conv3", CV_D3, h2, w2, {P.u2}, P.t3lo, MDIE_ACT_RELU, 0, nullptr));
   FORK_AT(10);
   RUN(run_up(c, P, "up3+skip0+pool", h2, w2, P.t3lo, P.o[0], P.t3));
+  if (!join_hook) RUN(join_dense(0));
+  RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3, mdie_pool_slabs(h1, w1), join_hook, &jc[0]));
   RUN(join_dense(0));
   // (cbam3's last pass as decoder.conv4's staging prologue -- mdie_cbam_conv_fwd, rounds 4 -- measured 68-69 us against 41 + 27 for the two
   //  launches and was removed in round 5; profiles/LEDGER.md has the stamps and what a form that could win would look like)
-  RUN(run_cbam_stage(c, P, CB_3, h1, w1, P.t3, &P.d[0], P.u3, mdie_pool_slabs(h1, w1)));
   RUN(run_conv(c, "dec.conv4", CV_D4, h1, w1, {P.u3}, P.t4lo, MDIE_ACT_RELU, 0, nullptr));
   bool half_base = false;
   {

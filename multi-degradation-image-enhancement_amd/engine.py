@@ -65,10 +65,12 @@ def pack_checkpoint(state_dict, dtype):
 #   0  conv_wide, one persistent workgroup per CU: fastest alone, but it holds every CU (and all of its LDS) until the layer ends, and the
 #      DenseBlock branches that run beside the layer queue behind it;
 #   2  conv_wide in two shorter runs per CU: every CU goes back to the dispatcher half way (MDIE_FWD_YIELD_CU_CONV4);
-#   1  conv_kernel: three ~50 KB workgroups per CU, 9 us slower alone (MDIE_FWD_SHARE_CU_CONV4).
+#   1  conv_kernel: three ~50 KB workgroups per CU, 9 us slower alone (MDIE_FWD_SHARE_CU_CONV4);
+#   3  form 2 with the dense1 branch started behind decoder.conv1 instead of behind encoder.conv4 (MDIE_FWD_LATE_DENSE1: 1-4 us on every
+#      box where it was swept beside form 2).
 # Which makes the STEP fastest depends on the box -- round 5, tools/sched_sweep.py, profiles/r05m_sched_sweep.txt, r05u_*: form 2 -29 ... -34 us
 # of 1045 on two boxes, form 1 -30 us of 1052 on a third and +10 of 1007 on the fastest one.  So the choice is TIMED, once per (device,
-# element type, batch shape) and process: CdanEngine.tune.  MDIE_SHARE_CU_CONV4 = auto (default) | 0 | 1 | 2 fixes it.
+# element type, batch shape) and process: CdanEngine.tune.  MDIE_SHARE_CU_CONV4 = auto (default) | 0 | 1 | 2 | 3 fixes it.
 _SHARE_CU = {}
 
 
@@ -99,11 +101,11 @@ class CdanEngine:
             L.check(L.lib.mdie_aux_create(C.byref(self._aux)), "mdie_aux_create")
 
     def tune(self, x, rounds=4, steps=40):
-        """Decide, for x's batch shape, which of the three bit-identical forms encoder.conv4 runs in (above): `rounds` alternating rounds of
+        """Decide, for x's batch shape, which of the bit-identical forms encoder.conv4 and the dense1 branch run in (above): `rounds` alternating rounds of
         `steps` eager forwards per form, the first round discarded (about half a second at B = 32, 256x256, once per shape and
         process; synchronises the device).  The runs must be LONG: what separates the forms is how the chip behaves under sustained
         load -- rounds of 8 forwards picked the wrong one on a box where 50-step runs differ by 1.6 % the other way
-        (gpurun_out/r05o).  Returns the form (0, 1 or 2); nothing is timed under stream capture (form 2 is used and NOT remembered)."""
+        (gpurun_out/r05o).  Returns the form (0 ... 3); nothing is timed under stream capture (form 2 is used and NOT remembered)."""
         B, _, H, W = x.shape
         key = (self.device.index, self.dtype, B, H, W, self.use_side_streams)
         if self.share_cu is not None:
@@ -114,9 +116,9 @@ class CdanEngine:
             _SHARE_CU[key] = 0
             return 0
         if torch.cuda.is_current_stream_capturing():
-            return 2          # (untimed: the form that was never slower than form 0 by more than its 2 us alone, and up to 3 % faster)
+            return 2          # (untimed: the form that was never slower than form 0 by more than its 2 us alone, and up to 4.5 % faster)
         y = torch.empty_like(x, dtype=torch.float32)
-        forms = (0, 2, 1)
+        forms = (0, 2, 3, 1)
         times = {f: [] for f in forms}
         with torch.no_grad():
             for f in forms:
@@ -138,6 +140,7 @@ class CdanEngine:
         _SHARE_CU[key] = best
         self.tuned = {"shape": (B, H, W), "form": best, "us_per_step": {"0 conv_wide, one run per CU": round(med[0] / steps * 1e6, 1),
                                                                          "2 conv_wide, two runs per CU": round(med[2] / steps * 1e6, 1),
+                                                                         "3 as 2, dense1 behind dec.conv1": round(med[3] / steps * 1e6, 1),
                                                                          "1 conv_kernel": round(med[1] / steps * 1e6, 1)}}
         return best
 
@@ -167,7 +170,8 @@ class CdanEngine:
 
     def _flags(self, general_tail=False, share_cu=0):
         return ((0 if self.use_side_streams else L.FWD_SERIAL) | (L.FWD_GENERAL_TAIL if general_tail else 0)
-                | (L.FWD_SHARE_CU_CONV4 if share_cu == 1 else L.FWD_YIELD_CU_CONV4 if share_cu == 2 else 0))
+                | (L.FWD_SHARE_CU_CONV4 if share_cu == 1 else L.FWD_YIELD_CU_CONV4 if share_cu == 2 else
+                   (L.FWD_YIELD_CU_CONV4 | L.FWD_LATE_DENSE1) if share_cu == 3 else 0))
 
     def forward(self, x, out=None, want_taps=False, profile=False, general_tail=False):
         """x: float32 NCHW [B,3,H,W] on this engine's GPU -> float32 NCHW [B,3,H,W]."""

@@ -25,7 +25,7 @@ ys = [torch.empty_like(x) for _ in configs]
 
 
 def setenv(c):
-    for var, v in (("MDIE_EXP_NOWIDE", c[0]), ("MDIE_EXP_FORK", c[1]), ("MDIE_EXP_WIDE_WGS", c[2] if len(c) > 2 else "-"), ("MDIE_EXP_STREAM_WGS", c[3] if len(c) > 3 else "-")):
+    for var, v in (("MDIE_EXP_NOWIDE", c[0]), ("MDIE_EXP_FORK", c[1]), ("MDIE_EXP_WIDE_WGS", c[2] if len(c) > 2 else "-"), ("MDIE_EXP_STREAM_WGS", c[3] if len(c) > 3 else "-"), ("MDIE_EXP_LATE_JOIN", c[4] if len(c) > 4 else "-")):
         if v == "-":
             os.environ.pop(var, None)
         else:
@@ -54,4 +54,4 @@ print(f"# {prec} B=32 256x256 eager, {rounds} interleaved rounds of {steps} step
 print(f"# {'conv_kernel instead of conv_wide':44s} {'fork d1,d2,d3':14s} {'step us':>8s} {'vs default':>10s}  same bits   rounds")
 for c, t, y in zip(configs, res, ys):
     m = sorted(t)[len(t) // 2]
-    print(f"  {(c[0] + (' wgs ' + c[2] if len(c) > 2 else '') + (' stream x' + c[3] if len(c) > 3 else '')):44s} {c[1]:14s} {m:8.1f} {m - base:+10.1f}  {str(bool(torch.equal(y, ys[0]))):9s}   " + " ".join(f"{v:.1f}" for v in t))
+    print(f"  {(c[0] + (' wgs ' + c[2] if len(c) > 2 else '') + (' stream x' + c[3] if len(c) > 3 and c[3] != '-' else '') + (' late-join' if len(c) > 4 and c[4] != '-' else '')):44s} {c[1]:14s} {m:8.1f} {m - base:+10.1f}  {str(bool(torch.equal(y, ys[0]))):9s}   " + " ".join(f"{v:.1f}" for v in t))
