@@ -676,6 +676,10 @@ static int ct_backward(const mdie_cbam_train_desc* d, CbtArgs& a, hipStream_t s)
   if (NV > 2) { set_error("mdie_cbam_train_bwd: C = %d too wide", d->C); return MDIE_EINVAL; }
   const int gx = ct_gx(d->H, d->W, groups);
   a.gx = gx;
+  // ONE number is the grid of cbt_bwd1 / cbt_bwd3 (the partials they write: partC[img][gridDim.x][C], part2[gx * B]) and the count
+  // cbt_gate_bwd / cbt_bnbwd fold (a.gx, gx * B): the fold can read neither fewer partials than were written nor one that was not
+  // (round-3 finding 6 asked for exactly this to be stated where it is enforced)
+  MDIE_REQUIRE(gx >= 1 && gx <= CT_MAX_GX && a.gx == gx, "mdie_cbam_train_bwd: %d partial blocks per image (1..%d)", gx, CT_MAX_GX);
   const int tiles = cdiv(d->W, CT_TS) * cdiv(d->H, CT_TS);
   if (NV == 1) hipLaunchKernelGGL((cbt_bwd1_kernel<T, 1>), dim3(gx, d->B), dim3(CT_THREADS), 0, s, a, LPP);
   else hipLaunchKernelGGL((cbt_bwd1_kernel<T, 2>), dim3(gx, d->B), dim3(CT_THREADS), 0, s, a, LPP);

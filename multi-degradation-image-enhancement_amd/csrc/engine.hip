@@ -912,6 +912,13 @@ extern "C" int mdie_aux_create(void** out) {
   Aux* a = new Aux();
   hipError_t err = hipSuccess;
   for (int i = 0; i < 3 && err == hipSuccess; ++i) {
+#ifdef EXP_SCHED   // schedule-exploration builds only: MDIE_EXP_SIDE_PRIO = low | high -- the side streams' priority against the caller's stream
+    if (const char* v = getenv("MDIE_EXP_SIDE_PRIO")) {
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      err = hipStreamCreateWithPriority(&a->side[i], hipStreamNonBlocking, v[0] == 'l' ? least : greatest);
+    } else
+#endif
     err = hipStreamCreateWithFlags(&a->side[i], hipStreamNonBlocking);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&a->fork[i], hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&a->join[i], hipEventDisableTiming);
