@@ -920,8 +920,13 @@ extern "C" int mdie_aux_create(void** out) {
     } else
 #endif
     err = hipStreamCreateWithFlags(&a->side[i], hipStreamNonBlocking);
-    if (err == hipSuccess) err = hipEventCreateWithFlags(&a->fork[i], hipEventDisableTiming);
-    if (err == hipSuccess) err = hipEventCreateWithFlags(&a->join[i], hipEventDisableTiming);
+    // Fork / join events with a DEVICE-scope release (hipEventReleaseToDevice): they order the caller's stream and the library's side
+    // streams on ONE GPU, and the default -- a system-scope release, i.e. a write-back towards the host at every record -- sits on the
+    // critical path three times per forward at each end of a branch.  Same-box A/B (tools/sched_sweep.py, profiles/r05ak_event_scope.txt):
+    // -5 ... -11 us per step in every schedule, outputs bit-identical.  (Nothing outside the device ever waits on these events.)
+    const unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&a->fork[i], evf);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&a->join[i], evf);
   }
   if (err != hipSuccess) { set_error("mdie_aux_create: HIP stream/event creation failed: %s", hipGetErrorString(err)); delete a; return MDIE_ELAUNCH; }
   *out = a;
