@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""The forward launched on torch's default (null) stream against a created stream: interleaved rounds of eager steps in one process."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from models.cdan import CDAN
+from mdie_amd import synthetic as P
+
+net = CDAN(precision="bf16")
+net.load_state_dict(P.make_state_dict(42), strict=True)
+net = net.eval().cuda()
+x, _ = P.lowlight_batch(1000, 32, 256, 256)
+x = x.cuda()
+y = torch.empty_like(x)
+dev = x.device
+eng0 = net._engine(dev)
+st = torch.cuda.Stream(dev)
+with torch.cuda.stream(st):
+    eng1 = net._engine(dev)          # (modules.CDAN keeps one engine per stream)
+eng0.tune(x)
+
+
+def run(eng, stream, n):
+    with torch.cuda.stream(stream):
+        for _ in range(5):
+            eng.forward(x, out=y)
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(n):
+            eng.forward(x, out=y)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t) / n * 1e6
+
+
+with torch.no_grad():
+    res = {"default stream": [], "created stream": []}
+    for _ in range(4):
+        res["default stream"].append(run(eng0, torch.cuda.default_stream(dev), 100))
+        res["created stream"].append(run(eng1, st, 100))
+for k, v in res.items():
+    print(f"{k}: " + " ".join(f"{t:.1f}" for t in v) + " us per step")
