@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MDIE_ABI_VERSION 26
+#define MDIE_ABI_VERSION 27
 
 enum { MDIE_F32 = 0, MDIE_BF16 = 1,
        MDIE_F16 = 2 /* IEEE half: the reference's mixed-precision dtype (torch.cuda.amp.autocast, models/model.py:15,159) */ };
@@ -362,6 +362,31 @@ typedef struct {
 } mdie_up_dense0_desc;
 int mdie_up_add_dense0_fwd(const mdie_up_dense0_desc* d, void* stream);
 
+/* decoder.final_dense as ONE launch (models/cdan.py:22-53,119,153-157; csrc/final_block.hip, ABI 27):
+ *     base = bilinear_x2(lo)[:, :3] + x ;  four DenseBlock layers (BN -> ReLU -> Conv3x3, 16 channels each) ;
+ *     y = sigmoid(Conv1x1(relu(bn_t(cat(base, g0..g3)))))
+ * A workgroup computes a 16 x 8 tile of y from the 24 x 16 base patch around it; the growth maps stay in LDS (the halo rings are
+ * recomputed by the neighbouring tiles), nothing but `lo`, `x` and `y` touches HBM.  16-bit element types, H a multiple of 8, W of 16.
+ * Parameters are exactly the chain's (mdie_up_add_dense0_fwd + three mdie_conv_fwd with mdie_tr_fuse): layer 0's weight in
+ * mdie_pack_conv_first_weight's layout, layers 1..3 as mdie_pack_conv_weight packs them (ksize 3, cout_stored 16, cin_stored
+ * 8 + 16 l, split 3, gap 5: the base is one 8-channel group), the transition likewise (ksize 1, cin_stored 72); pre_scale / pre_shift
+ * by STORED input channel.  Arithmetic is the chain's operation for operation: `y` is bit-identical to it. */
+typedef struct {
+  int dtype;
+  int B, H, W;                   /* output extent; lo is [B, H/2, W/2, >= 4 channels] */
+  const void* lo; int lo_stride; /* decoder.conv4's output (NHWC), elements between pixels */
+  const float* x;                /* fp32 NCHW [B,3,H,W] */
+  const void* w0;                /* layer 0 */
+  const void* w[3];              /* layers 1..3 */
+  const float* pre_scale[4]; const float* pre_shift[4];     /* folded pre-activation BatchNorm of layers 0..3 */
+  const float* post_scale[4]; const float* post_shift[4];   /* [16] each: (1, bias); layer 0 uses post_shift only */
+  const void* wt;                /* the transition's 1x1 weights */
+  const float* tr_pre_scale; const float* tr_pre_shift;     /* [72] */
+  const float* tr_post_scale; const float* tr_post_shift;   /* [>= 3]: (1, bias) */
+  float* y;                      /* fp32 NCHW [B,3,H,W] */
+} mdie_final_dense_desc;
+int mdie_final_dense_fwd(const mdie_final_dense_desc* d, void* stream);
+
 /* Concurrency of the three encoder DenseBlocks.  dense_k depends only on the pooled block output
  * o_k and is first consumed by the decoder (`out *= denses[k]`, models/cdan.py:133,141,149), so the
  * plan runs it beside the main chain from right after conv_k until the matching decoder CBAM:
@@ -419,7 +444,9 @@ enum { /* 1: was MDIE_FWD_FUSED_TAIL (the whole decoder tail as one launch, roun
                                        bit-identical either way; which is faster depends on the box (CdanEngine.tune times the forms) */,
        MDIE_FWD_YIELD_CU_CONV4 = 32 /* encoder.conv4 with mdie_conv_desc.share_cu = 2 (wins over 16 when both are set) */,
        MDIE_FWD_LATE_DENSE1 = 64    /* the dense1 branch (needed last, by cbam3) starts behind decoder.conv1 instead of behind encoder.conv4: a schedule,
-                                       not arithmetic -- bit-identical; another candidate of CdanEngine.tune */
+                                       not arithmetic -- bit-identical; another candidate of CdanEngine.tune */,
+       MDIE_FWD_CHAIN_TAIL = 128    /* decoder.final_dense as the chain of four launches with the transition folded in (rounds 3-5) where the
+                                       one-launch block (mdie_final_dense_fwd, ABI 27) would run: bit-identical, for A/B runs and tests */
        /* 8: was MDIE_FWD_FUSED_CBAM3 (cbam3's last pass fused into decoder.conv4, round 4): 68 us against 41 + 27, removed in round 5 */ };
 
 enum { MDIE_K_LAYOUT = 0, MDIE_K_CONV3 = 1, MDIE_K_CONV1 = 2, MDIE_K_CBAM_POOL = 3, MDIE_K_CBAM_GATE = 4,

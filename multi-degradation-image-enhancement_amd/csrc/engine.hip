@@ -832,6 +832,40 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
 #ifndef EXP_FULL_BASE   // (A/B builds only: the base as a whole 16-byte group)
     if (fold_tr && t4.C == 8) { t4.st = 4; half_base = true; }
 #endif
+    // ONE launch for the whole block (csrc/final_block.hip, ABI 27) wherever the folded chain would run with one weight set and nobody
+    // asks for the base tensor (taps): growth maps in LDS, halo rings recomputed, y bit-identical to the chain's
+    const bool one_launch = fold_tr && !(d->flags & MDIE_FWD_CHAIN_TAIL) && !d->taps && !c.delta;
+    if (one_launch) {
+      mdie_final_dense_desc f{};
+      f.dtype = d->dtype; f.B = B; f.H = H; f.W = W;
+      f.lo = c.ws + P.t4lo.off; f.lo_stride = P.t4lo.C; f.x = d->x;
+      f.w0 = c.params + c.L.fl0_w;
+      for (int l = 0; l < 4; ++l) {
+        if (l) f.w[l - 1] = c.params + c.L.conv[id0 + l].w;
+        f.pre_scale[l] = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + l].pre_scale);
+        f.pre_shift[l] = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + l].pre_shift);
+        f.post_scale[l] = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + l].post_scale);
+        f.post_shift[l] = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + l].post_shift);
+      }
+      f.wt = c.params + c.L.conv[id0 + 4].w;
+      f.tr_pre_scale = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + 4].pre_scale);
+      f.tr_pre_shift = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + 4].pre_shift);
+      f.tr_post_scale = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + 4].post_scale);
+      f.tr_post_shift = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + 4].post_shift);
+      f.y = d->y;
+      const int from = notes.mark();
+      if (!ablated("final.block")) RUN(mdie_final_dense_fwd(&f, stream));
+      if (notes.on()) {   // booked at the block's SURVEY 8d share: what the four launches of the chain are booked at, summed
+        double el = 9.0 * 3 * PX / 4 + 3 * PX + 16 * PX + (3 + 16) * PX, par = 3.0 * 16 * 9 + 16 + 2 * 3, fl = 2.0 * 3 * 16 * 9 * PX + 2.0 * (3 + 16) * 3 * PX;
+        for (int l = 1; l <= 3; ++l) {
+          const double cin = 3 + 16.0 * l;
+          el += cin * PX + 16 * PX + 16 * PX + (l == 3 ? 3 * PX : 0);
+          par += cin * 16 * 9 + 16 + 2 * cin + (l == 3 ? 67.0 * 3 + 3 + 2 * 67 : 0);
+          fl += 2.0 * cin * 16 * 9 * PX + 2.0 * 16 * 3 * PX;
+        }
+        notes.note(from, "up4+x+final_dense+sigmoid->nchw", el, par, fl);
+      }
+    } else {
     mdie_tr_fuse tr{};
     tr.weight = c.params + c.L.conv[id0 + 4].w;
     tr.pre_scale = reinterpret_cast<const float*>(c.params + c.L.conv[id0 + 4].pre_scale);
@@ -890,6 +924,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
       }
     } else {
       RUN(run_dense(c, 3, H, W, P.t4, P.fg, P.out16, MDIE_ACT_SIGMOID, d->y, true));
+    }
     }
   }
 #undef RUN

@@ -1,0 +1,651 @@
+// decoder.final_dense as ONE launch (models/cdan.py:22-53,119,153-157):
+//     base = bilinear_x2(t4)[:, :3] + x
+//     g_l  = conv3x3(relu(bn_l(cat(base, g_0 .. g_{l-1}))))            l = 0..3   (DenseBlock layers, 16 channels each)
+//     y    = sigmoid(conv1x1(relu(bn_t(cat(base, g_0 .. g_3)))))      (transition 67 -> 3)
+// Nothing of the block ever reaches HBM: a workgroup computes one 16 x 8 output tile from the 24 x 16 base patch around it; the
+// growth maps live in LDS, the halo rings of g0 / g1 / g2 (22x14, 20x12, 18x10) are recomputed by the neighbouring tiles.
+//
+// Why.  As a chain of four launches (updense0.hip, 3 x conv_thin.hip with the transition folded in) the block is 235 us of a
+// 1 007 us step at B = 32, 256x256, bf16 and 1.04 GB of its 3.36 GB: every byte of it is a growth map or a partial sum written
+// to HBM and read back (up to 3 x with an 18x18 halo) by the next launch.  Here the block reads t4 (8 bytes per low-resolution
+// pixel) and x and writes y: ~45 MB per step.
+//
+// LDS holds ACTIVATED operands, per consumer.  Layer l applies its OWN BatchNorm to every channel of its input
+// (models/cdan.py:41-46), so relu(bn_l(g_j)) differs per (l, j).  The producer of g_j has the map in registers (4 channels of one
+// pixel per lane = the MFMA accumulator layout): its epilogue rounds g_j to the storage type once (what the chain stores) and
+// writes relu(bn_l(g_j)) for EVERY later layer l into that layer's own input image A_l -- 6 vector instructions + one 8-byte LDS
+// write per consumer, no staging pass, no raw map.  Out-of-picture pixels are written as zeros (nn.Conv2d pads the ACTIVATED tensor).
+//     A_1: base, g0         on 22 x 14     A_2: base, g0, g1    on 20 x 12     A_3: base, g0, g1, g2  on 18 x 10
+// one 16-byte column (8 channels) per plane, planes 256-byte aligned (conflict-free ds_read_b128, see conv_thin.hip); A_3's two
+// g2 planes reuse A_1's g0 planes (dead by then): 49.9 KB of planes, 78.5 KB with the rest -- two workgroups per CU, so one
+// workgroup's epilogue / base phase (vector pipe, memory) runs under the other's matrix phase.
+//
+// The matrix work is conv_thin's: weights of layers 0..2 live in REGISTERS for the whole persistent run (layer 3's fragments are
+// read from LDS, 9 per K chunk, right before the chunk's MFMAs: 188 registers of weights would not leave two waves per SIMD a
+// working set), every per-channel constant and the transition's weight rows sit in a 4 KB LDS table; a wave
+// owns a band of output rows of the 16-wide centre strip, so the operand fragment of input row r and column shift kw feeds the
+// three output rows r, r-1, r-2; the halo columns left and right of the strip (2 x 3 / 2 / 1) are gathered into extra 16-pixel
+// groups with per-lane addresses.  Per 16 x 8 tile: 40 + 135 + 216 + 144 MFMAs + the transition's 32.
+//
+// Arithmetic is the chain's, operation for operation -- the base rounded to the storage type, every growth map rounded once,
+// every pre-activation one fused multiply-add rounded once, products accumulated in the same (chunk, tap) order on the same K
+// slots, the transition's terms summed in the same order (base + g0, + g1, + g2, + g3) -- so y is BIT-IDENTICAL to the chain's
+// (tests/test_gpu_parity.py::test_final_block_one_launch_equals_the_chain).
+#include <algorithm>
+
+#include "conv_common.hpp"
+
+#pragma clang fp contract(off)   // (the interpolation must round like updense0.hip / resample.hip)
+
+namespace mdie {
+
+constexpr int FB_THREADS = 256;
+constexpr int FB_TW = 16, FB_TH = 8;
+constexpr int FB_RBW = FB_TW + 8, FB_RBH = FB_TH + 8;   // the base patch: 24 x 16
+
+// input image of layer L = 1..3 (= the region layer L-1's output is needed on): halo K, one plane per 16-byte column
+template <int L> struct FbIn {
+  static constexpr int K = 4 - L, W = FB_TW + 2 * K, H = FB_TH + 2 * K, NCOL = 1 + 2 * L;
+  static constexpr int PLANE = (W * H * 16 + 255) / 256 * 256;
+};
+constexpr int FB_A1 = 0;
+constexpr int FB_A2 = FB_A1 + 3 * FbIn<1>::PLANE;
+constexpr int FB_A3 = FB_A2 + 5 * FbIn<2>::PLANE;
+constexpr int FB_A3_G2 = FB_A1 + FbIn<1>::PLANE;            // A_3's planes 5, 6 (g2) over A_1's planes 1, 2 (g0: last read by layer 1)
+constexpr int FB_PATCH = FB_A3 + 5 * FbIn<3>::PLANE;        // relu(bn_0(base)), [24 x 16 pixels][4]: layer 0's im2col source
+constexpr int FB_TRPATCH = FB_PATCH + FB_RBW * FB_RBH * 8;  // relu(bn_t(base)) of the tile's own pixels, [16 x 8][4]
+constexpr int FB_TRP = FB_TRPATCH + FB_TW * FB_TH * 8;      // the transition's fp32 partial sums, [16 x 8] float4
+constexpr int FB_W3 = FB_TRP + FB_TW * FB_TH * 16;          // layer 3's packed weights (2 chunks)
+constexpr int FB_WCHUNK = 4 * 9 * 16 * 16;
+// every per-channel constant of the block, copied once: the loop then needs no parameter pointer but lo, x and y (26 pointers in
+// SGPRs spilled 36 of them and, with them, the weights)
+constexpr int FB_CPS = FB_W3 + 2 * FB_WCHUNK;               // float [4 layers][72]: pre-activation scale by stored input channel
+constexpr int FB_CPB = FB_CPS + 4 * 72 * 4;                 //                       ... shift
+constexpr int FB_CTS = FB_CPB + 4 * 72 * 4;                 // float [72] + [72]: the transition's
+constexpr int FB_CTB = FB_CTS + 72 * 4;
+constexpr int FB_CES = FB_CTB + 72 * 4;                     // float [4][16] + [4][16]: the layers' epilogue scale / shift
+constexpr int FB_CEB = FB_CES + 4 * 16 * 4;
+constexpr int FB_CTE = FB_CEB + 4 * 16 * 4;                 // float [4] + [4]: the transition's epilogue
+constexpr int FB_TRW = FB_CTE + 32;                         // rows 0..3 of the transition's weights: [9 K groups (8 stored channels)][4 rows][16 B]
+constexpr int FB_LDS = FB_TRW + 9 * 64;
+static_assert(2 * FbIn<3>::PLANE <= 2 * FbIn<1>::PLANE, "g2's planes must fit A_1's g0 planes");
+static_assert(FB_LDS <= 80 * 1024, "two workgroups per CU");
+
+template <int L> __device__ __forceinline__ int fb_plane(int c) {   // byte offset of column c of A_L
+  if constexpr (L == 1) return FB_A1 + c * FbIn<1>::PLANE;
+  else if constexpr (L == 2) return FB_A2 + c * FbIn<2>::PLANE;
+  else return c < 5 ? FB_A3 + c * FbIn<3>::PLANE : FB_A3_G2 + (c - 5) * FbIn<3>::PLANE;
+}
+
+struct FbArgs {
+  int B, H, W, tiles_x, tiles_y;
+  const char* lo; unsigned lo_stride;      // decoder.conv4's output, NHWC at H/2 x W/2; bytes per pixel
+  const float* x;                          // fp32 NCHW
+  const char* w0;                          // layer 0, mdie_pack_conv_first_weight layout
+  const char* w[3];                        // layers 1..3, mdie_pack_conv_weight layout (16 stored outputs)
+  const float* ps[4]; const float* pb[4];  // folded pre-activation BatchNorm of layers 0..3, by stored input channel (base 0..2, g_j at 8 + 16 j)
+  const float* esc[4]; const float* esh[4];   // [16] each: the layers' epilogue (1, bias)
+  const char* wt;                          // the transition's packed 1x1 weights
+  const float* tps; const float* tpb;      // its folded BatchNorm by stored input channel
+  const float* tes; const float* teb;      // its epilogue (1, bias), >= 3 entries
+  float* y;                                // fp32 NCHW
+};
+
+__device__ __forceinline__ void fb_src(int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {   // = resample.hip src_index
+  float src = ((float)dst + 0.5f) * 0.5f - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+// relu(x * s + b) of 4 channels, rounded to the storage type: PreAct<T>::apply, two dwords at a time
+template <typename T> __device__ __forceinline__ uint2 fb_preact4(const f32x2& x0, const f32x2& x1, const float4& s, const float4& b) {
+  const f32x2 r0 = __builtin_elementwise_fma(x0, f32x2{s.x, s.y}, f32x2{b.x, b.y});
+  const f32x2 r1 = __builtin_elementwise_fma(x1, f32x2{s.z, s.w}, f32x2{b.z, b.w});
+  const i16x2 m0 = __builtin_elementwise_max(half_bits<T>(r0), i16x2{0, 0}), m1 = __builtin_elementwise_max(half_bits<T>(r1), i16x2{0, 0});
+  return make_uint2(__builtin_bit_cast(uint32_t, m0), __builtin_bit_cast(uint32_t, m1));
+}
+
+// the lane's 4 channels of g_J at pixel (ry, rx) of g_J's region -> column 1 + 2 J + lq / 2 of A_L, pre-activated with layer L's constants
+template <typename T, int J, int L, bool MAIN>
+__device__ __forceinline__ void fb_emit_one(char* smem, const f32x2& x0, const f32x2& x1, int ry, int rx, bool img_ok, bool lane_ok, int lq,
+                                            const float4& s, const float4& b) {
+  using R = FbIn<L>;
+  constexpr int D = L - 1 - J;                  // A_L's region starts D pixels inside g_J's
+  const int cy = ry - D, cx = rx - D;
+  bool in = cy >= 0 && cy < R::H;               // (MAIN: wave-uniform; the centre strip's columns lie inside every region)
+  if constexpr (!MAIN) in = in && lane_ok && cx >= 0 && cx < R::W;
+  if (in) {
+    uint2 v = fb_preact4<T>(x0, x1, s, b);
+    if (!img_ok) v = make_uint2(0u, 0u);        // zero padding of the ACTIVATED tensor
+    *reinterpret_cast<uint2*>(smem + fb_plane<L>(1 + 2 * J + (lq >> 1)) + (cy * R::W + cx) * 16 + (lq & 1) * 8) = v;
+  }
+}
+template <typename T, int J, bool MAIN>
+__device__ __forceinline__ void fb_emit(char* smem, uint32_t u0, uint32_t u1, int ry, int rx, bool img_ok, bool lane_ok, int lq,
+                                        const float4 (&cs)[3], const float4 (&cb)[3]) {
+  const f32x2 x0 = {Half<T>::lo(u0), Half<T>::hi(u0)}, x1 = {Half<T>::lo(u1), Half<T>::hi(u1)};
+  if constexpr (J < 1) fb_emit_one<T, J, 1, MAIN>(smem, x0, x1, ry, rx, img_ok, lane_ok, lq, cs[0], cb[0]);
+  if constexpr (J < 2) fb_emit_one<T, J, 2, MAIN>(smem, x0, x1, ry, rx, img_ok, lane_ok, lq, cs[1], cb[1]);
+  if constexpr (J < 3) fb_emit_one<T, J, 3, MAIN>(smem, x0, x1, ry, rx, img_ok, lane_ok, lq, cs[2], cb[2]);
+}
+
+// a band of NROWS output rows of layer L's centre strip (conv_thin's matrix phase): xb[k] = the lane's byte offset of input row
+// row0, column shift 0, K group lq of chunk k
+template <typename T, int L, int NCHUNK, int NROWS>
+__device__ __forceinline__ void fb_band(const char* smem, const int (&xb)[NCHUNK], const uint4 (&w)[NCHUNK][9], f32x4 (&acc)[NROWS]) {
+  constexpr int PW = FbIn<L>::W;
+#pragma unroll
+  for (int ps = 0; ps < NROWS; ++ps) acc[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NCHUNK; ++k) {
+    const char* const xk = smem + xb[k];
+    uint4 xf[2][3];
+    auto read_row = [&](int r, int b) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) xf[b][kw] = *reinterpret_cast<const uint4*>(xk + (r * PW + kw) * 16);
+    };
+    read_row(0, 0);
+#pragma unroll
+    for (int r = 0; r < NROWS + 2; ++r) {
+      if (r + 1 < NROWS + 2) read_row(r + 1, (r + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int kh = 2; kh >= 0; --kh) {
+          const int ps = r - kh;
+          if (ps >= 0 && ps < NROWS) acc[ps] = mma16<T>(w[k][kh * 3 + kw], xf[r & 1][kw], acc[ps]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// the same with the chunk's 9 weight fragments read from LDS (offset wl = the lane's fragment of chunk 0, tap 0) in front of its MFMAs
+template <typename T, int L, int NCHUNK, int NROWS>
+__device__ __forceinline__ void fb_band_wlds(const char* smem, const int (&xb)[NCHUNK], int wl, f32x4 (&acc)[NROWS]) {
+  constexpr int PW = FbIn<L>::W;
+#pragma unroll
+  for (int ps = 0; ps < NROWS; ++ps) acc[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NCHUNK; ++k) {
+    uint4 w[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) w[tap] = *reinterpret_cast<const uint4*>(smem + wl + k * FB_WCHUNK + tap * 256);
+    const char* const xk = smem + xb[k];
+    uint4 xf[2][3];
+    auto read_row = [&](int r, int b) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) xf[b][kw] = *reinterpret_cast<const uint4*>(xk + (r * PW + kw) * 16);
+    };
+    read_row(0, 0);
+#pragma unroll
+    for (int r = 0; r < NROWS + 2; ++r) {
+      if (r + 1 < NROWS + 2) read_row(r + 1, (r + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int kh = 2; kh >= 0; --kh) {
+          const int ps = r - kh;
+          if (ps >= 0 && ps < NROWS) acc[ps] = mma16<T>(w[kh * 3 + kw], xf[r & 1][kw], acc[ps]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// one 16-pixel group of halo columns: xg[k] = the lane's byte offset of ITS pixel's tap (0, 0), K group lq of chunk k
+template <typename T, int L, int NCHUNK>
+__device__ __forceinline__ f32x4 fb_group(const char* smem, const int (&xg)[NCHUNK], const uint4 (&w)[NCHUNK][9]) {
+  constexpr int PW = FbIn<L>::W;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const uint4 xv = *reinterpret_cast<const uint4*>(smem + xg[k] + ((tap / 3) * PW + tap % 3) * 16);
+      acc = mma16<T>(w[k][tap], xv, acc);
+    }
+  return acc;
+}
+
+// rows of the transition's weights for the 4 channels (stored input channel c0 + 4 lq ..) of a segment: A operand rows 0..2
+// (lane lp < 4 holds row lp; row 3 of the packed weights is zero), zeros elsewhere
+__device__ __forceinline__ uint2 fb_tr_rows(const char* smem, int c0, int lq, int lp) {
+  const int c = c0 + 4 * lq;
+  const uint2 w = *reinterpret_cast<const uint2*>(smem + FB_TRW + (c >> 3) * 64 + (lp & 3) * 16 + (c & 7) * 2);
+  return lp < 4 ? w : make_uint2(0u, 0u);
+}
+__device__ __forceinline__ float4 fb_c4(const char* smem, int table, int index) { return *reinterpret_cast<const float4*>(smem + table + index * 4); }
+__device__ __forceinline__ float4 fb_c3(const char* smem, int table, int index) {   // 3 channels of the base: the group's 4th (a pad channel) counts as 0
+  float4 v = *reinterpret_cast<const float4*>(smem + table + index * 4);
+  v.w = 0.f;
+  return v;
+}
+
+// Lane / wave indices laundered through an empty asm at the top of every phase: everything a phase derives from them (plane offsets,
+// halo-group pixels, gather offsets) is tile-invariant, and hoisted out of the tile loop it stayed live across ALL phases -- next to
+// 116 registers of weights that meant scratch spills.  Recomputing a few integer instructions per phase is cheaper.
+#define FB_FRESH_IDS()                                                                       \
+  int lqf_ = lq_, lpf_ = lp_, tidf_ = tid_, wavef_ = wave_;                                  \
+  asm volatile("" : "+v"(lqf_), "+v"(lpf_), "+v"(tidf_));                                    \
+  asm volatile("" : "+s"(wavef_));                                                           \
+  const int lq = lqf_, lp = lpf_, tid = tidf_, wave = wavef_;                                \
+  (void)lq; (void)lp; (void)tid; (void)wave
+
+template <typename T>
+__global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs a, const int n_items) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid_ = threadIdx.x, lane_ = tid_ & 63, lq_ = lane_ >> 4, lp_ = lane_ & 15;
+  const int wave_ = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+
+  // ---- this workgroup's run of tiles: contiguous, inside its XCD's share (conv_thin.hip) ----
+  const int per_xcd = (n_items + 7) >> 3, nwg = gridDim.x >> 3;
+  const int band0 = ((int)blockIdx.x & 7) * per_xcd, band1 = min(band0 + per_xcd, n_items);
+  const int run = (per_xcd + nwg - 1) / nwg;
+  int item = band0 + ((int)blockIdx.x >> 3) * run;
+  const int run_end = min(item + run, band1);
+  if (item >= run_end) return;
+
+  uint4 wf0[2], w1r[1][9], w2r[2][9];
+  {
+    FB_FRESH_IDS();
+    const int wlane = (lq * 9 * 16 + lp) * 16;
+    // ---- once: the base planes (their upper 8 bytes per pixel -- channels 4..7 of the base group -- stay zero for the whole run),
+    //      layer 3's weights -> LDS, layers 0..2 -> registers (A row lp = output channel, K group lq) ----
+    for (int i = tid; i < FbIn<1>::PLANE / 16; i += FB_THREADS) *reinterpret_cast<uint4*>(smem + fb_plane<1>(0) + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < FbIn<2>::PLANE / 16; i += FB_THREADS) *reinterpret_cast<uint4*>(smem + fb_plane<2>(0) + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < FbIn<3>::PLANE / 16; i += FB_THREADS) *reinterpret_cast<uint4*>(smem + fb_plane<3>(0) + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < 2 * FB_WCHUNK / 16; i += FB_THREADS) *reinterpret_cast<uint4*>(smem + FB_W3 + i * 16) = *reinterpret_cast<const uint4*>(a.w[2] + i * 16);
+    if (tid < 72) {
+      float* const cps = reinterpret_cast<float*>(smem + FB_CPS), * const cpb = reinterpret_cast<float*>(smem + FB_CPB);
+      cps[tid] = tid < 8 ? a.ps[0][tid] : 0.f; cpb[tid] = tid < 8 ? a.pb[0][tid] : 0.f;
+      cps[72 + tid] = tid < 24 ? a.ps[1][tid] : 0.f; cpb[72 + tid] = tid < 24 ? a.pb[1][tid] : 0.f;
+      cps[144 + tid] = tid < 40 ? a.ps[2][tid] : 0.f; cpb[144 + tid] = tid < 40 ? a.pb[2][tid] : 0.f;
+      cps[216 + tid] = tid < 56 ? a.ps[3][tid] : 0.f; cpb[216 + tid] = tid < 56 ? a.pb[3][tid] : 0.f;
+      reinterpret_cast<float*>(smem + FB_CTS)[tid] = a.tps[tid]; reinterpret_cast<float*>(smem + FB_CTB)[tid] = a.tpb[tid];
+    } else if (tid < 72 + 16) {
+      const int c = tid - 72;
+      float* const ces = reinterpret_cast<float*>(smem + FB_CES), * const ceb = reinterpret_cast<float*>(smem + FB_CEB);
+      ces[c] = a.esc[0][c]; ces[16 + c] = a.esc[1][c]; ces[32 + c] = a.esc[2][c]; ces[48 + c] = a.esc[3][c];
+      ceb[c] = a.esh[0][c]; ceb[16 + c] = a.esh[1][c]; ceb[32 + c] = a.esh[2][c]; ceb[48 + c] = a.esh[3][c];
+    } else if (tid < 72 + 16 + 4) {
+      const int c = tid - 88;
+      reinterpret_cast<float*>(smem + FB_CTE)[c] = c < 3 ? a.tes[c] : 0.f; reinterpret_cast<float*>(smem + FB_CTE)[4 + c] = c < 3 ? a.teb[c] : 0.f;
+    } else if (tid >= 96 && tid < 96 + 9 * 16) {   // rows 0..3 of every K group of the transition's weights (K group g = stored channels 8 g .. 8 g + 7 at byte 256 g)
+      const int i = tid - 96, g = i >> 4, rw = (i >> 2) & 3, dwi = i & 3;
+      *reinterpret_cast<uint32_t*>(smem + FB_TRW + g * 64 + rw * 16 + dwi * 4) = *reinterpret_cast<const uint32_t*>(a.wt + g * 256 + rw * 16 + dwi * 4);
+    }
+  #pragma unroll
+    for (int s = 0; s < 2; ++s) wf0[s] = *reinterpret_cast<const uint4*>(a.w0 + ((size_t)s * 16 + lp) * 64 + lq * 16);
+  #pragma unroll
+    for (int tap = 0; tap < 9; ++tap) w1r[0][tap] = *reinterpret_cast<const uint4*>(a.w[0] + wlane + tap * 256);
+  #pragma unroll
+    for (int k = 0; k < 2; ++k)
+  #pragma unroll
+      for (int tap = 0; tap < 9; ++tap) w2r[k][tap] = *reinterpret_cast<const uint4*>(a.w[1] + (size_t)k * FB_WCHUNK + wlane + tap * 256);
+
+  }
+  const int Hl = a.H >> 1, Wl = a.W >> 1;
+  const size_t hw = (size_t)a.H * a.W;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int tx, ty, img;
+  { int r = item; tx = r % a.tiles_x; r /= a.tiles_x; ty = r % a.tiles_y; img = r / a.tiles_y; }
+  __syncthreads();
+
+  for (; item < run_end; ++item) {
+    const int y0 = ty * FB_TH, x0 = tx * FB_TW;
+
+    // =========================== P0: the base patch, 24 x 16 ===========================
+    float fbase[2][3];
+    bool inimg[2];
+    {
+      FB_FRESH_IDS();
+      float t[2][4][3], xin[2][3], hy[2][2], wx[2][2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int p = tid + it * FB_THREADS;
+        const int py = p / FB_RBW, px = p - py * FB_RBW;
+        const int gy = y0 - 4 + py, gx = x0 - 4 + px;
+        inimg[it] = p < FB_RBW * FB_RBH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) t[it][k][c] = 0.f;
+        xin[it][0] = xin[it][1] = xin[it][2] = 0.f;
+        hy[it][0] = hy[it][1] = wx[it][0] = wx[it][1] = 0.f;
+        if (inimg[it]) {
+          int ya, yb, xa, xb;
+          fb_src(gy, Hl, ya, yb, hy[it][0], hy[it][1]);
+          fb_src(gx, Wl, xa, xb, wx[it][0], wx[it][1]);
+          const char* lb = a.lo + (size_t)img * Hl * Wl * a.lo_stride;             // wave-uniform
+          const unsigned ls = a.lo_stride, ra = __umul24(ya, Wl), rb = __umul24(yb, Wl);
+          const char* q[4] = {lb + __umul24(ra + xa, ls), lb + __umul24(ra + xb, ls), lb + __umul24(rb + xa, ls), lb + __umul24(rb + xb, ls)};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint2 u = *reinterpret_cast<const uint2*>(q[k]);
+            t[it][k][0] = Half<T>::lo(u.x); t[it][k][1] = Half<T>::hi(u.x); t[it][k][2] = Half<T>::lo(u.y);
+          }
+          const float* xbase = a.x + (size_t)img * 3 * hw;                          // wave-uniform
+          const unsigned xo = (__umul24(gy, a.W) + gx) * 4u;
+          xin[it][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xbase) + xo);
+          xin[it][1] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xbase + hw) + xo);
+          xin[it][2] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xbase + 2 * hw) + xo);
+        }
+      }
+      // (the base channels' constants in four of its five consumers: broadcast LDS reads)
+      const float4 c0s = fb_c3(smem, FB_CPS, 0), c0b = fb_c3(smem, FB_CPB, 0), c1s = fb_c3(smem, FB_CPS, 72), c1b = fb_c3(smem, FB_CPB, 72);
+      const float4 c2s = fb_c3(smem, FB_CPS, 144), c2b = fb_c3(smem, FB_CPB, 144), cts = fb_c3(smem, FB_CTS, 0), ctb = fb_c3(smem, FB_CTB, 0);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int p = tid + it * FB_THREADS;
+        float f[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          f[c] = hy[it][0] * (wx[it][0] * t[it][0][c] + wx[it][1] * t[it][1][c]) + hy[it][1] * (wx[it][0] * t[it][2][c] + wx[it][1] * t[it][3][c]) + xin[it][c];
+          f[c] = (float)(T)f[c];                   // the stored base of the chain
+          fbase[it][c] = f[c];
+        }
+        if (p < FB_RBW * FB_RBH) {                 // (it == 1: waves 0, 1 only)
+          const int py = p / FB_RBW, px = p - py * FB_RBW;
+          const bool in = inimg[it];
+          // layer 0's source: relu before the rounding, as updense0.hip forms it
+          uint2 pv = make_uint2(0u, 0u);
+          if (in) pv = make_uint2(Half<T>::pack(fmaxf(fmaf(f[0], c0s.x, c0b.x), 0.f), fmaxf(fmaf(f[1], c0s.y, c0b.y), 0.f)), Half<T>::pack(fmaxf(fmaf(f[2], c0s.z, c0b.z), 0.f), 0.f));
+          *reinterpret_cast<uint2*>(smem + FB_PATCH + p * 8) = pv;
+          const f32x2 x01 = {f[0], f[1]}, x2 = {f[2], 0.f};
+          {   // column 0 of A_1
+            const int cy = py - 1, cx = px - 1;
+            if (cy >= 0 && cy < FbIn<1>::H && cx >= 0 && cx < FbIn<1>::W) {
+              uint2 v = fb_preact4<T>(x01, x2, c1s, c1b);
+              if (!in) v = make_uint2(0u, 0u);
+              *reinterpret_cast<uint2*>(smem + fb_plane<1>(0) + (cy * FbIn<1>::W + cx) * 16) = v;
+            }
+          }
+          {   // column 0 of A_2
+            const int cy = py - 2, cx = px - 2;
+            if (cy >= 0 && cy < FbIn<2>::H && cx >= 0 && cx < FbIn<2>::W) {
+              uint2 v = fb_preact4<T>(x01, x2, c2s, c2b);
+              if (!in) v = make_uint2(0u, 0u);
+              *reinterpret_cast<uint2*>(smem + fb_plane<2>(0) + (cy * FbIn<2>::W + cx) * 16) = v;
+            }
+          }
+          {   // the transition's pre-activation of the tile's own base pixels (always inside the picture)
+            const int cy = py - 4, cx = px - 4;
+            if (cy >= 0 && cy < FB_TH && cx >= 0 && cx < FB_TW)
+              *reinterpret_cast<uint2*>(smem + FB_TRPATCH + (cy * FB_TW + cx) * 8) =
+                  make_uint2(Half<T>::pack(fmaxf(fmaf(f[0], cts.x, ctb.x), 0.f), fmaxf(fmaf(f[1], cts.y, ctb.y), 0.f)), Half<T>::pack(fmaxf(fmaf(f[2], cts.z, ctb.z), 0.f), 0.f));
+          }
+        }
+      }
+    }
+    __syncthreads();   // B1: patch, A_1 / A_2 column 0 and trpatch are in LDS; every wave has left the previous tile's layer 3
+
+    // =========================== P1: layer 0 on 22 x 14 -> A_1, A_2, A_3, transition terms of base + g0 ===========================
+    {
+      FB_FRESH_IDS();
+      // layer 0's im2col gather (updense0.hip): K group lq = taps 2 lq, 2 lq + 1 of the pixel's 3x3 window, second step = tap 8
+      const int goA = (((2 * lq) / 3) * FB_RBW + (2 * lq) % 3) * 8, goB = (((2 * lq + 1) / 3) * FB_RBW + (2 * lq + 1) % 3) * 8, goC = (2 * FB_RBW + 2) * 8;
+      // column 0 of A_3 (layer 3 of the PREVIOUS tile read it until B1)
+      const float4 c3s = fb_c3(smem, FB_CPS, 216), c3b = fb_c3(smem, FB_CPB, 216);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int p = tid + it * FB_THREADS;
+        if (p < FB_RBW * FB_RBH) {
+          const int py = p / FB_RBW, px = p - py * FB_RBW;
+          const int cy = py - 3, cx = px - 3;
+          if (cy >= 0 && cy < FbIn<3>::H && cx >= 0 && cx < FbIn<3>::W) {
+            uint2 v = fb_preact4<T>(f32x2{fbase[it][0], fbase[it][1]}, f32x2{fbase[it][2], 0.f}, c3s, c3b);
+            if (!inimg[it]) v = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(smem + fb_plane<3>(0) + (cy * FbIn<3>::W + cx) * 16) = v;
+          }
+        }
+      }
+      float4 cs[3], cb[3];
+#pragma unroll
+      for (int L = 1; L <= 3; ++L) { cs[L - 1] = fb_c4(smem, FB_CPS, 72 * L + 8 + 4 * lq); cb[L - 1] = fb_c4(smem, FB_CPB, 72 * L + 8 + 4 * lq); }
+      const float4 ts = fb_c4(smem, FB_CTS, 8 + 4 * lq), tb = fb_c4(smem, FB_CTB, 8 + 4 * lq);
+      const float4 bias = fb_c4(smem, FB_CEB, 4 * lq);
+      uint4 tra;
+      {
+        const uint2 wg = fb_tr_rows(smem, 8, lq, lp);
+        const uint2 wb = *reinterpret_cast<const uint2*>(smem + FB_TRW + (lp & 3) * 16);   // the base's stored channels 0..3: K group 0
+        tra = make_uint4(wg.x, wg.y, (lq == 0 && lp < 4) ? wb.x : 0u, (lq == 0 && lp < 4) ? wb.y : 0u);
+      }
+      auto l0 = [&](int ry, int rx, uint32_t& u0, uint32_t& u1) {
+        const char* const bp = smem + FB_PATCH + (ry * FB_RBW + rx) * 8;
+        const uint2 pa = *reinterpret_cast<const uint2*>(bp + goA), pb = *reinterpret_cast<const uint2*>(bp + goB), pc = *reinterpret_cast<const uint2*>(bp + goC);
+        f32x4 acc = mma16<T>(wf0[0], make_uint4(pa.x, pa.y, pb.x, pb.y), zero4);
+        acc = mma16<T>(wf0[1], make_uint4(pc.x, pc.y, pc.x, pc.y), acc);
+        u0 = Half<T>::pack(acc[0] + bias.x, acc[1] + bias.y); u1 = Half<T>::pack(acc[2] + bias.z, acc[3] + bias.w);
+      };
+      // centre strip: rows 0..13, 4 / 4 / 3 / 3 per wave
+      const int row0 = wave < 2 ? 4 * wave : 8 + 3 * (wave - 2), nrows = wave < 2 ? 4 : 3;
+      for (int r = 0; r < nrows; ++r) {
+        const int ry = row0 + r, gy = y0 - 3 + ry;
+        const bool img_ok = gy >= 0 && gy < a.H;                                   // wave-uniform
+        uint32_t u0, u1;
+        l0(ry, 3 + lp, u0, u1);
+        fb_emit<T, 0, true>(smem, u0, u1, ry, 3 + lp, img_ok, true, lq, cs, cb);
+        const int c = ry - 3;                                                      // row of the tile itself
+        if (c >= 0 && c < FB_TH) {
+          const uint2 tv = fb_preact4<T>(f32x2{Half<T>::lo(u0), Half<T>::hi(u0)}, f32x2{Half<T>::lo(u1), Half<T>::hi(u1)}, ts, tb);
+          const uint2 bv = *reinterpret_cast<const uint2*>(smem + FB_TRPATCH + (c * FB_TW + lp) * 8);
+          const f32x4 ta = mma16<T>(tra, make_uint4(tv.x, tv.y, bv.x, bv.y), zero4);
+          if (lq == 0) *reinterpret_cast<float4*>(smem + FB_TRP + (c * FB_TW + lp) * 16) = make_float4(ta[0], ta[1], ta[2], 0.f);
+        }
+      }
+      // halo columns 0..2, 19..21: 84 pixels in 6 groups, 1 / 1 / 2 / 2 per wave
+      const int g0 = wave < 2 ? wave : 2 * wave - 2, ng = wave < 2 ? 1 : 2;
+      for (int g = g0; g < g0 + ng; ++g) {
+        const int q = 16 * g + lp;
+        const bool ok = q < 6 * FbIn<1>::H;
+        const int qq = ok ? q : 0, ry = qq / 6, cc = qq - 6 * ry, rx = cc < 3 ? cc : cc + 16;
+        const int gy = y0 - 3 + ry, gx = x0 - 3 + rx;
+        const bool img_ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        uint32_t u0, u1;
+        l0(ry, rx, u0, u1);
+        fb_emit<T, 0, false>(smem, u0, u1, ry, rx, img_ok, ok, lq, cs, cb);
+      }
+    }
+    __syncthreads();   // B2
+
+    // =========================== P2: layer 1 on 20 x 12 -> A_2, A_3, transition term of g1 ===========================
+    {
+      FB_FRESH_IDS();
+      float4 cs[3], cb[3];
+      cs[0] = cb[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int L = 2; L <= 3; ++L) { cs[L - 1] = fb_c4(smem, FB_CPS, 72 * L + 24 + 4 * lq); cb[L - 1] = fb_c4(smem, FB_CPB, 72 * L + 24 + 4 * lq); }
+      const float4 ts = fb_c4(smem, FB_CTS, 24 + 4 * lq), tb = fb_c4(smem, FB_CTB, 24 + 4 * lq);
+      const float4 esc = fb_c4(smem, FB_CES, 16 + 4 * lq), esh = fb_c4(smem, FB_CEB, 16 + 4 * lq);
+      const uint2 trw = fb_tr_rows(smem, 24, lq, lp);
+      auto finish = [&](const f32x4& acc, uint32_t& u0, uint32_t& u1) {
+        const f32x2 lo = __builtin_elementwise_fma(f32x2{acc[0], acc[1]}, f32x2{esc.x, esc.y}, f32x2{esh.x, esh.y});
+        const f32x2 hi = __builtin_elementwise_fma(f32x2{acc[2], acc[3]}, f32x2{esc.z, esc.w}, f32x2{esh.z, esh.w});
+        u0 = __builtin_bit_cast(uint32_t, half_bits<T>(lo)); u1 = __builtin_bit_cast(uint32_t, half_bits<T>(hi));
+      };
+      const int row0 = 3 * wave;
+      const int xb[1] = {fb_plane<1>(min(lq, 2)) + (row0 * FbIn<1>::W + 2 + lp) * 16};
+      f32x4 acc[3];
+      fb_band<T, 1, 1, 3>(smem, xb, w1r, acc);
+#pragma unroll
+      for (int ps = 0; ps < 3; ++ps) {
+        const int ry = row0 + ps, gy = y0 - 2 + ry;
+        const bool img_ok = gy >= 0 && gy < a.H;
+        uint32_t u0, u1;
+        finish(acc[ps], u0, u1);
+        fb_emit<T, 1, true>(smem, u0, u1, ry, 2 + lp, img_ok, true, lq, cs, cb);
+        const int c = ry - 2;
+        if (c >= 0 && c < FB_TH) {
+          const uint2 tv = fb_preact4<T>(f32x2{Half<T>::lo(u0), Half<T>::hi(u0)}, f32x2{Half<T>::lo(u1), Half<T>::hi(u1)}, ts, tb);
+          const f32x4 ta = mma16<T>(make_uint4(trw.x, trw.y, 0u, 0u), make_uint4(tv.x, tv.y, 0u, 0u), zero4);
+          if (lq == 0) {
+            float4* const pp = reinterpret_cast<float4*>(smem + FB_TRP + (c * FB_TW + lp) * 16);
+            const float4 part = *pp;
+            *pp = make_float4(part.x + ta[0], part.y + ta[1], part.z + ta[2], 0.f);
+          }
+        }
+      }
+      if (wave < 3) {   // halo columns 0, 1, 18, 19: 48 pixels in 3 groups
+        const int q = 16 * wave + lp, ry = q >> 2, cc = q & 3, rx = cc < 2 ? cc : cc + 16;
+        const int gy = y0 - 2 + ry, gx = x0 - 2 + rx;
+        const bool img_ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const int xg[1] = {fb_plane<1>(min(lq, 2)) + (ry * FbIn<1>::W + rx) * 16};
+        const f32x4 ga = fb_group<T, 1, 1>(smem, xg, w1r);
+        uint32_t u0, u1;
+        finish(ga, u0, u1);
+        fb_emit<T, 1, false>(smem, u0, u1, ry, rx, img_ok, true, lq, cs, cb);
+      }
+    }
+    __syncthreads();   // B3
+
+    // =========================== P3: layer 2 on 18 x 10 -> A_3 (g2 over A_1's g0 planes), transition term of g2 ===========================
+    {
+      FB_FRESH_IDS();
+      float4 cs[3], cb[3];
+      cs[0] = cb[0] = cs[1] = cb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      cs[2] = fb_c4(smem, FB_CPS, 216 + 40 + 4 * lq); cb[2] = fb_c4(smem, FB_CPB, 216 + 40 + 4 * lq);
+      const float4 ts = fb_c4(smem, FB_CTS, 40 + 4 * lq), tb = fb_c4(smem, FB_CTB, 40 + 4 * lq);
+      const float4 esc = fb_c4(smem, FB_CES, 32 + 4 * lq), esh = fb_c4(smem, FB_CEB, 32 + 4 * lq);
+      const uint2 trw = fb_tr_rows(smem, 40, lq, lp);
+      auto finish = [&](const f32x4& acc, uint32_t& u0, uint32_t& u1) {
+        const f32x2 lo = __builtin_elementwise_fma(f32x2{acc[0], acc[1]}, f32x2{esc.x, esc.y}, f32x2{esh.x, esh.y});
+        const f32x2 hi = __builtin_elementwise_fma(f32x2{acc[2], acc[3]}, f32x2{esc.z, esc.w}, f32x2{esh.z, esh.w});
+        u0 = __builtin_bit_cast(uint32_t, half_bits<T>(lo)); u1 = __builtin_bit_cast(uint32_t, half_bits<T>(hi));
+      };
+      auto row_out = [&](const f32x4& acc, int ry) {
+        const int gy = y0 - 1 + ry;
+        const bool img_ok = gy >= 0 && gy < a.H;
+        uint32_t u0, u1;
+        finish(acc, u0, u1);
+        fb_emit<T, 2, true>(smem, u0, u1, ry, 1 + lp, img_ok, true, lq, cs, cb);
+        const int c = ry - 1;
+        if (c >= 0 && c < FB_TH) {
+          const uint2 tv = fb_preact4<T>(f32x2{Half<T>::lo(u0), Half<T>::hi(u0)}, f32x2{Half<T>::lo(u1), Half<T>::hi(u1)}, ts, tb);
+          const f32x4 ta = mma16<T>(make_uint4(trw.x, trw.y, 0u, 0u), make_uint4(tv.x, tv.y, 0u, 0u), zero4);
+          if (lq == 0) {
+            float4* const pp = reinterpret_cast<float4*>(smem + FB_TRP + (c * FB_TW + lp) * 16);
+            const float4 part = *pp;
+            *pp = make_float4(part.x + ta[0], part.y + ta[1], part.z + ta[2], 0.f);
+          }
+        }
+      };
+      // centre strip: rows 0..9, 3 / 3 / 2 / 2 per wave
+      const int row0 = wave < 2 ? 3 * wave : 6 + 2 * (wave - 2);
+      int xb[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) xb[k] = fb_plane<2>(min(4 * k + lq, 4)) + (row0 * FbIn<2>::W + 1 + lp) * 16;
+      if (wave < 2) {
+        f32x4 acc[3];
+        fb_band<T, 2, 2, 3>(smem, xb, w2r, acc);
+#pragma unroll
+        for (int ps = 0; ps < 3; ++ps) row_out(acc[ps], row0 + ps);
+      } else {
+        f32x4 acc[2];
+        fb_band<T, 2, 2, 2>(smem, xb, w2r, acc);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) row_out(acc[ps], row0 + ps);
+        // halo columns 0, 17: 20 pixels in 2 groups (waves 2, 3)
+        const int q = 16 * (wave - 2) + lp;
+        const bool ok = q < 2 * FbIn<3>::H;
+        const int qq = ok ? q : 0, ry = qq >> 1, rx = (qq & 1) ? 17 : 0;
+        const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+        const bool img_ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        int xg[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) xg[k] = fb_plane<2>(min(4 * k + lq, 4)) + (ry * FbIn<2>::W + rx) * 16;
+        const f32x4 ga = fb_group<T, 2, 2>(smem, xg, w2r);
+        uint32_t u0, u1;
+        finish(ga, u0, u1);
+        fb_emit<T, 2, false>(smem, u0, u1, ry, rx, img_ok, ok, lq, cs, cb);
+      }
+    }
+    __syncthreads();   // B4
+
+    // =========================== P4: layer 3 on the tile, its transition term, bias, sigmoid -> y ===========================
+    {
+      FB_FRESH_IDS();
+      const int wlane = (lq * 9 * 16 + lp) * 16;
+      const int row0 = 2 * wave;
+      int xb[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) xb[k] = fb_plane<3>(min(4 * k + lq, 6)) + (row0 * FbIn<3>::W + lp) * 16;
+      f32x4 acc[2];
+      fb_band_wlds<T, 3, 2, 2>(smem, xb, FB_W3 + wlane, acc);
+      const float4 ts = fb_c4(smem, FB_CTS, 56 + 4 * lq), tb = fb_c4(smem, FB_CTB, 56 + 4 * lq);
+      const float4 esc = fb_c4(smem, FB_CES, 48 + 4 * lq), esh = fb_c4(smem, FB_CEB, 48 + 4 * lq);
+      const uint2 trw = fb_tr_rows(smem, 56, lq, lp);
+      const float4 tes = fb_c4(smem, FB_CTE, 0), teb = fb_c4(smem, FB_CTE, 4);
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int c = row0 + ps;
+        const f32x2 lo = __builtin_elementwise_fma(f32x2{acc[ps][0], acc[ps][1]}, f32x2{esc.x, esc.y}, f32x2{esh.x, esh.y});
+        const f32x2 hi = __builtin_elementwise_fma(f32x2{acc[ps][2], acc[ps][3]}, f32x2{esc.z, esc.w}, f32x2{esh.z, esh.w});
+        const uint32_t u0 = __builtin_bit_cast(uint32_t, half_bits<T>(lo)), u1 = __builtin_bit_cast(uint32_t, half_bits<T>(hi));
+        const uint2 tv = fb_preact4<T>(f32x2{Half<T>::lo(u0), Half<T>::hi(u0)}, f32x2{Half<T>::lo(u1), Half<T>::hi(u1)}, ts, tb);
+        const f32x4 ta = mma16<T>(make_uint4(trw.x, trw.y, 0u, 0u), make_uint4(tv.x, tv.y, 0u, 0u), zero4);
+        if (lq == 0) {
+          const float4 part = *reinterpret_cast<const float4*>(smem + FB_TRP + (c * FB_TW + lp) * 16);
+          float* const ob = a.y + (size_t)img * 3 * hw + ((size_t)(y0 + c) * a.W + x0);   // wave-uniform
+          const float v0 = fmaf(part.x + ta[0], tes.x, teb.x), v1 = fmaf(part.y + ta[1], tes.y, teb.y), v2 = fmaf(part.z + ta[2], tes.z, teb.z);
+          ob[lp] = sigmoidf(v0);
+          ob[hw + lp] = sigmoidf(v1);
+          ob[2 * hw + lp] = sigmoidf(v2);
+        }
+      }
+    }
+    if (++tx == a.tiles_x) { tx = 0; if (++ty == a.tiles_y) { ty = 0; ++img; } }
+  }
+}
+
+}  // namespace mdie
+
+using namespace mdie;
+
+extern "C" int mdie_final_dense_fwd(const mdie_final_dense_desc* d, void* stream) {
+  MDIE_REQUIRE(d != nullptr, "mdie_final_dense_fwd: null descriptor");
+  MDIE_REQUIRE(d->dtype == MDIE_BF16 || d->dtype == MDIE_F16, "mdie_final_dense_fwd: 16-bit element types only (got %d)", d->dtype);
+  MDIE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->H % FB_TH == 0 && d->W % FB_TW == 0,
+               "mdie_final_dense_fwd: extent %dx%dx%d (H a multiple of %d, W of %d)", d->B, d->H, d->W, FB_TH, FB_TW);
+  MDIE_REQUIRE(d->lo && d->x && d->y && d->w0 && d->wt && d->tr_pre_scale && d->tr_pre_shift && d->tr_post_scale && d->tr_post_shift, "mdie_final_dense_fwd: null pointer");
+  for (int l = 0; l < 4; ++l)
+    MDIE_REQUIRE(d->pre_scale[l] && d->pre_shift[l] && d->post_scale[l] && d->post_shift[l] && (l == 0 || d->w[l - 1]), "mdie_final_dense_fwd: layer %d: null pointer", l);
+  uintptr_t al = (uintptr_t)d->lo | (uintptr_t)d->w0 | (uintptr_t)d->wt | (uintptr_t)d->tr_pre_scale | (uintptr_t)d->tr_pre_shift;
+  for (int l = 0; l < 4; ++l) al |= (uintptr_t)d->pre_scale[l] | (uintptr_t)d->pre_shift[l] | (uintptr_t)d->post_scale[l] | (uintptr_t)d->post_shift[l] | (l ? (uintptr_t)d->w[l - 1] : 0);
+  MDIE_REQUIRE((al & 15) == 0, "mdie_final_dense_fwd: lo, the weights and the constant vectors must be 16-byte aligned");
+  MDIE_REQUIRE(d->lo_stride >= 4 && d->lo_stride % 4 == 0, "mdie_final_dense_fwd: lo's pixel stride must be a multiple of 4 channels (%d)", d->lo_stride);
+  MDIE_REQUIRE((size_t)d->H * d->W < ((size_t)1 << 24) && (size_t)(d->H / 2) * (d->W / 2) * d->lo_stride * 2 < ((size_t)1 << 32) && d->lo_stride * 2 < (1 << 24),
+               "mdie_final_dense_fwd: picture too large for the kernel's 24-bit pixel / 32-bit byte offsets (%dx%d)", d->H, d->W);
+  FbArgs a{};
+  a.B = d->B; a.H = d->H; a.W = d->W; a.tiles_x = d->W / FB_TW; a.tiles_y = d->H / FB_TH;
+  a.lo = reinterpret_cast<const char*>(d->lo); a.lo_stride = (unsigned)d->lo_stride * 2u;
+  a.x = d->x;
+  a.w0 = reinterpret_cast<const char*>(d->w0);
+  for (int l = 0; l < 3; ++l) a.w[l] = reinterpret_cast<const char*>(d->w[l]);
+  for (int l = 0; l < 4; ++l) { a.ps[l] = d->pre_scale[l]; a.pb[l] = d->pre_shift[l]; a.esc[l] = d->post_scale[l]; a.esh[l] = d->post_shift[l]; }
+  a.wt = reinterpret_cast<const char*>(d->wt); a.tps = d->tr_pre_scale; a.tpb = d->tr_pre_shift; a.tes = d->tr_post_scale; a.teb = d->tr_post_shift;
+  a.y = d->y;
+  const long items_l = (long)d->B * a.tiles_x * a.tiles_y;
+  MDIE_REQUIRE(items_l < (1l << 30), "mdie_final_dense_fwd: too many tiles (%ld)", items_l);
+  const int items = (int)items_l;
+  const int wgs = 8 * cdiv(std::min(items, 256 * 2), 8);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  TimedLaunch tl(MDIE_K_CONV3);
+  if (d->dtype == MDIE_BF16) {
+    static LdsOptIn opt;
+    if (!opt.ensure(reinterpret_cast<const void*>(&final_block_kernel<bf16>), FB_LDS)) return MDIE_ELAUNCH;
+    hipLaunchKernelGGL((final_block_kernel<bf16>), dim3(wgs), dim3(FB_THREADS), FB_LDS, s, a, items);
+  } else {
+    static LdsOptIn opt;
+    if (!opt.ensure(reinterpret_cast<const void*>(&final_block_kernel<f16>), FB_LDS)) return MDIE_ELAUNCH;
+    hipLaunchKernelGGL((final_block_kernel<f16>), dim3(wgs), dim3(FB_THREADS), FB_LDS, s, a, items);
+  }
+  MDIE_LAUNCH_CHECK("mdie_final_dense_fwd");
+  return MDIE_OK;
+}

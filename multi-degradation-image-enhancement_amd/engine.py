@@ -5,6 +5,7 @@ operation of the path runs in libmdie_hip.so.
 """
 import ctypes as C
 import os
+import threading
 import time
 
 import numpy as np
@@ -69,9 +70,14 @@ def pack_checkpoint(state_dict, dtype):
 #   3  form 2 with the dense1 branch started behind decoder.conv1 instead of behind encoder.conv4 (MDIE_FWD_LATE_DENSE1: 1-4 us on every
 #      box where it was swept beside form 2).
 # Which makes the STEP fastest depends on the box -- round 5, tools/sched_sweep.py, profiles/r05m_sched_sweep.txt, r05u_*: form 2 -29 ... -34 us
-# of 1045 on two boxes, form 1 -30 us of 1052 on a third and +10 of 1007 on the fastest one.  So the choice is TIMED, once per (device,
-# element type, batch shape) and process: CdanEngine.tune.  MDIE_SHARE_CU_CONV4 = auto (default) | 0 | 1 | 2 | 3 fixes it.
+# of 1045 on two boxes, form 1 -30 us of 1052 on a third and +10 of 1007 on the fastest one; form 3 beat form 2 by 1-4 us on every box swept
+# and costs the fastest boxes <= 0.4 %.  So forward() takes form 3 STATICALLY wherever conv_wide runs the layer (it never times anything and
+# never synchronises: the C ABI's contract), and CdanEngine.tune() is an EXPLICIT call -- bench.py makes it in its untimed warm-up, a serving
+# loop may -- that times the four forms once per (device, element type, batch shape) and remembers the winner for later forwards of that
+# shape.  MDIE_SHARE_CU_CONV4 = 0 | 1 | 2 | 3 fixes the form for the process (then tune() returns it untimed).
 _SHARE_CU = {}
+_SHARE_CU_LOCK = threading.Lock()
+DEFAULT_FORM = 3
 
 
 def _share_cu_eligible(dtype, B, H, W):
@@ -94,50 +100,64 @@ class CdanEngine:
         self._ws = None
         self._ws_key = None
         self.use_side_streams = os.environ.get("MDIE_SIDE_STREAMS", "1") != "0"
+        self.chain_tail = os.environ.get("MDIE_CHAIN_TAIL", "0") == "1"   # A/B runs: decoder.final_dense as the four-launch chain (bit-identical)
         mode = os.environ.get("MDIE_SHARE_CU_CONV4", "auto")
-        self.share_cu = None if mode == "auto" else int(mode)          # None: timed per batch shape (tune); 0 / 1 / 2: the form
+        self.share_cu = None if mode == "auto" else int(mode)          # None: the static default, or what an explicit tune() found; 0 .. 3: the form
         self._aux = C.c_void_p(0)
         with torch.cuda.device(self.device):
             L.check(L.lib.mdie_aux_create(C.byref(self._aux)), "mdie_aux_create")
 
-    def tune(self, x, rounds=4, steps=40):
-        """Decide, for x's batch shape, which of the bit-identical forms encoder.conv4 and the dense1 branch run in (above): `rounds` alternating rounds of
-        `steps` eager forwards per form, the first round discarded (about half a second at B = 32, 256x256, once per shape and
-        process; synchronises the device).  The runs must be LONG: what separates the forms is how the chip behaves under sustained
-        load -- rounds of 8 forwards picked the wrong one on a box where 50-step runs differ by 1.6 % the other way
-        (gpurun_out/r05o).  Returns the form (0 ... 3); nothing is timed under stream capture (form 2 is used and NOT remembered)."""
-        B, _, H, W = x.shape
-        key = (self.device.index, self.dtype, B, H, W, self.use_side_streams)
+    def _key(self, B, H, W):
+        return (self.device.index, self.dtype, B, H, W, self.use_side_streams)
+
+    def form(self, B, H, W):
+        """the form forward() runs a batch of this shape in: the environment's, what an explicit tune() found, or the static default -- no timing, no sync"""
         if self.share_cu is not None:
             return self.share_cu
+        got = _SHARE_CU.get(self._key(B, H, W))
+        if got is not None:
+            return got
+        return DEFAULT_FORM if (self.use_side_streams and _share_cu_eligible(self.dtype, B, H, W)) else 0
+
+    def tune(self, x, rounds=4, steps=40):
+        """EXPLICIT, never called by forward(): decide, for x's batch shape, which of the bit-identical forms encoder.conv4 and the dense1 branch
+        run in (above): `rounds` alternating rounds of `steps` eager forwards per form, the first round discarded (about half a second at
+        B = 32, 256x256; SYNCHRONISES the device: call it from a warm-up, with nothing else in flight).  The runs must be LONG: what separates
+        the forms is how the chip behaves under sustained load -- rounds of 8 forwards picked the wrong one on a box where 50-step runs
+        differ by 1.6 % the other way (gpurun_out/r05o).  Returns the form (0 ... 3) and remembers it for later forwards of this shape;
+        under stream capture, with a form fixed by the environment, or for a shape conv_wide does not take, nothing is timed."""
+        B, _, H, W = x.shape
+        key = self._key(B, H, W)
+        if self.share_cu is not None or torch.cuda.is_current_stream_capturing():
+            return self.form(B, H, W)
         if key in _SHARE_CU:
             return _SHARE_CU[key]
         if not self.use_side_streams or not _share_cu_eligible(self.dtype, B, H, W):
-            _SHARE_CU[key] = 0
             return 0
-        if torch.cuda.is_current_stream_capturing():
-            return 2          # (untimed: the form that was never slower than form 0 by more than its 2 us alone, and up to 4.5 % faster)
         y = torch.empty_like(x, dtype=torch.float32)
         forms = (0, 2, 3, 1)
         times = {f: [] for f in forms}
-        with torch.no_grad():
-            for f in forms:
-                self.share_cu = f
-                for _ in range(3):
-                    self.forward(x, out=y)
-            for _ in range(rounds):
+        try:
+            with torch.no_grad():
                 for f in forms:
                     self.share_cu = f
-                    torch.cuda.synchronize(self.device)
-                    t0 = time.perf_counter()
-                    for _ in range(steps):
+                    for _ in range(3):
                         self.forward(x, out=y)
-                    torch.cuda.synchronize(self.device)
-                    times[f].append(time.perf_counter() - t0)
-        self.share_cu = None
+                for _ in range(rounds):
+                    for f in forms:
+                        self.share_cu = f
+                        torch.cuda.synchronize(self.device)
+                        t0 = time.perf_counter()
+                        for _ in range(steps):
+                            self.forward(x, out=y)
+                        torch.cuda.synchronize(self.device)
+                        times[f].append(time.perf_counter() - t0)
+        finally:
+            self.share_cu = None      # (also when a forward raised: a candidate form must not stay pinned)
         med = {f: sorted(t[1:])[(len(t) - 1) // 2] for f, t in times.items()}       # (median of the rounds behind the first)
         best = min(forms, key=lambda f: med[f])
-        _SHARE_CU[key] = best
+        with _SHARE_CU_LOCK:
+            _SHARE_CU[key] = best
         self.tuned = {"shape": (B, H, W), "form": best, "us_per_step": {"0 conv_wide, one run per CU": round(med[0] / steps * 1e6, 1),
                                                                          "2 conv_wide, two runs per CU": round(med[2] / steps * 1e6, 1),
                                                                          "3 as 2, dense1 behind dec.conv1": round(med[3] / steps * 1e6, 1),
@@ -168,13 +188,16 @@ class CdanEngine:
             self._ws_key = key
         return self._ws
 
-    def _flags(self, general_tail=False, share_cu=0):
-        return ((0 if self.use_side_streams else L.FWD_SERIAL) | (L.FWD_GENERAL_TAIL if general_tail else 0)
+    def _flags(self, general_tail=False, share_cu=0, chain_tail=False):
+        return ((0 if self.use_side_streams else L.FWD_SERIAL) | (L.FWD_GENERAL_TAIL if general_tail else 0) | (L.FWD_CHAIN_TAIL if (chain_tail or self.chain_tail) else 0)
                 | (L.FWD_SHARE_CU_CONV4 if share_cu == 1 else L.FWD_YIELD_CU_CONV4 if share_cu == 2 else
                    (L.FWD_YIELD_CU_CONV4 | L.FWD_LATE_DENSE1) if share_cu == 3 else 0))
 
-    def forward(self, x, out=None, want_taps=False, profile=False, general_tail=False):
-        """x: float32 NCHW [B,3,H,W] on this engine's GPU -> float32 NCHW [B,3,H,W]."""
+    def forward(self, x, out=None, want_taps=False, profile=False, general_tail=False, chain_tail=False):
+        """x: float32 NCHW [B,3,H,W] on this engine's GPU -> float32 NCHW [B,3,H,W].  Asynchronous on the current stream: enqueues the
+        launches and returns; never times or synchronises anything (tune() is a separate, explicit call).
+        chain_tail / general_tail: decoder.final_dense as the four-launch chain / the general five-launch chain instead of the one-launch
+        block (bit-identical / within the order of one fp32 sum): A/B runs and tests."""
         if self.params is None:
             raise L.MdieError("CdanEngine.forward before load(state_dict)")
         _require_gpu(x, "CdanEngine.forward")
@@ -183,18 +206,18 @@ class CdanEngine:
         x = x.to(torch.float32).contiguous()
         B, _, H, W = x.shape
         ws = self._workspace(B, H, W)
-        share = self.share_cu if self.share_cu is not None else self.tune(x)
+        share = self.form(B, H, W)
         if out is None and not want_taps and not profile:
             # the plain path goes through the registered operator (torch.ops.mdie.cdan_forward, ops.py)
             from . import ops  # noqa: F401  (registers the library)
             aux = self._aux.value if (self.use_side_streams and self._aux) else 0
-            return torch.ops.mdie.cdan_forward(x, self.params, ws, self.dtype, aux or 0, self._flags(general_tail, share))
+            return torch.ops.mdie.cdan_forward(x, self.params, ws, self.dtype, aux or 0, self._flags(general_tail, share, chain_tail))
         y = out if out is not None else torch.empty_like(x)
         d = L.CdanFwdDesc()
         d.dtype, d.B, d.H, d.W = self.dtype, B, H, W
         d.params, d.x, d.y = self.params.data_ptr(), x.data_ptr(), y.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-        d.flags = self._flags(general_tail, share)
+        d.flags = self._flags(general_tail, share, chain_tail)
         d.aux = self._aux if self.use_side_streams else None
         taps = (L.Tap * len(L.TAP_NAMES))() if want_taps else None
         if taps is not None:

@@ -17,13 +17,14 @@ LIB_PATH = os.environ.get("MDIE_LIB") or os.path.join(_HERE, "libmdie_hip.so")  
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 26
+ABI_VERSION = 27
 PP_KINDS = {"enhance_contrast": 0, "enhance_color": 1, "sharpen": 2, "soft_denoise": 3}
 FWD_SERIAL = 2
 FWD_GENERAL_TAIL = 4
 FWD_SHARE_CU_CONV4 = 16
 FWD_YIELD_CU_CONV4 = 32
 FWD_LATE_DENSE1 = 64
+FWD_CHAIN_TAIL = 128
 LOSS_KINDS = {"mse": 0, "l1": 1, "charbonnier": 2, "ssim": 3, "gradient_l1": 4}
 
 TAP_NAMES = ("skip0", "skip1", "skip2", "dense0", "dense1", "dense2", "enc", "bott", "dec1", "dec2", "dec3", "dec4")
@@ -151,6 +152,15 @@ class UpDense0Desc(C.Structure):
                 ("tr", C.POINTER(TrFuse)), ("blob_delta", C.c_void_p)]
 
 
+class FinalDenseDesc(C.Structure):
+    """mdie_final_dense_desc: decoder.final_dense as one launch (csrc/final_block.hip)"""
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("lo", C.c_void_p), ("lo_stride", C.c_int),
+                ("x", C.c_void_p), ("w0", C.c_void_p), ("w", C.c_void_p * 3),
+                ("pre_scale", C.c_void_p * 4), ("pre_shift", C.c_void_p * 4), ("post_scale", C.c_void_p * 4), ("post_shift", C.c_void_p * 4),
+                ("wt", C.c_void_p), ("tr_pre_scale", C.c_void_p), ("tr_pre_shift", C.c_void_p),
+                ("tr_post_scale", C.c_void_p), ("tr_post_shift", C.c_void_p), ("y", C.c_void_p)]
+
+
 class CbamDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
                 ("x", C.c_void_p), ("x_stride", C.c_int),
@@ -207,6 +217,7 @@ SIGNATURES = {
     "mdie_conv_first_weight_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mdie_pack_conv_first_weight": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mdie_up_add_dense0_fwd": (C.c_int, [C.POINTER(UpDense0Desc), C.c_void_p]),
+    "mdie_final_dense_fwd": (C.c_int, [C.POINTER(FinalDenseDesc), C.c_void_p]),
     "mdie_cbam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mdie_cbam_fwd": (C.c_int, [C.POINTER(CbamDesc), C.c_void_p]),
     "mdie_cbam_channel_only_fwd": (C.c_int, [C.POINTER(CbamDesc), C.c_void_p]),

@@ -506,16 +506,12 @@ def test_upsample_into_first_dense_layer_fused(E, L, precision):
     assert (g0[..., :8] == -7.0).all() and (g0[..., 24:] == -7.0).all()
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
-@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 16, 16), (5, 240, 256)])
-def test_transition_folded_into_its_producers(E, L, precision, shape):
-    """decoder.final_dense with its transition (BN -> ReLU -> Conv1x1 67 -> 3 -> sigmoid, models/cdan.py:48-53,155-157) folded
-    into the four producers of the transition's input (mdie_tr_fuse: csrc/updense0.hip, csrc/conv_thin.hip) against
-      * the SAME block as the general chain -- mdie_up_add_dense0_fwd, three 3x3 layers, the 1x1 launch -- whose terms are the
-        same roundings of the same stored tensors, so the two may differ only in the order of the fp32 sum over the five
-        segments: <= 3e-6 on outputs in (0, 1), growth maps g0..g2 bit-identical, and
-      * torch's CPU arithmetic of the block on the engine's own base tensor.
-    A few tiles (one per workgroup), a single tile, and runs of several tiles per persistent workgroup across image borders."""
+def _final_dense_problem(E, L, precision, shape):
+    """decoder.final_dense (models/cdan.py:22-53,119,153-157) on seeded parameters, behind three forms of the C ABI:
+    run(fold=False): mdie_up_add_dense0_fwd, three 3x3 layers, the 1x1 launch; run(fold=True[, half=True]): the transition folded into the
+    four producers (mdie_tr_fuse); run_block(): ONE launch (mdie_final_dense_fwd).  Returns (run, run_block, ref) with ref() = torch's CPU
+    arithmetic of the block on a given base tensor."""
+
     import ctypes as C
     import torch.nn.functional as F
     dt, td = E.dtype_id(precision), TORCH_DT[precision]
@@ -609,6 +605,47 @@ def test_transition_folded_into_its_producers(E, L, precision, shape):
         torch.cuda.synchronize()
         return base, gs, y
 
+
+    def run_block():
+        f = L.FinalDenseDesc()
+        f.dtype, f.B, f.H, f.W = dt, B, H, W
+        f.lo, f.lo_stride, f.x, f.w0 = lo.data_ptr(), 16, x.data_ptr(), w0.data_ptr()
+        for l in (1, 2, 3):
+            f.w[l - 1] = wl[l].data_ptr()
+        for l in range(4):
+            f.pre_scale[l], f.pre_shift[l], f.post_scale[l], f.post_shift[l] = ps_d[l].data_ptr(), pb_d[l].data_ptr(), ones.data_ptr(), b_d[l].data_ptr()
+        f.wt, f.tr_pre_scale, f.tr_pre_shift = wtp.data_ptr(), pst_d.data_ptr(), pbt_d.data_ptr()
+        f.tr_post_scale, f.tr_post_shift = ones.data_ptr(), bt_d.data_ptr()
+        y = torch.full((B, 3, H, W), -1.0, device="cuda")
+        f.y = y.data_ptr()
+        L.check(L.lib.mdie_final_dense_fwd(C.byref(f), None), "mdie_final_dense_fwd")
+        torch.cuda.synchronize()
+        return y
+
+    def ref(base):
+        # torch CPU arithmetic of the block on the engine's base (stored roundings reproduced: every growth map and every activated operand is rounded to the storage type)
+        feats = [base[..., :3].float().cpu().permute(0, 3, 1, 2)]
+        for l in range(4):
+            cat = torch.cat(feats, 1)
+            act = rnd(torch.relu(cat * pss[l].view(1, -1, 1, 1) + pbs[l].view(1, -1, 1, 1)))
+            feats.append(rnd(F.conv2d(act, rnd(ws[l]), bs[l], padding=1)))
+        cat = torch.cat(feats, 1)
+        act = rnd(torch.relu(cat * pst.view(1, -1, 1, 1) + pbt.view(1, -1, 1, 1)))
+        return torch.sigmoid(F.conv2d(act, rnd(wt), bt))
+    return run, run_block, ref
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 16, 16), (5, 240, 256)])
+def test_transition_folded_into_its_producers(E, L, precision, shape):
+    """decoder.final_dense with its transition (BN -> ReLU -> Conv1x1 67 -> 3 -> sigmoid, models/cdan.py:48-53,155-157) folded
+    into the four producers of the transition's input (mdie_tr_fuse: csrc/updense0.hip, csrc/conv_thin.hip) against
+      * the SAME block as the general chain -- mdie_up_add_dense0_fwd, three 3x3 layers, the 1x1 launch -- whose terms are the
+        same roundings of the same stored tensors, so the two may differ only in the order of the fp32 sum over the five
+        segments: <= 3e-6 on outputs in (0, 1), growth maps g0..g2 bit-identical, and
+      * torch's CPU arithmetic of the block on the engine's own base tensor.
+    A few tiles (one per workgroup), a single tile, and runs of several tiles per persistent workgroup across image borders."""
+    run, _, ref_of = _final_dense_problem(E, L, precision, shape)
     base_u, gs_u, y_u = run(False)
     base_f, gs_f, y_f = run(True)
     base_h, gs_h, y_h = run(True, half=True)
@@ -620,16 +657,71 @@ def test_transition_folded_into_its_producers(E, L, precision, shape):
         assert torch.equal(gs_u[l], gs_f[l]), f"growth map {l} must not change"
     assert (gs_f[3] == -7.0).all(), "the last growth map is never stored when the transition is folded in"
     assert (y_f - y_u).abs().max().item() <= 3e-6
-    # torch CPU arithmetic of the block on the engine's base (stored roundings reproduced: every growth map and every activated operand is rounded to the storage type)
-    feats = [base_f[..., :3].float().cpu().permute(0, 3, 1, 2)]
-    for l in range(4):
-        cat = torch.cat(feats, 1)
-        act = rnd(torch.relu(cat * pss[l].view(1, -1, 1, 1) + pbs[l].view(1, -1, 1, 1)))
-        feats.append(rnd(F.conv2d(act, rnd(ws[l]), bs[l], padding=1)))
-    cat = torch.cat(feats, 1)
-    act = rnd(torch.relu(cat * pst.view(1, -1, 1, 1) + pbt.view(1, -1, 1, 1)))
-    ref = torch.sigmoid(F.conv2d(act, rnd(wt), bt))
-    assert rel_to_max(y_f, ref) <= {"bf16": 8e-3, "fp16": 1e-3}[precision]
+    assert rel_to_max(y_f, ref_of(base_f)) <= {"bf16": 8e-3, "fp16": 1e-3}[precision]
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 16, 16), (1, 8, 16), (3, 24, 32), (5, 240, 256), (33, 64, 48)])
+def test_final_block_one_launch_equals_the_chain(E, L, precision, shape):
+    """mdie_final_dense_fwd (csrc/final_block.hip, ABI 27): upsample + x, the four DenseBlock layers, the transition and the sigmoid in ONE
+    launch -- 16 x 8 output tiles, growth maps in LDS, halo rings recomputed -- against the chain of launches on the same parameters.
+    The kernel keeps the chain's arithmetic operation for operation, so y must be BIT-IDENTICAL to the folded chain's (H a multiple of 16:
+    conv_thin's tiles) and within the order of one fp32 sum (3e-6) of the general chain's everywhere; and <= the storage type's bound of
+    torch's CPU arithmetic of the block.  Single tiles, pictures whose every tile touches a border, H a multiple of 8 only, runs of many
+    tiles per persistent workgroup across picture and image borders, more tiles than workgroups (33 images)."""
+    run, run_block, ref_of = _final_dense_problem(E, L, precision, shape)
+    B, H, W = shape
+    base_u, gs_u, y_u = run(False)
+    y_b = run_block()
+    assert torch.isfinite(y_b).all() and (y_b > 0).all() and (y_b < 1).all(), "every output pixel must have been written with a sigmoid value"
+    assert (y_b - y_u).abs().max().item() <= 3e-6
+    if H % 16 == 0 and W % 16 == 0:
+        _, _, y_f = run(True, half=True)
+        assert torch.equal(y_b, y_f), f"one launch vs folded chain: {(y_b != y_f).sum().item()} of {y_b.numel()} values differ, max {(y_b - y_f).abs().max().item():.3e}"
+    assert torch.equal(run_block(), y_b), "run-to-run"
+    assert rel_to_max(y_b, ref_of(base_u)) <= {"bf16": BF16_TOL, "fp16": F16_TOL}[precision]     # (torch CPU arithmetic: the operator bound)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 64, 64), (3, 128, 160), (32, 256, 256)])
+def test_network_with_the_one_launch_block_equals_the_chain(E, precision, shape):
+    """mdie_cdan_forward runs decoder.final_dense as ONE launch where the folded chain would run (16-bit types, whole 16x16 tiles, one weight
+    set, no taps); MDIE_FWD_CHAIN_TAIL puts the four-launch chain back.  Same arithmetic: the network's output must not change by a bit."""
+    from oracle import params as P
+    x, _ = P.lowlight_batch(45, *shape)
+    x = x.cuda()
+    eng = E.CdanEngine("cuda", precision).load(P.make_state_dict(42))
+    y_block = eng.forward(x, out=torch.empty_like(x)).clone()
+    y_chain = eng.forward(x, out=torch.empty_like(x), chain_tail=True).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(y_block, y_chain), f"{(y_block != y_chain).sum().item()} values differ, max {(y_block - y_chain).abs().max().item():.3e}"
+    _, ex_b = eng.forward(x, out=torch.empty_like(x), profile=True)
+    _, ex_c = eng.forward(x, out=torch.empty_like(x), profile=True, chain_tail=True)
+    assert len(ex_c["launches"]) - len(ex_b["launches"]) == 3, "four launches of the chain become one"
+    assert abs(sum(b for _, b, _ in ex_b["launch_info"]) - sum(b for _, b, _ in ex_c["launch_info"])) <= 1e-6 * sum(b for _, b, _ in ex_c["launch_info"]), \
+        "the block is booked at the chain's share of the SURVEY 8d byte model"
+
+
+def test_forward_of_a_new_shape_does_not_synchronise_or_time_anything(E):
+    """CdanEngine.forward is asynchronous like the C ABI under it: the FIRST forward of a new batch shape enqueues its launches behind whatever
+    the stream holds and returns (round 5 timed 652 forwards inside it -- CdanEngine.tune, now an explicit call bench.py makes in its
+    warm-up).  A long busy-wait kernel is put on the stream first: when forward() returns, the stream must still be busy."""
+    from oracle import params as P
+    eng = E.CdanEngine("cuda", "bf16").load(P.make_state_dict(42))
+    shape = (4, 256, 320)      # a shape no other test uses: conv_wide takes encoder.conv4, so round 5's forward would have tuned here
+    assert E._share_cu_eligible(eng.dtype, *shape) and eng._key(*shape) not in E._SHARE_CU
+    x, _ = P.lowlight_batch(46, *shape)
+    x = x.cuda()
+    y = torch.empty_like(x)
+    eng._workspace(*shape)        # (the arena allocation may synchronise; it is not the forward)
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(2.0e8))     # ~0.1 s of GPU time in front of the forward
+    eng.forward(x, out=y)
+    assert not torch.cuda.current_stream().query(), "forward() returned only after the stream had drained: it synchronised"
+    torch.cuda.synchronize()
+    assert eng._key(*shape) not in E._SHARE_CU and eng.form(*shape) == E.DEFAULT_FORM
+    _, ex = eng.forward(x, out=y, profile=True)
+    assert len(ex["launches"]) == 36, len(ex["launches"])     # 39 of round 5, decoder.final_dense's four now one
 
 
 def test_transition_fusion_rejects_what_it_cannot_run(E, L):
@@ -843,9 +935,11 @@ def test_conv4_forms_are_bit_identical(E, L, prec, shape):
         for k in outs[0][1]:
             assert torch.equal(outs[0][1][k], outs[form][1][k]), (form, k)
     eng.share_cu = None
+    # forward() runs the static default untimed; tune() is the explicit call that times the forms and is remembered for the shape
+    assert eng.form(*shape) == (E.DEFAULT_FORM if E._share_cu_eligible(eng.dtype, *shape) else 0) or eng._key(*shape) in E._SHARE_CU
     d1 = eng.tune(x)
     d2 = eng.tune(x)
-    assert d1 == d2 and d1 in (0, 1, 2, 3)
+    assert d1 == d2 and d1 in (0, 1, 2, 3) and eng.form(*shape) == d1
     assert torch.equal(eng.forward(x), outs[0][0])
     if not E._share_cu_eligible(eng.dtype, *shape):
         assert d1 == 0

@@ -17,7 +17,7 @@ eng0 = net._engine(dev)
 st = torch.cuda.Stream(dev)
 with torch.cuda.stream(st):
     eng1 = net._engine(dev)          # (modules.CDAN keeps one engine per stream)
-eng0.tune(x)
+eng0.tune(x)   # (explicit: forward() never tunes)
 
 
 def run(eng, stream, n):
