@@ -89,6 +89,7 @@ struct FbArgs {
   const float* tps; const float* tpb;      // its folded BatchNorm by stored input channel
   const float* tes; const float* teb;      // its epilogue (1, bias), >= 3 entries
   float* y;                                // fp32 NCHW
+  unsigned long long* dbg;                 // (diagnostic builds)
 };
 
 __device__ __forceinline__ void fb_src(int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {   // = resample.hip src_index
@@ -227,6 +228,13 @@ __device__ __forceinline__ float4 fb_c3(const char* smem, int table, int index) 
   return v;
 }
 
+#ifdef EXP_FBSTAMPS   // diagnostic build only (tools/stamp_final.py): per-phase shader-clock sums of every wave, summed over its tiles
+static unsigned long long* g_fb_dbg = nullptr;
+#define FSEG(k) do { if (dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if ((k) >= 0) facc[(k) < 0 ? 0 : (k)] += t_ - fprev; fprev = t_; } } while (0)
+#else
+#define FSEG(k) do {} while (0)
+#endif
+
 // Lane / wave indices laundered through an empty asm at the top of every phase: everything a phase derives from them (plane offsets,
 // halo-group pixels, gather offsets) is tile-invariant, and hoisted out of the tile loop it stayed live across ALL phases -- next to
 // 116 registers of weights that meant scratch spills.  Recomputing a few integer instructions per phase is cheaper.
@@ -250,6 +258,12 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
   int item = band0 + ((int)blockIdx.x >> 3) * run;
   const int run_end = min(item + run, band1);
   if (item >= run_end) return;
+#ifdef EXP_FBSTAMPS
+  unsigned long long* const dbg = a.dbg;
+  unsigned long long facc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = 0, fstart = 0, rstart = 0;
+  if (dbg) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(fstart), "=s"(rstart) :: "memory");
+  const int item_first = item;
+#endif
 
   uint4 wf0[2], w1r[1][9], w2r[2][9];
   {
@@ -300,6 +314,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
 
   for (; item < run_end; ++item) {
     const int y0 = ty * FB_TH, x0 = tx * FB_TW;
+    FSEG(-1);
 
     // =========================== P0: the base patch, 24 x 16 ===========================
     float fbase[2][3];
@@ -384,8 +399,10 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
         }
       }
     }
+    FSEG(0);
     __syncthreads();   // B1: patch, A_1 / A_2 column 0 and trpatch are in LDS; every wave has left the previous tile's layer 3
 
+    FSEG(1);
     // =========================== P1: layer 0 on 22 x 14 -> A_1, A_2, A_3, transition terms of base + g0 ===========================
     {
       FB_FRESH_IDS();
@@ -453,7 +470,9 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
         fb_emit<T, 0, false>(smem, u0, u1, ry, rx, img_ok, ok, lq, cs, cb);
       }
     }
+    FSEG(2);
     __syncthreads();   // B2
+    FSEG(3);
 
     // =========================== P2: layer 1 on 20 x 12 -> A_2, A_3, transition term of g1 ===========================
     {
@@ -474,6 +493,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
       const int xb[1] = {fb_plane<1>(min(lq, 2)) + (row0 * FbIn<1>::W + 2 + lp) * 16};
       f32x4 acc[3];
       fb_band<T, 1, 1, 3>(smem, xb, w1r, acc);
+      FSEG(4);
 #pragma unroll
       for (int ps = 0; ps < 3; ++ps) {
         const int ry = row0 + ps, gy = y0 - 2 + ry;
@@ -503,7 +523,9 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
         fb_emit<T, 1, false>(smem, u0, u1, ry, rx, img_ok, true, lq, cs, cb);
       }
     }
+    FSEG(9);
     __syncthreads();   // B3
+    FSEG(5);
 
     // =========================== P3: layer 2 on 18 x 10 -> A_3 (g2 over A_1's g0 planes), transition term of g2 ===========================
     {
@@ -544,11 +566,13 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
       if (wave < 2) {
         f32x4 acc[3];
         fb_band<T, 2, 2, 3>(smem, xb, w2r, acc);
+        FSEG(6);
 #pragma unroll
         for (int ps = 0; ps < 3; ++ps) row_out(acc[ps], row0 + ps);
       } else {
         f32x4 acc[2];
         fb_band<T, 2, 2, 2>(smem, xb, w2r, acc);
+        FSEG(6);
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) row_out(acc[ps], row0 + ps);
         // halo columns 0, 17: 20 pixels in 2 groups (waves 2, 3)
@@ -566,7 +590,9 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
         fb_emit<T, 2, false>(smem, u0, u1, ry, rx, img_ok, ok, lq, cs, cb);
       }
     }
+    FSEG(10);
     __syncthreads();   // B4
+    FSEG(7);
 
     // =========================== P4: layer 3 on the tile, its transition term, bias, sigmoid -> y ===========================
     {
@@ -578,6 +604,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
       for (int k = 0; k < 2; ++k) xb[k] = fb_plane<3>(min(4 * k + lq, 6)) + (row0 * FbIn<3>::W + lp) * 16;
       f32x4 acc[2];
       fb_band_wlds<T, 3, 2, 2>(smem, xb, FB_W3 + wlane, acc);
+      FSEG(8);
       const float4 ts = fb_c4(smem, FB_CTS, 56 + 4 * lq), tb = fb_c4(smem, FB_CTB, 56 + 4 * lq);
       const float4 esc = fb_c4(smem, FB_CES, 48 + 4 * lq), esh = fb_c4(smem, FB_CEB, 48 + 4 * lq);
       const uint2 trw = fb_tr_rows(smem, 56, lq, lp);
@@ -600,8 +627,17 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
         }
       }
     }
+    FSEG(11);
     if (++tx == a.tiles_x) { tx = 0; if (++ty == a.tiles_y) { ty = 0; ++img; } }
   }
+#ifdef EXP_FBSTAMPS
+  if (dbg && (tid_ & 63) == 0) {
+    unsigned long long t1, r1; asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+    unsigned long long* o = dbg + ((size_t)blockIdx.x * 4 + wave_) * 16;
+    for (int k = 0; k < 12; ++k) o[k] = facc[k];
+    o[12] = item - item_first; o[13] = t1 - fstart; o[14] = rstart; o[15] = r1;
+  }
+#endif
 }
 
 }  // namespace mdie
@@ -635,6 +671,9 @@ extern "C" int mdie_final_dense_fwd(const mdie_final_dense_desc* d, void* stream
   MDIE_REQUIRE(items_l < (1l << 30), "mdie_final_dense_fwd: too many tiles (%ld)", items_l);
   const int items = (int)items_l;
   const int wgs = 8 * cdiv(std::min(items, 256 * 2), 8);
+#ifdef EXP_FBSTAMPS
+  a.dbg = g_fb_dbg;
+#endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   TimedLaunch tl(MDIE_K_CONV3);
   if (d->dtype == MDIE_BF16) {
@@ -649,3 +688,7 @@ extern "C" int mdie_final_dense_fwd(const mdie_final_dense_desc* d, void* stream
   MDIE_LAUNCH_CHECK("mdie_final_dense_fwd");
   return MDIE_OK;
 }
+
+#ifdef EXP_FBSTAMPS
+extern "C" void mdie_exp_set_fb_dbg(void* p) { mdie::g_fb_dbg = (unsigned long long*)p; }
+#endif
