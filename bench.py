@@ -268,7 +268,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        LA.init_or_exit(dist.init_process_group, "nccl", device_id=dev)
 
     from mdie_amd import lib as L
     from models.cdan import CDAN
@@ -355,9 +355,15 @@ def main():
             for k in prof:
                 prof[k] = (prof[k][0] // reps, prof[k][1] / reps, prof[k][2] / reps, prof[k][3] / reps)
 
+    # under world > 1 every rank reports the form ITS box timed as fastest (the forms are bit-identical; boxes differ in which one wins)
+    forms = None
+    if dist is not None:
+        forms = [None] * world
+        dist.all_gather_object(forms, getattr(eng, "tuned", {"form": eng.form(B, S, S), "untimed": True}).get("form"))
     if rank != 0:
         if dist is not None:
-            dist.destroy_process_group()
+            graph = run = None
+            _host.shutdown_distributed()      # (no graph of this process holds a collective; the order is the library's one teardown order all the same)
         return
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -411,7 +417,8 @@ def main():
                       "runtime": args.runtime,
                       # encoder.conv4 runs in one of three bit-identical forms, timed once per shape in the first (untimed) step: how long it
                       # holds its CUs while the DenseBlock branches wait for them (mdie_amd/engine.py: CdanEngine.tune)
-                      "conv4_form": getattr(eng, "tuned", {"form": eng.form(B, S, S), "untimed": True})},
+                      "conv4_form": getattr(eng, "tuned", {"form": eng.form(B, S, S), "untimed": True}),
+                      **({"conv4_form_per_rank": forms} if forms is not None else {})},
            "roofline": roofline}
 
     if not args.no_extra and world == 1:
@@ -476,7 +483,8 @@ def main():
         e.pop("_y", None)
     print(json.dumps(out))
     if dist is not None:
-        dist.destroy_process_group()
+        graph = run = None
+        _host.shutdown_distributed()
 
 
 if __name__ == "__main__":

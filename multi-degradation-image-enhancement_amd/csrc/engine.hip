@@ -945,6 +945,7 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
 extern "C" int mdie_aux_create(void** out) {
   MDIE_REQUIRE(out != nullptr, "mdie_aux_create: null argument");
   Aux* a = new Aux();
+  for (int i = 0; i < 3; ++i) { a->side[i] = nullptr; a->fork[i] = nullptr; a->join[i] = nullptr; }
   hipError_t err = hipSuccess;
   for (int i = 0; i < 3 && err == hipSuccess; ++i) {
 #ifdef EXP_SCHED   // schedule-exploration builds only: MDIE_EXP_SIDE_PRIO = low | high -- the side streams' priority against the caller's stream
@@ -963,7 +964,11 @@ extern "C" int mdie_aux_create(void** out) {
     if (err == hipSuccess) err = hipEventCreateWithFlags(&a->fork[i], evf);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&a->join[i], evf);
   }
-  if (err != hipSuccess) { set_error("mdie_aux_create: HIP stream/event creation failed: %s", hipGetErrorString(err)); delete a; return MDIE_ELAUNCH; }
+  if (err != hipSuccess) {   // give back what was created before the failure
+    set_error("mdie_aux_create: HIP stream/event creation failed: %s", hipGetErrorString(err));
+    mdie_aux_destroy(a);
+    return MDIE_ELAUNCH;
+  }
   *out = a;
   return MDIE_OK;
 }
@@ -972,9 +977,9 @@ extern "C" void mdie_aux_destroy(void* aux) {
   Aux* a = reinterpret_cast<Aux*>(aux);
   if (!a) return;
   for (int i = 0; i < 3; ++i) {
-    (void)hipStreamDestroy(a->side[i]);
-    (void)hipEventDestroy(a->fork[i]);
-    (void)hipEventDestroy(a->join[i]);
+    if (a->side[i]) (void)hipStreamDestroy(a->side[i]);
+    if (a->fork[i]) (void)hipEventDestroy(a->fork[i]);
+    if (a->join[i]) (void)hipEventDestroy(a->join[i]);
   }
   delete a;
 }

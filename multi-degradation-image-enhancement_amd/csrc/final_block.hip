@@ -67,7 +67,8 @@ constexpr int FB_CES = FB_CTB + 72 * 4;                     // float [4][16] + [
 constexpr int FB_CEB = FB_CES + 4 * 16 * 4;
 constexpr int FB_CTE = FB_CEB + 4 * 16 * 4;                 // float [4] + [4]: the transition's epilogue
 constexpr int FB_TRW = FB_CTE + 32;                         // rows 0..3 of the transition's weights: [9 K groups (8 stored channels)][4 rows][16 B]
-constexpr int FB_LDS = FB_TRW + 9 * 64;
+constexpr int FB_DUMP = FB_TRW + 9 * 64;                    // 16 bytes nobody reads: where a lane writes when its pixel lies outside a consumer's region
+constexpr int FB_LDS = FB_DUMP + 64;
 static_assert(2 * FbIn<3>::PLANE <= 2 * FbIn<1>::PLANE, "g2's planes must fit A_1's g0 planes");
 static_assert(FB_LDS <= 80 * 1024, "two workgroups per CU");
 
@@ -312,9 +313,371 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
   { int r = item; tx = r % a.tiles_x; r /= a.tiles_x; ty = r % a.tiles_y; img = r / a.tiles_y; }
   __syncthreads();
 
+
+  // ===================================================================================================================
+  // INTERIOR tiles (the whole 24 x 16 base patch inside the picture: 82 % of the tiles of a 256 x 256 picture).  Same arithmetic as
+  // the general path below, none of its border logic, and everything a thread can know before the tile exists is hoisted or made
+  // compile-time: version 1 of this kernel (one path for all tiles) ran 313 us against 235 us for the chain -- issue-bound, 2 540
+  // instructions per wave and tile of which 143 MFMAs (profiles/r06c_final_block_v1_stamps.txt).  Here:
+  //   * no in-picture predicates, no selects of zeros, unconditional loads; the bilinear weights are the pixel's parity (0.25 / 0.75);
+  //   * rows are dealt to waves so that wave w owns rows 2 w, 2 w + 1 of the tile in EVERY layer: the transition's running sums of
+  //     those two rows stay in registers (lanes 0..15 / 16..31 through two A-operand row slots), no LDS read-modify-write;
+  //     the halo rows above / below go to waves 0 / 3, the halo-column groups to waves 1 / 2;
+  //   * a pixel outside a consumer's region is written to a dump slot (one select) instead of branched around.
+  // ===================================================================================================================
+  auto tile_interior = [&](const int img, const int y0, const int x0) {
+    float fbase[2][3];
+    f32x4 tsum = zero4;          // lanes (lq < 2, lp): transition outputs 0..2 of pixel (row 2 wave + lq, column lp), summed over the segments so far
+    // ---- P0 ----
+    {
+      const int tid = tid_;      // (NOT laundered: a thread's patch pixel, its tap offsets and LDS slots are tile-invariant and meant to be hoisted)
+      const unsigned ls = a.lo_stride;
+      const char* const lb = a.lo + ((size_t)(img * Hl + ((y0 - 4) >> 1)) * Wl + ((x0 - 4) >> 1)) * ls;   // scalar: tap (0, 0) of patch pixel (1, 1)
+      const float* const xb = a.x + (size_t)img * 3 * hw + (size_t)(y0 - 4) * a.W + (x0 - 4);             // scalar: patch pixel (0, 0)
+      uint2 tap[2][4];
+      float xin[2][3];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        if (it == 0 || tid < FB_RBW * FB_RBH - FB_THREADS) {
+          const int p = tid + it * FB_THREADS, py = p / FB_RBW, px = p - py * FB_RBW;
+          const int lo_off = (((py - 1) >> 1) * Wl + ((px - 1) >> 1)) * (int)ls;     // (may be negative: the patch starts one low-resolution pixel before lb)
+          const char* const q = lb + lo_off;
+          tap[it][0] = *reinterpret_cast<const uint2*>(q); tap[it][1] = *reinterpret_cast<const uint2*>(q + ls);
+          tap[it][2] = *reinterpret_cast<const uint2*>(q + (size_t)Wl * ls); tap[it][3] = *reinterpret_cast<const uint2*>(q + (size_t)Wl * ls + ls);
+          const float* const xq = xb + py * a.W + px;
+          xin[it][0] = xq[0]; xin[it][1] = xq[hw]; xin[it][2] = xq[2 * hw];
+        }
+      }
+      const float4 c0s = fb_c3(smem, FB_CPS, 0), c0b = fb_c3(smem, FB_CPB, 0), c1s = fb_c3(smem, FB_CPS, 72), c1b = fb_c3(smem, FB_CPB, 72);
+      const float4 c2s = fb_c3(smem, FB_CPS, 144), c2b = fb_c3(smem, FB_CPB, 144), cts = fb_c3(smem, FB_CTS, 0), ctb = fb_c3(smem, FB_CTB, 0);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        if (it == 0 || tid < FB_RBW * FB_RBH - FB_THREADS) {
+          const int p = tid + it * FB_THREADS, py = p / FB_RBW, px = p - py * FB_RBW;
+          // src = (dst + 0.5) / 2 - 0.5 away from the picture's edge: the upper / left tap weighs 0.25 on even, 0.75 on odd pixels (fb_src's values)
+          const float hy1 = (py & 1) ? 0.25f : 0.75f, hy0 = 1.0f - hy1, wx1 = (px & 1) ? 0.25f : 0.75f, wx0 = 1.0f - wx1;
+          float f[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float t0 = c == 0 ? Half<T>::lo(tap[it][0].x) : c == 1 ? Half<T>::hi(tap[it][0].x) : Half<T>::lo(tap[it][0].y);
+            const float t1 = c == 0 ? Half<T>::lo(tap[it][1].x) : c == 1 ? Half<T>::hi(tap[it][1].x) : Half<T>::lo(tap[it][1].y);
+            const float t2 = c == 0 ? Half<T>::lo(tap[it][2].x) : c == 1 ? Half<T>::hi(tap[it][2].x) : Half<T>::lo(tap[it][2].y);
+            const float t3 = c == 0 ? Half<T>::lo(tap[it][3].x) : c == 1 ? Half<T>::hi(tap[it][3].x) : Half<T>::lo(tap[it][3].y);
+            f[c] = hy0 * (wx0 * t0 + wx1 * t1) + hy1 * (wx0 * t2 + wx1 * t3) + xin[it][c];
+            f[c] = (float)(T)f[c];
+            fbase[it][c] = f[c];
+          }
+          *reinterpret_cast<uint2*>(smem + FB_PATCH + p * 8) =
+              make_uint2(Half<T>::pack(fmaxf(fmaf(f[0], c0s.x, c0b.x), 0.f), fmaxf(fmaf(f[1], c0s.y, c0b.y), 0.f)), Half<T>::pack(fmaxf(fmaf(f[2], c0s.z, c0b.z), 0.f), 0.f));
+          const f32x2 x01 = {f[0], f[1]}, x2 = {f[2], 0.f};
+          const bool in1 = (unsigned)(py - 1) < (unsigned)FbIn<1>::H && (unsigned)(px - 1) < (unsigned)FbIn<1>::W;
+          const bool in2 = (unsigned)(py - 2) < (unsigned)FbIn<2>::H && (unsigned)(px - 2) < (unsigned)FbIn<2>::W;
+          const bool in4 = (unsigned)(py - 4) < (unsigned)FB_TH && (unsigned)(px - 4) < (unsigned)FB_TW;
+          *reinterpret_cast<uint2*>(smem + (in1 ? fb_plane<1>(0) + ((py - 1) * FbIn<1>::W + (px - 1)) * 16 : FB_DUMP)) = fb_preact4<T>(x01, x2, c1s, c1b);
+          *reinterpret_cast<uint2*>(smem + (in2 ? fb_plane<2>(0) + ((py - 2) * FbIn<2>::W + (px - 2)) * 16 : FB_DUMP)) = fb_preact4<T>(x01, x2, c2s, c2b);
+          *reinterpret_cast<uint2*>(smem + (in4 ? FB_TRPATCH + ((py - 4) * FB_TW + (px - 4)) * 8 : FB_DUMP)) =
+              make_uint2(Half<T>::pack(fmaxf(fmaf(f[0], cts.x, ctb.x), 0.f), fmaxf(fmaf(f[1], cts.y, ctb.y), 0.f)), Half<T>::pack(fmaxf(fmaf(f[2], cts.z, ctb.z), 0.f), 0.f));
+        }
+      }
+    }
+    FSEG(0);
+    __syncthreads();   // B1
+    FSEG(1);
+    // ---- P1: layer 0 ----
+    {
+      {   // column 0 of A_3 (layer 3 of the previous tile read it until B1)
+        const int tid = tid_;
+        const float4 c3s = fb_c3(smem, FB_CPS, 216), c3b = fb_c3(smem, FB_CPB, 216);
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+          if (it == 0 || tid < FB_RBW * FB_RBH - FB_THREADS) {
+            const int p = tid + it * FB_THREADS, py = p / FB_RBW, px = p - py * FB_RBW;
+            const bool in3 = (unsigned)(py - 3) < (unsigned)FbIn<3>::H && (unsigned)(px - 3) < (unsigned)FbIn<3>::W;
+            *reinterpret_cast<uint2*>(smem + (in3 ? fb_plane<3>(0) + ((py - 3) * FbIn<3>::W + (px - 3)) * 16 : FB_DUMP)) =
+                fb_preact4<T>(f32x2{fbase[it][0], fbase[it][1]}, f32x2{fbase[it][2], 0.f}, c3s, c3b);
+          }
+      }
+      FB_FRESH_IDS();
+      const int goA = (((2 * lq) / 3) * FB_RBW + (2 * lq) % 3) * 8, goB = (((2 * lq + 1) / 3) * FB_RBW + (2 * lq + 1) % 3) * 8, goC = (2 * FB_RBW + 2) * 8;
+      float4 cs[3], cb[3];
+#pragma unroll
+      for (int L = 1; L <= 3; ++L) { cs[L - 1] = fb_c4(smem, FB_CPS, 72 * L + 8 + 4 * lq); cb[L - 1] = fb_c4(smem, FB_CPB, 72 * L + 8 + 4 * lq); }
+      const float4 ts = fb_c4(smem, FB_CTS, 8 + 4 * lq), tb = fb_c4(smem, FB_CTB, 8 + 4 * lq);
+      const float4 bias = fb_c4(smem, FB_CEB, 4 * lq);
+      uint4 trw;   // the transition's rows (lp & 3) for g0's channels 4 lq .. and, in K group 0, the base's
+      {
+        const int c = 8 + 4 * lq;
+        const uint2 wg = *reinterpret_cast<const uint2*>(smem + FB_TRW + (c >> 3) * 64 + (lp & 3) * 16 + (c & 7) * 2);
+        const uint2 wb = *reinterpret_cast<const uint2*>(smem + FB_TRW + (lp & 3) * 16);
+        trw = make_uint4(wg.x, wg.y, lq == 0 ? wb.x : 0u, lq == 0 ? wb.y : 0u);
+      }
+      // the lane's column of g0 (2 planes per growth map: lq >> 1; 8-byte half: lq & 1) in the three images, at the centre strip's pixel lp of row 0
+      const int half = (lq & 1) * 8;
+      const int e1 = fb_plane<1>(1 + (lq >> 1)) + half + (3 + lp) * 16, e2 = fb_plane<2>(1 + (lq >> 1)) + half + (2 + lp) * 16, e3 = fb_plane<3>(1 + (lq >> 1)) + half + (1 + lp) * 16;
+      f32x4 ta = zero4;
+      // Five units per wave.  Waves 0 / 3: rows 0..4 (taken 4, 3, .. 0) / 9..13 of the centre strip -- the two tile rows first, then the halo
+      // rows outwards, so unit u means the same thing in both; waves 1 / 2: rows 5, 6 / 7, 8 and three groups of halo columns (0..2, 19..21 of
+      // all 14 rows: 84 pixels in 6 groups).  Per unit: the window corner in the patch and the slot of the lane's 8 bytes in A_1, A_2, A_3
+      // (the dump slot where the pixel lies outside the image of that layer); units 0, 1 are rows of the tile itself.
+      // ALL reads of the phase, then all MFMAs, then the epilogues: LDS operations keep their program order (one address space to the
+      // compiler), so a unit-by-unit loop paid a full read -> MFMA -> convert -> write latency chain per unit (version 1: ~800 cycles each).
+      int vb[5], a1[5], a2[5], a3[5], crow[2];
+      const int plane_lane = FB_PATCH + (3 + lp) * 8;
+      if (wave == 0 || wave == 3) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int row = wave == 0 ? 4 - u : 9 + u;
+          vb[u] = plane_lane + row * (FB_RBW * 8);
+          a1[u] = e1 + row * (FbIn<1>::W * 16);
+          a2[u] = u <= 3 ? e2 + (row - 1) * (FbIn<2>::W * 16) : FB_DUMP;
+          a3[u] = u <= 2 ? e3 + (row - 2) * (FbIn<3>::W * 16) : FB_DUMP;
+          if (u < 2) crow[u] = row - 3;
+        }
+      } else {
+        const int pl = (1 + (lq >> 1));
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          if (u < 2) {
+            const int row = 3 + 2 * wave + u;
+            vb[u] = plane_lane + row * (FB_RBW * 8);
+            a1[u] = e1 + row * (FbIn<1>::W * 16); a2[u] = e2 + (row - 1) * (FbIn<2>::W * 16); a3[u] = e3 + (row - 2) * (FbIn<3>::W * 16);
+            crow[u] = 2 * wave + u;
+          } else {
+            const int q = 16 * (3 * (wave - 1) + u - 2) + lp;
+            const bool ok = q < 6 * FbIn<1>::H;
+            const int qq = ok ? q : 0, ry = qq / 6, cc = qq - 6 * ry, rx = cc < 3 ? cc : cc + 16;
+            const bool in2 = ok && (unsigned)(ry - 1) < (unsigned)FbIn<2>::H && (unsigned)(rx - 1) < (unsigned)FbIn<2>::W;
+            const bool in3 = ok && (unsigned)(ry - 2) < (unsigned)FbIn<3>::H && (unsigned)(rx - 2) < (unsigned)FbIn<3>::W;
+            vb[u] = FB_PATCH + (ry * FB_RBW + rx) * 8;
+            a1[u] = ok ? fb_plane<1>(pl) + half + (ry * FbIn<1>::W + rx) * 16 : FB_DUMP;
+            a2[u] = in2 ? fb_plane<2>(pl) + half + ((ry - 1) * FbIn<2>::W + rx - 1) * 16 : FB_DUMP;
+            a3[u] = in3 ? fb_plane<3>(pl) + half + ((ry - 2) * FbIn<3>::W + rx - 2) * 16 : FB_DUMP;
+          }
+        }
+      }
+      uint2 pa[5], pb[5], pc[5], bv[2];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        pa[u] = *reinterpret_cast<const uint2*>(smem + vb[u] + goA); pb[u] = *reinterpret_cast<const uint2*>(smem + vb[u] + goB); pc[u] = *reinterpret_cast<const uint2*>(smem + vb[u] + goC);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) bv[u] = *reinterpret_cast<const uint2*>(smem + FB_TRPATCH + (crow[u] * FB_TW + lp) * 8);
+      f32x4 acc[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) acc[u] = mma16<T>(wf0[0], make_uint4(pa[u].x, pa[u].y, pb[u].x, pb[u].y), zero4);
+#pragma unroll
+      for (int u = 0; u < 5; ++u) acc[u] = mma16<T>(wf0[1], make_uint4(pc[u].x, pc[u].y, pc[u].x, pc[u].y), acc[u]);
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const uint32_t u0 = Half<T>::pack(acc[u][0] + bias.x, acc[u][1] + bias.y), u1 = Half<T>::pack(acc[u][2] + bias.z, acc[u][3] + bias.w);
+        const f32x2 x0_ = {Half<T>::lo(u0), Half<T>::hi(u0)}, x1_ = {Half<T>::lo(u1), Half<T>::hi(u1)};
+        *reinterpret_cast<uint2*>(smem + a1[u]) = fb_preact4<T>(x0_, x1_, cs[0], cb[0]);
+        *reinterpret_cast<uint2*>(smem + a2[u]) = fb_preact4<T>(x0_, x1_, cs[1], cb[1]);
+        *reinterpret_cast<uint2*>(smem + a3[u]) = fb_preact4<T>(x0_, x1_, cs[2], cb[2]);
+        if (u < 2) {   // a row of the tile: the transition's terms of base + g0 into row slot crow & 1
+          const uint2 tv = fb_preact4<T>(x0_, x1_, ts, tb);
+          const bool mine = (lp >> 2) == (crow[u] & 1);
+          ta = mma16<T>(make_uint4(mine ? trw.x : 0u, mine ? trw.y : 0u, mine ? trw.z : 0u, mine ? trw.w : 0u), make_uint4(tv.x, tv.y, bv[u].x, bv[u].y), ta);
+        }
+      }
+      tsum = ta;
+    }
+    FSEG(2);
+    __syncthreads();   // B2
+    FSEG(3);
+    // ---- P2: layer 1 ----
+    {
+      FB_FRESH_IDS();
+      float4 cs[3], cb[3];
+      cs[0] = cb[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int L = 2; L <= 3; ++L) { cs[L - 1] = fb_c4(smem, FB_CPS, 72 * L + 24 + 4 * lq); cb[L - 1] = fb_c4(smem, FB_CPB, 72 * L + 24 + 4 * lq); }
+      const float4 ts = fb_c4(smem, FB_CTS, 24 + 4 * lq), tb = fb_c4(smem, FB_CTB, 24 + 4 * lq);
+      const float4 esc = fb_c4(smem, FB_CES, 16 + 4 * lq), esh = fb_c4(smem, FB_CEB, 16 + 4 * lq);
+      const uint2 trw = *reinterpret_cast<const uint2*>(smem + FB_TRW + ((24 + 4 * lq) >> 3) * 64 + (lp & 3) * 16 + ((24 + 4 * lq) & 7) * 2);
+      const int half = (lq & 1) * 8, pl = 3 + (lq >> 1);
+      const int e2 = fb_plane<2>(pl) + half + (2 + lp) * 16, e3 = fb_plane<3>(pl) + half + (1 + lp) * 16;
+      f32x4 ta = zero4;
+      auto finish = [&](const f32x4& acc, f32x2& x0_, f32x2& x1_) {
+        const f32x2 lo = __builtin_elementwise_fma(f32x2{acc[0], acc[1]}, f32x2{esc.x, esc.y}, f32x2{esh.x, esh.y});
+        const f32x2 hi = __builtin_elementwise_fma(f32x2{acc[2], acc[3]}, f32x2{esc.z, esc.w}, f32x2{esh.z, esh.w});
+        const uint32_t u0 = __builtin_bit_cast(uint32_t, half_bits<T>(lo)), u1 = __builtin_bit_cast(uint32_t, half_bits<T>(hi));
+        x0_ = f32x2{Half<T>::lo(u0), Half<T>::hi(u0)}; x1_ = f32x2{Half<T>::lo(u1), Half<T>::hi(u1)};
+      };
+      auto tr_term = [&](const f32x2& x0_, const f32x2& x1_, int slot) {
+        const uint2 tv = fb_preact4<T>(x0_, x1_, ts, tb);
+        const bool mine = (lp >> 2) == slot;
+        ta = mma16<T>(make_uint4(mine ? trw.x : 0u, mine ? trw.y : 0u, 0u, 0u), make_uint4(tv.x, tv.y, 0u, 0u), ta);
+      };
+      if (wave == 0 || wave == 3) {   // rows 0..3 / 8..11 of the centre strip
+        const int row0 = wave == 0 ? 0 : 8;
+        const int xb[1] = {fb_plane<1>(min(lq, 2)) + (row0 * FbIn<1>::W + 2 + lp) * 16};
+        f32x4 acc[4];
+        fb_band<T, 1, 1, 4>(smem, xb, w1r, acc);
+        FSEG(4);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int row = row0 + ps;
+          f32x2 x0_, x1_;
+          finish(acc[ps], x0_, x1_);
+          *reinterpret_cast<uint2*>(smem + e2 + row * (FbIn<2>::W * 16)) = fb_preact4<T>(x0_, x1_, cs[1], cb[1]);
+          if (wave == 0 ? ps >= 1 : ps <= 2) *reinterpret_cast<uint2*>(smem + e3 + (row - 1) * (FbIn<3>::W * 16)) = fb_preact4<T>(x0_, x1_, cs[2], cb[2]);
+          if (wave == 0 ? ps >= 2 : ps <= 1) tr_term(x0_, x1_, ps & 1);
+        }
+      } else {                        // rows 4, 5 / 6, 7 and two groups of halo columns (0, 1, 18, 19 of 12 rows: 48 pixels in 3 groups; wave 2's second group is empty)
+        const int row0 = 2 + 2 * wave;
+        const int xb[1] = {fb_plane<1>(min(lq, 2)) + (row0 * FbIn<1>::W + 2 + lp) * 16};
+        int g2a[2], g3a[2], xg[2][1];
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+          const int q = 16 * (2 * (wave - 1) + gi) + lp;
+          const bool ok = q < 4 * FbIn<2>::H;
+          const int qq = ok ? q : 0, ry = qq >> 2, cc = qq & 3, rx = cc < 2 ? cc : cc + 16;
+          const bool in3 = ok && (unsigned)(ry - 1) < (unsigned)FbIn<3>::H && (unsigned)(rx - 1) < (unsigned)FbIn<3>::W;
+          xg[gi][0] = fb_plane<1>(min(lq, 2)) + (ry * FbIn<1>::W + rx) * 16;
+          g2a[gi] = ok ? fb_plane<2>(pl) + half + (ry * FbIn<2>::W + rx) * 16 : FB_DUMP;
+          g3a[gi] = in3 ? fb_plane<3>(pl) + half + ((ry - 1) * FbIn<3>::W + rx - 1) * 16 : FB_DUMP;
+        }
+        f32x4 acc[2], ga[2];
+        fb_band<T, 1, 1, 2>(smem, xb, w1r, acc);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) ga[gi] = fb_group<T, 1, 1>(smem, xg[gi], w1r);
+        FSEG(4);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int row = row0 + ps;
+          f32x2 x0_, x1_;
+          finish(acc[ps], x0_, x1_);
+          *reinterpret_cast<uint2*>(smem + e2 + row * (FbIn<2>::W * 16)) = fb_preact4<T>(x0_, x1_, cs[1], cb[1]);
+          *reinterpret_cast<uint2*>(smem + e3 + (row - 1) * (FbIn<3>::W * 16)) = fb_preact4<T>(x0_, x1_, cs[2], cb[2]);
+          tr_term(x0_, x1_, ps);
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+          f32x2 x0_, x1_;
+          finish(ga[gi], x0_, x1_);
+          *reinterpret_cast<uint2*>(smem + g2a[gi]) = fb_preact4<T>(x0_, x1_, cs[1], cb[1]);
+          *reinterpret_cast<uint2*>(smem + g3a[gi]) = fb_preact4<T>(x0_, x1_, cs[2], cb[2]);
+        }
+      }
+      tsum = f32x4{tsum[0] + ta[0], tsum[1] + ta[1], tsum[2] + ta[2], 0.f};
+    }
+    FSEG(9);
+    __syncthreads();   // B3
+    FSEG(5);
+    // ---- P3: layer 2 ----
+    {
+      FB_FRESH_IDS();
+      const float4 c3s = fb_c4(smem, FB_CPS, 216 + 40 + 4 * lq), c3b = fb_c4(smem, FB_CPB, 216 + 40 + 4 * lq);
+      const float4 ts = fb_c4(smem, FB_CTS, 40 + 4 * lq), tb = fb_c4(smem, FB_CTB, 40 + 4 * lq);
+      const float4 esc = fb_c4(smem, FB_CES, 32 + 4 * lq), esh = fb_c4(smem, FB_CEB, 32 + 4 * lq);
+      const uint2 trw = *reinterpret_cast<const uint2*>(smem + FB_TRW + ((40 + 4 * lq) >> 3) * 64 + (lp & 3) * 16 + ((40 + 4 * lq) & 7) * 2);
+      const int half = (lq & 1) * 8, pl = 5 + (lq >> 1);
+      const int e3 = fb_plane<3>(pl) + half + (1 + lp) * 16;
+      f32x4 ta = zero4;
+      auto finish = [&](const f32x4& acc, f32x2& x0_, f32x2& x1_) {
+        const f32x2 lo = __builtin_elementwise_fma(f32x2{acc[0], acc[1]}, f32x2{esc.x, esc.y}, f32x2{esh.x, esh.y});
+        const f32x2 hi = __builtin_elementwise_fma(f32x2{acc[2], acc[3]}, f32x2{esc.z, esc.w}, f32x2{esh.z, esh.w});
+        const uint32_t u0 = __builtin_bit_cast(uint32_t, half_bits<T>(lo)), u1 = __builtin_bit_cast(uint32_t, half_bits<T>(hi));
+        x0_ = f32x2{Half<T>::lo(u0), Half<T>::hi(u0)}; x1_ = f32x2{Half<T>::lo(u1), Half<T>::hi(u1)};
+      };
+      auto tr_term = [&](const f32x2& x0_, const f32x2& x1_, int slot) {
+        const uint2 tv = fb_preact4<T>(x0_, x1_, ts, tb);
+        const bool mine = (lp >> 2) == slot;
+        ta = mma16<T>(make_uint4(mine ? trw.x : 0u, mine ? trw.y : 0u, 0u, 0u), make_uint4(tv.x, tv.y, 0u, 0u), ta);
+      };
+      if (wave == 0 || wave == 3) {   // rows 0..2 / 7..9
+        const int row0 = wave == 0 ? 0 : 7;
+        int xb[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) xb[k] = fb_plane<2>(min(4 * k + lq, 4)) + (row0 * FbIn<2>::W + 1 + lp) * 16;
+        f32x4 acc[3];
+        fb_band<T, 2, 2, 3>(smem, xb, w2r, acc);
+        FSEG(6);
+#pragma unroll
+        for (int ps = 0; ps < 3; ++ps) {
+          f32x2 x0_, x1_;
+          finish(acc[ps], x0_, x1_);
+          *reinterpret_cast<uint2*>(smem + e3 + (row0 + ps) * (FbIn<3>::W * 16)) = fb_preact4<T>(x0_, x1_, c3s, c3b);
+          if (wave == 0 ? ps >= 1 : ps <= 1) tr_term(x0_, x1_, wave == 0 ? ps - 1 : ps);
+        }
+      } else {                        // rows 3, 4 / 5, 6 and one group of halo columns (0, 17 of 10 rows: 20 pixels in 2 groups)
+        const int row0 = 1 + 2 * wave;
+        int xb[2], xg[2];
+        const int q = 16 * (wave - 1) + lp;
+        const bool ok = q < 2 * FbIn<3>::H;
+        const int qq = ok ? q : 0, ry = qq >> 1, rx = (qq & 1) ? 17 : 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          xb[k] = fb_plane<2>(min(4 * k + lq, 4)) + (row0 * FbIn<2>::W + 1 + lp) * 16;
+          xg[k] = fb_plane<2>(min(4 * k + lq, 4)) + (ry * FbIn<2>::W + rx) * 16;
+        }
+        const int g3a = ok ? fb_plane<3>(pl) + half + (ry * FbIn<3>::W + rx) * 16 : FB_DUMP;
+        f32x4 acc[2];
+        fb_band<T, 2, 2, 2>(smem, xb, w2r, acc);
+        const f32x4 ga = fb_group<T, 2, 2>(smem, xg, w2r);
+        FSEG(6);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          f32x2 x0_, x1_;
+          finish(acc[ps], x0_, x1_);
+          *reinterpret_cast<uint2*>(smem + e3 + (row0 + ps) * (FbIn<3>::W * 16)) = fb_preact4<T>(x0_, x1_, c3s, c3b);
+          tr_term(x0_, x1_, ps);
+        }
+        f32x2 x0_, x1_;
+        finish(ga, x0_, x1_);
+        *reinterpret_cast<uint2*>(smem + g3a) = fb_preact4<T>(x0_, x1_, c3s, c3b);
+      }
+      tsum = f32x4{tsum[0] + ta[0], tsum[1] + ta[1], tsum[2] + ta[2], 0.f};
+    }
+    FSEG(10);
+    __syncthreads();   // B4
+    FSEG(7);
+    // ---- P4: layer 3, transition, sigmoid ----
+    {
+      FB_FRESH_IDS();
+      const int wlane = (lq * 9 * 16 + lp) * 16;
+      const int row0 = 2 * wave;
+      int xb[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) xb[k] = fb_plane<3>(min(4 * k + lq, 6)) + (row0 * FbIn<3>::W + lp) * 16;
+      f32x4 acc[2];
+      fb_band_wlds<T, 3, 2, 2>(smem, xb, FB_W3 + wlane, acc);
+      FSEG(8);
+      const float4 ts = fb_c4(smem, FB_CTS, 56 + 4 * lq), tb = fb_c4(smem, FB_CTB, 56 + 4 * lq);
+      const float4 esc = fb_c4(smem, FB_CES, 48 + 4 * lq), esh = fb_c4(smem, FB_CEB, 48 + 4 * lq);
+      const uint2 trw = *reinterpret_cast<const uint2*>(smem + FB_TRW + ((56 + 4 * lq) >> 3) * 64 + (lp & 3) * 16 + ((56 + 4 * lq) & 7) * 2);
+      const float4 tes = fb_c4(smem, FB_CTE, 0), teb = fb_c4(smem, FB_CTE, 4);
+      f32x4 ta = zero4;
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const f32x2 lo = __builtin_elementwise_fma(f32x2{acc[ps][0], acc[ps][1]}, f32x2{esc.x, esc.y}, f32x2{esh.x, esh.y});
+        const f32x2 hi = __builtin_elementwise_fma(f32x2{acc[ps][2], acc[ps][3]}, f32x2{esc.z, esc.w}, f32x2{esh.z, esh.w});
+        const uint32_t u0 = __builtin_bit_cast(uint32_t, half_bits<T>(lo)), u1 = __builtin_bit_cast(uint32_t, half_bits<T>(hi));
+        const uint2 tv = fb_preact4<T>(f32x2{Half<T>::lo(u0), Half<T>::hi(u0)}, f32x2{Half<T>::lo(u1), Half<T>::hi(u1)}, ts, tb);
+        const bool mine = (lp >> 2) == ps;
+        ta = mma16<T>(make_uint4(mine ? trw.x : 0u, mine ? trw.y : 0u, 0u, 0u), make_uint4(tv.x, tv.y, 0u, 0u), ta);
+      }
+      if (lq < 2) {   // lane (lq, lp): pixel (row 2 wave + lq, column lp) of the tile
+        float* const ob = a.y + (size_t)img * 3 * hw + ((size_t)(y0 + row0) * a.W + x0);   // wave-uniform
+        const unsigned po = (unsigned)lq * (unsigned)a.W + (unsigned)lp;
+        const float v0 = fmaf(tsum[0] + ta[0], tes.x, teb.x), v1 = fmaf(tsum[1] + ta[1], tes.y, teb.y), v2 = fmaf(tsum[2] + ta[2], tes.z, teb.z);
+        ob[po] = sigmoidf(v0);
+        ob[hw + po] = sigmoidf(v1);
+        ob[2 * hw + po] = sigmoidf(v2);
+      }
+    }
+    FSEG(11);
+  };
+
   for (; item < run_end; ++item) {
     const int y0 = ty * FB_TH, x0 = tx * FB_TW;
     FSEG(-1);
+    if (y0 >= 8 && y0 + 12 <= a.H && x0 >= 16 && x0 + 20 <= a.W) {   // the whole base patch (and its low-resolution taps) inside: no clamp, no padding
+      tile_interior(img, y0, x0);
+      if (++tx == a.tiles_x) { tx = 0; if (++ty == a.tiles_y) { ty = 0; ++img; } }
+      continue;
+    }
 
     // =========================== P0: the base patch, 24 x 16 ===========================
     float fbase[2][3];

@@ -24,6 +24,7 @@ import warnings
 from collections import OrderedDict
 
 import numpy as np
+from . import launch
 import torch
 from PIL import Image
 from torch.utils.data import DataLoader, Dataset
@@ -296,14 +297,55 @@ def init_distributed(backend=None):
     if world <= 1 or (dist.is_available() and dist.is_initialized()):
         return rank, world, local
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # (a launcher -- torchrun, mdie_amd.launch.self_launch -- always sets MASTER_PORT, the latter to a port the kernel has just handed out;
+    #  29500 is only the last resort of a hand-started rank: it is where every torch job on a shared host looks first)
     os.environ.setdefault("MASTER_PORT", "29500")
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
         bind_to_gpu_numa(local)
-        dist.init_process_group(backend or "nccl", device_id=torch.device("cuda", local))
+        launch.init_or_exit(dist.init_process_group, backend or "nccl", device_id=torch.device("cuda", local))
     else:
-        dist.init_process_group(backend or "gloo")
+        launch.init_or_exit(dist.init_process_group, backend or "gloo")
+    global _OWNS_PROCESS_GROUP
+    _OWNS_PROCESS_GROUP = True
     return rank, world, local
+
+
+_OWNS_PROCESS_GROUP = False      # init_distributed() created the default group: run() then also takes it down, in the order below
+
+
+def shutdown_distributed(captured=None, buckets=None, destroy=True):
+    """THE teardown order of a data-parallel process; every path that owns a process group ends with it (host.run, bench.py,
+    tools/bench_train.py, tests/ddp_one_rank_gpu.py).
+
+    What RCCL (= NCCL's rules) and torch require, and what round 5 violated: a hipGraph that captured collectives RETAINS resources of
+    the communicator (RCCL attaches a user object to the graph -- hipGraphRetainUserObject -- whose destructor, run by the HIP runtime
+    on a thread of its own when the graph and its executables are finally released, hands the captured plans back to the communicator),
+    and an async Work handle keeps events of the communication stream.  The communicator must therefore outlive every such graph and
+    handle.  Round 5's one abort (`Fatal Python error: Aborted`, main thread inside destroy_process_group(), a second thread with no
+    Python frame: gpurun_out/r05a/poison.log) came out of a process that had captured RCCL all-reduces into CapturedStep graphs and went
+    into the teardown relying on `del cap` alone -- no collection of reference cycles, a synchronize BEFORE the last graphs were dropped but none
+    after -- while the product path (Model.train under torchrun) kept its graphs until interpreter exit and never destroyed the group at all.
+    The order, made explicit:
+      1. drop every CapturedStep (the graphs with the captured collectives and their private memory pools);
+      2. close the GradBuckets (hooks off; finish() / exchange() leave no Work handle behind);
+      3. gc.collect(): a graph held by a reference cycle is otherwise alive until some later collection;
+      4. torch.cuda.synchronize(): every replay and collective has finished, the runtime has nothing in flight to defer a graph's release for;
+      5. only then destroy_process_group().
+    `captured`: a dict / list of CapturedStep (cleared in place); `buckets`: a GradBuckets or None.  Safe to call without a process group."""
+    import gc
+    import torch.distributed as dist
+    if captured is not None:
+        captured.clear()
+    if buckets is not None:
+        buckets.close()
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if destroy and dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+        global _OWNS_PROCESS_GROUP
+        _OWNS_PROCESS_GROUP = False
 
 
 def make_dataloader(dataset, args):
@@ -504,30 +546,39 @@ class Model:
         # Data parallel: the bucketed all-reduce ALWAYS overlaps backward (models/model.py:164-166 is the step being sharded).  In a captured
         # step the collectives are branches of the graph (train.CapturedStep, `buckets=`); in an eager step they are issued by the buckets'
         # hooks during backward.  There is no "exchange after a finished backward" on this path (round 4 ran five collectives behind the
-        # replay).  Which form a distributed step takes (MDIE_DDP_CAPTURE=auto): measured on a one-rank RCCL group, bf16, B = 8
-        # (profiles/r05c_ddp_forms.txt) -- 512x512: eager + hooks 8.69 ms, collectives inside the graph 8.89 (each of the five fork-joins
-        # costs the replay ~80 us); 256x256: eager 6.97 (host-bound), inside the graph 4.22.  So: captured while the step is launch-bound
-        # (fewer than 8 x 384 x 384 input pixels), eager + hooks above.  MDIE_DDP_CAPTURE=1 / 0 forces one form for every size.
+        # replay).  Which form a distributed step takes: MDIE_DDP_CAPTURE = 0 (default) | 1 | auto.
+        #   0     eager steps, the collectives issued by the buckets' hooks during backward: the DEFAULT under world > 1, because it is the only
+        #         form that has ever run on more than one rank (two-rank gloo tests; the 1-rank RCCL test cannot see a wrong order between the
+        #         gradient kernels, the communication stream's fork / join and the captured Adam step: an in-place all-reduce over one rank is
+        #         the identity).
+        #   1     every step captured, the collectives as branches of the graph (train.CapturedStep, `buckets=`).
+        #   auto  captured below 8 x 384 x 384 input pixels, eager above.  That threshold was derived on ONE rank (profiles/r05c_ddp_forms.txt,
+        #         bf16, B = 8: 512x512 eager + hooks 8.69 ms against 8.89 in the graph -- each of the five fork-joins costs a replay ~80 us;
+        #         256x256 6.97 host-bound against 4.22), i.e. from host and launch overheads only: whether the overlap hides any exchange time
+        #         is UNMEASURED until a multi-GPU box runs tools/bench_train.py --gpus N.
         n_buckets = int(os.environ.get("MDIE_DDP_BUCKETS", "4"))
         buckets = T.GradBuckets(self.network.parameters(), n_buckets=n_buckets) if distributed else None
-        ddp_mode = os.environ.get("MDIE_DDP_CAPTURE", "auto")
+        ddp_mode = os.environ.get("MDIE_DDP_CAPTURE", "0")
         if buckets is not None:
             small = (lambda x: x.shape[0] * x.shape[2] * x.shape[3] < 8 * 384 * 384)
             graph_ok = want_graph
             want_graph = (lambda x: graph_ok(x) and (ddp_mode == "1" or (ddp_mode == "auto" and small(x))))
-        ddp_capture = True
-        self.exchange_mode = None if buckets is None else "overlapped: inside the captured step (launch-bound sizes), grad hooks on eager steps"
+        self.exchange_mode = None if buckets is None else {"0": "hooks (eager steps, overlapped with backward)", "1": "in-graph (captured steps)",
+                                                           "auto": "in-graph below 8x384x384 input pixels, hooks above"}.get(ddp_mode, ddp_mode)
+        self.n_buckets = None if buckets is None else len(buckets.buckets)
         best = float("inf")
         self.history = []
         try:
             for epoch in range(n_epoch):
-                best = self._train_epoch(epoch, n_epoch, lr, losses, scaler, opt, captured, buckets, want_graph, whole, ddp_capture, distributed, best)
+                best = self._train_epoch(epoch, n_epoch, lr, losses, scaler, opt, captured, buckets, want_graph, whole, distributed, best)
         finally:
-            if buckets is not None:
-                buckets.close()      # hooks off and the training Functions stop writing gradients into this instance's buckets -- also when a step raised
+            # graphs first (under world > 1 they hold captured collectives of the communicator), then the buckets (hooks off, the training
+            # Functions stop writing into this instance's slices), collected and synchronised -- also when a step raised; the process group
+            # itself is host.run's to destroy (shutdown_distributed, the same order)
+            shutdown_distributed(captured, buckets, destroy=False)
         return self.history
 
-    def _train_epoch(self, epoch, n_epoch, lr, losses, scaler, opt, captured, buckets, want_graph, whole, ddp_capture, distributed, best):
+    def _train_epoch(self, epoch, n_epoch, lr, losses, scaler, opt, captured, buckets, want_graph, whole, distributed, best):
         import torch.distributed as dist
         from . import train as T
         t0 = time.time()
@@ -537,7 +588,7 @@ class Model:
         sums, n = {}, 0
         for inputs, targets in self.dataloader:
             x, y = self._to_device(inputs), self._to_device(targets)
-            if want_graph(x) and (buckets is None or ddp_capture):
+            if want_graph(x):
                 key = (tuple(x.shape), tuple(y.shape))
                 if key not in captured:
                     captured[key] = T.CapturedStep(self.network, losses, opt if whole else None, x, y,
@@ -704,6 +755,8 @@ def run(config):
             log.generate_plots()
     finally:
         log.close()
+        if _OWNS_PROCESS_GROUP:      # this process joined the group in Model.__init__ (torchrun / self_launch): take it down, in order
+            shutdown_distributed()
     return harness
 
 

@@ -41,24 +41,47 @@ def child_env(rank, world, port, base=None):
     return env
 
 
-def self_launch(argv, world, grace_s=20.0):
+def init_or_exit(init, *args, **kwargs):
+    """`init(*args, **kwargs)` (torch.distributed.init_process_group) for a self-launched rank: when the rendezvous port handed out by
+    free_port() was taken by somebody else before rank 0 could bind it, exit with EADDRINUSE_EXIT so that the parent retries on a fresh
+    port (self_launch); every other error propagates."""
+    try:
+        return init(*args, **kwargs)
+    except Exception as e:      # torch raises DistNetworkError (a RuntimeError) with the errno's text
+        text = str(e).lower()
+        if os.environ.get("MDIE_SELF_LAUNCHED") == "1" and ("eaddrinuse" in text or "address already in use" in text):
+            sys.exit(EADDRINUSE_EXIT)
+        raise
+
+
+EADDRINUSE_EXIT = 98      # a rank whose rendezvous port was taken between free_port() and its bind exits with this code (errno EADDRINUSE)
+
+
+def self_launch(argv, world, grace_s=20.0, kill_after_s=10.0, _retried=False):
     """Run `sys.executable argv...` as `world` ranks; returns the worst exit code (a signal death counts as 128 + signal).
-    When one rank fails the others get `grace_s` seconds to notice (a broken collective usually ends them) and are then
-    terminated -- each by its own PID."""
+    When one rank fails the others get `grace_s` seconds to notice (a broken collective usually ends them), are then terminated
+    -- each by its own PID -- and, if a rank ignores that for `kill_after_s` more seconds (blocked inside a collective or behind a hung
+    kernel, SIGTERM is not delivered to Python), killed; the return code is then non-zero whatever the survivors report.
+    free_port() closes its socket before the children bind the port, so another job can take it in between: when EVERY rank that failed
+    did so with EADDRINUSE_EXIT (entry points map the rendezvous error to it) the launch is repeated once on a fresh port."""
     port = free_port()
     procs = [subprocess.Popen([sys.executable] + list(argv), env=child_env(r, world, port)) for r in range(world)]
-    worst, failed_at = 0, None
+    worst, failed_at, terminated_at, forced = 0, None, None, False
     try:
         while any(p.poll() is None for p in procs):
-            for p in procs:
-                rc = p.poll()
-                if rc is not None and rc != 0 and failed_at is None:
-                    failed_at = time.monotonic()
-            if failed_at is not None and time.monotonic() - failed_at > grace_s:
+            now = time.monotonic()
+            if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+                failed_at = now
+            if failed_at is not None and terminated_at is None and now - failed_at > grace_s:
                 for p in procs:
                     if p.poll() is None:
                         p.terminate()
-                failed_at = time.monotonic() + 1e9     # terminate once; the loop ends when they are gone
+                terminated_at, forced = now, True
+            if terminated_at is not None and now - terminated_at > kill_after_s:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                terminated_at = now + 1e9      # (SIGKILL cannot be ignored: the loop ends when the kernel has reaped them)
             time.sleep(0.05)
     except KeyboardInterrupt:
         for p in procs:
@@ -67,7 +90,10 @@ def self_launch(argv, world, grace_s=20.0):
         for p in procs:
             p.wait()
         return 130
-    for p in procs:
-        rc = p.returncode
+    codes = [p.returncode for p in procs]
+    failed = [rc for rc in codes if rc != 0 and not (forced and rc < 0)]      # (ranks this function signalled are not the cause)
+    if failed and not _retried and all(rc == EADDRINUSE_EXIT for rc in failed):
+        return self_launch(argv, world, grace_s, kill_after_s, _retried=True)
+    for rc in codes:
         worst = max(worst, rc if rc >= 0 else 128 - rc)
-    return worst
+    return max(worst, 1) if forced else worst

@@ -971,6 +971,9 @@ def forward_train(net, x, precision="fp32", dropout_p=0.2):
 
 
 # ---- one training step as a hipGraph (models/model.py:154-172: zero_grad, forward, loss, backward, optimizer step) -------------------
+_CAPTURING_STEP = None     # the CapturedStep whose graph is being recorded right now (GradBuckets._launch checks the stream against it)
+
+
 class CapturedStep:
     """forward + loss + backward (+ the optimizer step) of ONE batch shape, captured once and replayed.
 
@@ -1045,10 +1048,15 @@ class CapturedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         net.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.values = fwd_bwd()
-            if optimizer is not None:
-                optimizer.step()
+        global _CAPTURING_STEP
+        _CAPTURING_STEP = self
+        try:
+            with torch.cuda.graph(self.graph):
+                self.values = fwd_bwd()
+                if optimizer is not None:
+                    optimizer.step()
+        finally:
+            _CAPTURING_STEP = None
         self.grads = [p.grad for p in self.params]     # the graph's own gradient tensors (rewritten by every replay)
 
     def __call__(self, x, t):
@@ -1190,6 +1198,11 @@ class GradBuckets:
         if self.trace is not None:
             self.trace.append(("launch", bi))
         flat = self.flat[bi]
+        if flat.is_cuda and torch.cuda.is_current_stream_capturing() != (_CAPTURING_STEP is not None):
+            # a hook that fires on a thread / stream other than the one CapturedStep is capturing on would issue its collective OUTSIDE the
+            # graph (or an eager step would record one into somebody's capture): refuse loudly rather than exchange stale gradients
+            raise RuntimeError("GradBuckets: a bucket's all-reduce was about to be issued on a stream whose capture state does not match the step "
+                               "being built (CapturedStep capturing: %s, current stream capturing: %s)" % (_CAPTURING_STEP is not None, torch.cuda.is_current_stream_capturing()))
         side = _WGRAD_SIDE.get(flat.device) if (flat.is_cuda and _wgrad_side_this_step and WGRAD_STREAM) else None
         if side is not None:          # dW kernels of this bucket may be on the side stream: order the collective behind both streams
             side.wait_stream(torch.cuda.current_stream(flat.device))

@@ -1,10 +1,20 @@
 #!/usr/bin/env python3
 """The one-rank RCCL checks of tests/test_gpu_parity.py::test_ddp_one_rank_nccl_gradients_live_in_the_buckets, in a process of their own.
 
-Not collected by pytest (no test_ prefix).  The test runs this file as a child process and passes when it prints DDP-ONE-RANK-OK:
-every assertion sits in front of that line, the process-group teardown behind it.  Round 5 saw `destroy_process_group()` abort the
-interpreter once (no message from c10d, RCCL or HIP; gpurun_out/r05a/poison.log; not reproduced in four more runs) -- inside the pytest
-process that takes the whole GPU suite down with it, in a child it is a line in the test's output."""
+Not collected by pytest (no test_ prefix).  The test runs this file as a child process and passes only when the child prints
+DDP-ONE-RANK-OK (every assertion sits in front of that line), then DDP-TEARDOWN-OK, and exits with code 0.
+
+Why a child, and what the teardown must look like.  Round 5 saw `destroy_process_group()` abort the interpreter once (SIGABRT: main
+thread inside torch/distributed/distributed_c10d.py destroy_process_group, a second thread with no Python frame, no text from c10d, RCCL
+or HIP: gpurun_out/r05a/poison.log; not reproduced in four more runs).  What was alive in that process: it had captured RCCL all-reduces
+into hipGraphs (CapturedStep(buckets=...), the section below) on the communicator being destroyed.  RCCL attaches a user object to such a
+graph (hipGraphRetainUserObject) whose destructor -- run by the HIP runtime on a thread of its own when the graph and its executables
+are finally released -- returns the captured plans to the communicator: the communicator must outlive every such graph, and "outlive"
+means the release has HAPPENED, not that the last Python reference was dropped.  The test then relied on `del cap` (no collection of
+reference cycles) and synchronised only BEFORE the final section; the product path (Model.train under torchrun) kept its graphs until
+interpreter exit and never destroyed the group.  The ordering rule, now one function used by every owner of a process group
+(mdie_amd.host.shutdown_distributed): drop the CapturedSteps, close the GradBuckets, gc.collect(), torch.cuda.synchronize(), and only
+then destroy_process_group().  A teardown that does not come back clean FAILS the test (round 5 downgraded it to a warning)."""
 import os
 import sys
 
@@ -138,8 +148,8 @@ def main():
         torch.cuda.synchronize()
         print("DDP-ONE-RANK-OK", flush=True)
     finally:
-        torch.cuda.synchronize()
-        dist.destroy_process_group()
+        from mdie_amd import host as H
+        H.shutdown_distributed()      # graphs and buckets of every section above are gone by now; collect, synchronise, THEN destroy
     print("DDP-TEARDOWN-OK", flush=True)
 
 

@@ -338,3 +338,64 @@ def test_self_launch_returns_the_worst_rank_exit_code(tmp_path):
     assert LA.needs_self_launch(2, env={}) and not LA.needs_self_launch(1, env={}) and not LA.needs_self_launch(8, env={"WORLD_SIZE": "8"})
     e = LA.child_env(3, 8, 1234, base={})
     assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_ADDR"], e["MASTER_PORT"]) == ("3", "3", "8", "127.0.0.1", "1234")
+
+
+def test_self_launch_kills_a_rank_that_ignores_sigterm_and_retries_a_taken_port(tmp_path):
+    """(a) one rank fails, the other is stuck where SIGTERM does not reach it (a rank blocked inside a collective behaves like that): after
+    the grace period it is terminated, then KILLED, and the job reports failure instead of hanging; (b) every failed rank reporting
+    EADDRINUSE_EXIT (the rendezvous port was taken between free_port() and the bind) repeats the launch once on a fresh port."""
+    import time
+    sys.path.insert(0, ROOT)
+    from mdie_amd import launch as LA
+    stuck = tmp_path / "stuck.py"
+    stuck.write_text("import os, signal, sys, time\n"
+                     "if os.environ['RANK'] == '1':\n    sys.exit(5)\n"
+                     "signal.signal(signal.SIGTERM, signal.SIG_IGN)\ntime.sleep(600)\n")
+    t0 = time.monotonic()
+    rc = LA.self_launch([str(stuck)], 2, grace_s=0.5, kill_after_s=0.5)
+    assert rc != 0 and time.monotonic() - t0 < 30
+    marker = tmp_path / "seen"
+    retry = tmp_path / "retry.py"
+    retry.write_text("import os, sys\n"
+                     f"m = {str(marker)!r} + os.environ['RANK']\n"
+                     "if not os.path.exists(m):\n    open(m, 'w').write(os.environ['MASTER_PORT'])\n"
+                     f"    sys.exit({LA.EADDRINUSE_EXIT} if os.environ['RANK'] == '0' else 0)\n"
+                     "sys.exit(0)\n")
+    assert LA.self_launch([str(retry)], 2, grace_s=0.5) == 0
+
+
+def test_bench_train_rehearsal_launches_exchanges_and_tears_down():
+    """`tools/bench_train.py --gpus 2 --rehearse`: the training bench's own launch, rendezvous, GradBuckets exchange (hooks -> bucketed
+    all-reduce -> finish) and host.shutdown_distributed teardown on gloo with a stand-in network -- so that the first multi-GPU run of
+    the training curve cannot fail on argument plumbing (the step itself needs the GPU and is covered by the GPU tests)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_train.py"), "--gpus", "2", "--rehearse", "bf16", "2", "64"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("train[rehearse")]
+    assert len(lines) == 1 and "B=2x2 64x64" in lines[0] and "exchange: hooks, 2 buckets, ranks agree: True" in lines[0] and "teardown: ok" in lines[0], r.stdout
+
+
+def test_shutdown_distributed_order_two_ranks(tmp_path):
+    """host.shutdown_distributed: graphs dropped, buckets closed, collected, synchronised, THEN the group destroyed -- and callable without
+    a group.  Two gloo ranks: afterwards no process group, no gradient sink, the holder of captured steps empty."""
+    import subprocess
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "from mdie_amd import host as H, train as T\n"
+        "H.shutdown_distributed()            # no group: a no-op\n"
+        "dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))\n"
+        "net = torch.nn.Linear(4, 4)\n"
+        "bk = T.GradBuckets(net.parameters(), n_buckets=1)\n"
+        "net(torch.ones(2, 4)).sum().backward(); bk.finish()\n"
+        "held = {'k': object()}\n"
+        "H.shutdown_distributed(held, bk)\n"
+        "assert not dist.is_initialized() and T._GRAD_SINK is None and held == {} and not bk._hooks\n"
+        "print('RANK-OK', os.environ['RANK'])\n")
+    sys.path.insert(0, ROOT)
+    from mdie_amd import launch as LA
+    assert LA.self_launch([str(script)], 2) == 0

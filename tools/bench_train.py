@@ -12,6 +12,11 @@ GEMMs of every convolution; `mdie_cdan_flops`); HBM bytes = 3 x the forward's fu
 per parameter per step (fp32 weight read, gradient write + read, Adam's two moments read + written, weight written)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REHEARSE = "--rehearse" in sys.argv      # the same launch / rendezvous / exchange / teardown plumbing on gloo with a stub step: no GPU (tests/test_bench_sharding_cpu.py)
+if REHEARSE:
+    sys.argv.remove("--rehearse")
+    os.environ["MDIE_BENCH_TRAIN_REHEARSE"] = "1"
+REHEARSE = REHEARSE or os.environ.get("MDIE_BENCH_TRAIN_REHEARSE") == "1"
 if "--gpus" in sys.argv:      # `tools/bench_train.py --gpus N ...` with no launcher: become the parent of N ranks before anything touches the GPU
     _i = sys.argv.index("--gpus")
     _n = int(sys.argv[_i + 1])
@@ -20,6 +25,43 @@ if "--gpus" in sys.argv:      # `tools/bench_train.py --gpus N ...` with no laun
     if _LA.needs_self_launch(_n):
         sys.exit(_LA.self_launch([os.path.abspath(__file__)] + sys.argv[1:], _n))
 import torch
+
+
+def rehearse():
+    """`tools/bench_train.py --gpus N --rehearse [prec] [B] [S]`: every rank joins a gloo group, runs GradBuckets over a tiny stand-in
+    network for three steps -- hooks, five-bucket all-reduce, finish -- checks that all ranks end with the same averaged gradients, and
+    leaves through host.shutdown_distributed: what can break on argument plumbing, rendezvous or teardown breaks here, without a GPU."""
+    import torch.distributed as dist
+    from mdie_amd import host as H
+    from mdie_amd import train as T
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    prec, B, S = (args + ["bf16", "8", "512"])[0] if args else "bf16", int(args[1]) if len(args) > 1 else 8, int(args[2]) if len(args) > 2 else 512
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 3, 3, padding=1))
+    buckets = T.GradBuckets(net.parameters(), n_buckets=2)
+    try:
+        for i in range(3):
+            torch.manual_seed(100 + rank + 10 * i)
+            net.zero_grad(set_to_none=True)
+            net(torch.rand(2, 3, 16, 16)).square().mean().backward()
+            buckets.finish()
+        flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        same = all(torch.equal(g, gathered[0]) for g in gathered)
+        nb = len(buckets.buckets)
+    finally:
+        H.shutdown_distributed(None, buckets)
+    if rank == 0:
+        print(f"train[rehearse,{prec}] B={B}x{world} {S}x{S}: gloo, stub step | exchange: hooks, {nb} buckets, ranks agree: {same} | teardown: ok", flush=True)
+    sys.exit(0 if same else 1)
+
+
+if REHEARSE:
+    rehearse()
 from models.cdan import CDAN
 from mdie_amd import host as H
 from mdie_amd import lib as L
@@ -40,7 +82,8 @@ if world > 1 or os.environ.get("MDIE_DDP_SINGLE") == "1":
     if "MASTER_PORT" not in os.environ:
         from mdie_amd import launch as _LA2
         os.environ["MASTER_PORT"] = str(_LA2.free_port())
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    from mdie_amd import launch as _LA3
+    _LA3.init_or_exit(dist.init_process_group, "nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 x, t = P.lowlight_batch(100 + rank, B, S, S)
 x, t = x.cuda(), t.cuda()
 losses = H.build_losses({"enabled": True, "terms": [{"name": s.split(":")[0], "weight": float(s.split(":")[1])} for s in spec.split(",")]})
@@ -97,13 +140,17 @@ for mode, comm in variants:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     if buckets is not None:
-        note = f" | exchange: {'overlapped' if comm == 'overlap' else comm}{' (inside the graph)' if mode == 'graph' and comm == 'overlap' else ''}, {len(buckets.buckets)} buckets, {buckets.copies_in} gradient copies into buckets over {n + 3} steps"
-        buckets.close()
+        form = "in-graph" if (mode == "graph" and comm == "overlap") else "hooks" if comm == "overlap" else "after backward (not overlapped)"
+        note = f" | exchange: {form}, {len(buckets.buckets)} buckets, {buckets.copies_in} gradient copies into buckets over {n + 3} steps"
     else:
         note = " | no gradient exchange" if dist is not None else ""
     if rank == 0:
         print(f"train[{prec},{mode}] B={B}x{world} {S}x{S} loss={spec}: {dt*1e3:.2f} ms/step, {B*world/dt:.1f} img/s, loss {l.item():.4f} | "
               f"model: {flops/1e9:.0f} GFLOP, {byts/1e9:.2f} GB per rank-step -> {flops/dt/1e12:.0f} TFLOP/s = {flops/dt/1e12/peak_tf:.3f} of the {prec} MFMA peak, "
               f"{byts/dt/1e9:.0f} GB/s = {byts/dt/8e12:.3f} of 8 TB/s{note}", flush=True)
+    # this variant's graph (captured collectives of the communicator under world > 1) and buckets go BEFORE the next variant and before the
+    # group: host.shutdown_distributed's order
+    cap = step = None
+    H.shutdown_distributed(None, buckets, destroy=False)
 if dist is not None:
-    dist.destroy_process_group()
+    H.shutdown_distributed()
