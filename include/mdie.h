@@ -370,7 +370,10 @@ int mdie_up_add_dense0_fwd(const mdie_up_dense0_desc* d, void* stream);
  * Parameters are exactly the chain's (mdie_up_add_dense0_fwd + three mdie_conv_fwd with mdie_tr_fuse): layer 0's weight in
  * mdie_pack_conv_first_weight's layout, layers 1..3 as mdie_pack_conv_weight packs them (ksize 3, cout_stored 16, cin_stored
  * 8 + 16 l, split 3, gap 5: the base is one 8-channel group), the transition likewise (ksize 1, cin_stored 72); pre_scale / pre_shift
- * by STORED input channel.  Arithmetic is the chain's operation for operation: `y` is bit-identical to it. */
+ * by STORED input channel.  Arithmetic is the chain's operation for operation: `y` is bit-identical to it.
+ * Measured (round 6, B = 32, 256 x 256, bf16): 292-319 us against 235 us for the chain's four launches -- the block removes ~1 GB of HBM traffic per
+ * step and is bound by vector-instruction issue and per-wave latency chains instead (2 waves per SIMD: 218-256 registers, 78 KB of LDS).  The engine
+ * therefore runs the chain by default (MDIE_FWD_BLOCK_TAIL selects this entry point). */
 typedef struct {
   int dtype;
   int B, H, W;                   /* output extent; lo is [B, H/2, W/2, >= 4 channels] */
@@ -445,8 +448,10 @@ enum { /* 1: was MDIE_FWD_FUSED_TAIL (the whole decoder tail as one launch, roun
        MDIE_FWD_YIELD_CU_CONV4 = 32 /* encoder.conv4 with mdie_conv_desc.share_cu = 2 (wins over 16 when both are set) */,
        MDIE_FWD_LATE_DENSE1 = 64    /* the dense1 branch (needed last, by cbam3) starts behind decoder.conv1 instead of behind encoder.conv4: a schedule,
                                        not arithmetic -- bit-identical; another candidate of CdanEngine.tune */,
-       MDIE_FWD_CHAIN_TAIL = 128    /* decoder.final_dense as the chain of four launches with the transition folded in (rounds 3-5) where the
-                                       one-launch block (mdie_final_dense_fwd, ABI 27) would run: bit-identical, for A/B runs and tests */
+       MDIE_FWD_BLOCK_TAIL = 128    /* decoder.final_dense as ONE launch (mdie_final_dense_fwd, ABI 27) wherever the folded chain of four launches
+                                       would run with one weight set and no taps: BIT-IDENTICAL to the chain, and slower -- 292-319 us against 235 us at
+                                       B = 32, 256x256, bf16 (round 6: instruction issue and per-wave latency chains, profiles/r06*_final_block_*) --
+                                       so it is opt-in: A/B runs, tests, and the starting point of whoever takes the block's VALU work down further */
        /* 8: was MDIE_FWD_FUSED_CBAM3 (cbam3's last pass fused into decoder.conv4, round 4): 68 us against 41 + 27, removed in round 5 */ };
 
 enum { MDIE_K_LAYOUT = 0, MDIE_K_CONV3 = 1, MDIE_K_CONV1 = 2, MDIE_K_CBAM_POOL = 3, MDIE_K_CBAM_GATE = 4,

@@ -832,9 +832,10 @@ static int forward_impl(const mdie_cdan_fwd_desc* d, hipStream_t stream) {
 #ifndef EXP_FULL_BASE   // (A/B builds only: the base as a whole 16-byte group)
     if (fold_tr && t4.C == 8) { t4.st = 4; half_base = true; }
 #endif
-    // ONE launch for the whole block (csrc/final_block.hip, ABI 27) wherever the folded chain would run with one weight set and nobody
-    // asks for the base tensor (taps): growth maps in LDS, halo rings recomputed, y bit-identical to the chain's
-    const bool one_launch = fold_tr && !(d->flags & MDIE_FWD_CHAIN_TAIL) && !d->taps && !c.delta;
+    // ONE launch for the whole block (csrc/final_block.hip, ABI 27; MDIE_FWD_BLOCK_TAIL) wherever the folded chain would run with one weight set
+    // and nobody asks for the base tensor (taps): growth maps in LDS, halo rings recomputed, y bit-identical to the chain's.  OPT-IN: measured
+    // 292-319 us against the chain's 235 us at B = 32, 256x256, bf16 (round 6; profiles/r06*_final_block_*, LEDGER round 6)
+    const bool one_launch = fold_tr && (d->flags & MDIE_FWD_BLOCK_TAIL) && !d->taps && !c.delta;
     if (one_launch) {
       mdie_final_dense_desc f{};
       f.dtype = d->dtype; f.B = B; f.H = H; f.W = W;

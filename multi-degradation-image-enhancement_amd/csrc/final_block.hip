@@ -67,8 +67,8 @@ constexpr int FB_CES = FB_CTB + 72 * 4;                     // float [4][16] + [
 constexpr int FB_CEB = FB_CES + 4 * 16 * 4;
 constexpr int FB_CTE = FB_CEB + 4 * 16 * 4;                 // float [4] + [4]: the transition's epilogue
 constexpr int FB_TRW = FB_CTE + 32;                         // rows 0..3 of the transition's weights: [9 K groups (8 stored channels)][4 rows][16 B]
-constexpr int FB_DUMP = FB_TRW + 9 * 64;                    // 16 bytes nobody reads: where a lane writes when its pixel lies outside a consumer's region
-constexpr int FB_LDS = FB_DUMP + 64;
+constexpr int FB_DUMP = FB_TRW + 9 * 64;                    // 8 bytes per lane nobody reads: where a lane writes when its pixel lies outside a consumer's region
+constexpr int FB_LDS = FB_DUMP + 64 * 8;                    // (ONE shared slot made every such write a 64-way bank conflict: round 6, 308 us)
 static_assert(2 * FbIn<3>::PLANE <= 2 * FbIn<1>::PLANE, "g2's planes must fit A_1's g0 planes");
 static_assert(FB_LDS <= 80 * 1024, "two workgroups per CU");
 
@@ -325,29 +325,37 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
   //     the halo rows above / below go to waves 0 / 3, the halo-column groups to waves 1 / 2;
   //   * a pixel outside a consumer's region is written to a dump slot (one select) instead of branched around.
   // ===================================================================================================================
+  // (Requesting the NEXT tile's base inputs at the start of layer 3 was built and measured: 292 -> 308 us.  Issuing the 14 scattered 8-byte / 4-byte
+  //  loads costs the two waves with two patch pixels ~1.2 k cycles wherever it is placed -- the vector memory path, not the wait, is what the
+  //  base phase pays for: profiles/r06f_final_block_v2_stamps.txt.)
+  auto issue_base_loads = [&](const int img, const int y0, const int x0, uint2 (&ptap)[2][4], float (&pxin)[2][3]) {
+    const int tid = tid_;      // (NOT laundered: a thread's patch pixel and its tap offsets are tile-invariant and meant to be hoisted)
+    const unsigned ls = a.lo_stride;
+    const char* const lb = a.lo + ((size_t)(img * Hl + ((y0 - 4) >> 1)) * Wl + ((x0 - 4) >> 1)) * ls;   // scalar: tap (0, 0) of patch pixel (1, 1)
+    const float* const xb = a.x + (size_t)img * 3 * hw + (size_t)(y0 - 4) * a.W + (x0 - 4);             // scalar: patch pixel (0, 0)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      if (it == 0 || tid < FB_RBW * FB_RBH - FB_THREADS) {
+        const int p = tid + it * FB_THREADS, py = p / FB_RBW, px = p - py * FB_RBW;
+        const int lo_off = (((py - 1) >> 1) * Wl + ((px - 1) >> 1)) * (int)ls;     // (may be negative: the patch starts one low-resolution pixel before lb)
+        const char* const q = lb + lo_off;
+        ptap[it][0] = *reinterpret_cast<const uint2*>(q); ptap[it][1] = *reinterpret_cast<const uint2*>(q + ls);
+        ptap[it][2] = *reinterpret_cast<const uint2*>(q + (size_t)Wl * ls); ptap[it][3] = *reinterpret_cast<const uint2*>(q + (size_t)Wl * ls + ls);
+        const float* const xq = xb + py * a.W + px;
+        pxin[it][0] = xq[0]; pxin[it][1] = xq[hw]; pxin[it][2] = xq[2 * hw];
+      }
+    }
+  };
   auto tile_interior = [&](const int img, const int y0, const int x0) {
     float fbase[2][3];
     f32x4 tsum = zero4;          // lanes (lq < 2, lp): transition outputs 0..2 of pixel (row 2 wave + lq, column lp), summed over the segments so far
     // ---- P0 ----
     {
-      const int tid = tid_;      // (NOT laundered: a thread's patch pixel, its tap offsets and LDS slots are tile-invariant and meant to be hoisted)
-      const unsigned ls = a.lo_stride;
-      const char* const lb = a.lo + ((size_t)(img * Hl + ((y0 - 4) >> 1)) * Wl + ((x0 - 4) >> 1)) * ls;   // scalar: tap (0, 0) of patch pixel (1, 1)
-      const float* const xb = a.x + (size_t)img * 3 * hw + (size_t)(y0 - 4) * a.W + (x0 - 4);             // scalar: patch pixel (0, 0)
-      uint2 tap[2][4];
-      float xin[2][3];
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        if (it == 0 || tid < FB_RBW * FB_RBH - FB_THREADS) {
-          const int p = tid + it * FB_THREADS, py = p / FB_RBW, px = p - py * FB_RBW;
-          const int lo_off = (((py - 1) >> 1) * Wl + ((px - 1) >> 1)) * (int)ls;     // (may be negative: the patch starts one low-resolution pixel before lb)
-          const char* const q = lb + lo_off;
-          tap[it][0] = *reinterpret_cast<const uint2*>(q); tap[it][1] = *reinterpret_cast<const uint2*>(q + ls);
-          tap[it][2] = *reinterpret_cast<const uint2*>(q + (size_t)Wl * ls); tap[it][3] = *reinterpret_cast<const uint2*>(q + (size_t)Wl * ls + ls);
-          const float* const xq = xb + py * a.W + px;
-          xin[it][0] = xq[0]; xin[it][1] = xq[hw]; xin[it][2] = xq[2 * hw];
-        }
-      }
+      const int tid = tid_;      // (NOT laundered: a thread's patch pixel and its LDS slots are tile-invariant and meant to be hoisted)
+      const int dump = FB_DUMP + (tid & 63) * 8;
+      uint2 ptap[2][4];
+      float pxin[2][3];
+      issue_base_loads(img, y0, x0, ptap, pxin);
       const float4 c0s = fb_c3(smem, FB_CPS, 0), c0b = fb_c3(smem, FB_CPB, 0), c1s = fb_c3(smem, FB_CPS, 72), c1b = fb_c3(smem, FB_CPB, 72);
       const float4 c2s = fb_c3(smem, FB_CPS, 144), c2b = fb_c3(smem, FB_CPB, 144), cts = fb_c3(smem, FB_CTS, 0), ctb = fb_c3(smem, FB_CTB, 0);
 #pragma unroll
@@ -359,11 +367,11 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
           float f[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const float t0 = c == 0 ? Half<T>::lo(tap[it][0].x) : c == 1 ? Half<T>::hi(tap[it][0].x) : Half<T>::lo(tap[it][0].y);
-            const float t1 = c == 0 ? Half<T>::lo(tap[it][1].x) : c == 1 ? Half<T>::hi(tap[it][1].x) : Half<T>::lo(tap[it][1].y);
-            const float t2 = c == 0 ? Half<T>::lo(tap[it][2].x) : c == 1 ? Half<T>::hi(tap[it][2].x) : Half<T>::lo(tap[it][2].y);
-            const float t3 = c == 0 ? Half<T>::lo(tap[it][3].x) : c == 1 ? Half<T>::hi(tap[it][3].x) : Half<T>::lo(tap[it][3].y);
-            f[c] = hy0 * (wx0 * t0 + wx1 * t1) + hy1 * (wx0 * t2 + wx1 * t3) + xin[it][c];
+            const float t0 = c == 0 ? Half<T>::lo(ptap[it][0].x) : c == 1 ? Half<T>::hi(ptap[it][0].x) : Half<T>::lo(ptap[it][0].y);
+            const float t1 = c == 0 ? Half<T>::lo(ptap[it][1].x) : c == 1 ? Half<T>::hi(ptap[it][1].x) : Half<T>::lo(ptap[it][1].y);
+            const float t2 = c == 0 ? Half<T>::lo(ptap[it][2].x) : c == 1 ? Half<T>::hi(ptap[it][2].x) : Half<T>::lo(ptap[it][2].y);
+            const float t3 = c == 0 ? Half<T>::lo(ptap[it][3].x) : c == 1 ? Half<T>::hi(ptap[it][3].x) : Half<T>::lo(ptap[it][3].y);
+            f[c] = hy0 * (wx0 * t0 + wx1 * t1) + hy1 * (wx0 * t2 + wx1 * t3) + pxin[it][c];
             f[c] = (float)(T)f[c];
             fbase[it][c] = f[c];
           }
@@ -373,9 +381,9 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
           const bool in1 = (unsigned)(py - 1) < (unsigned)FbIn<1>::H && (unsigned)(px - 1) < (unsigned)FbIn<1>::W;
           const bool in2 = (unsigned)(py - 2) < (unsigned)FbIn<2>::H && (unsigned)(px - 2) < (unsigned)FbIn<2>::W;
           const bool in4 = (unsigned)(py - 4) < (unsigned)FB_TH && (unsigned)(px - 4) < (unsigned)FB_TW;
-          *reinterpret_cast<uint2*>(smem + (in1 ? fb_plane<1>(0) + ((py - 1) * FbIn<1>::W + (px - 1)) * 16 : FB_DUMP)) = fb_preact4<T>(x01, x2, c1s, c1b);
-          *reinterpret_cast<uint2*>(smem + (in2 ? fb_plane<2>(0) + ((py - 2) * FbIn<2>::W + (px - 2)) * 16 : FB_DUMP)) = fb_preact4<T>(x01, x2, c2s, c2b);
-          *reinterpret_cast<uint2*>(smem + (in4 ? FB_TRPATCH + ((py - 4) * FB_TW + (px - 4)) * 8 : FB_DUMP)) =
+          *reinterpret_cast<uint2*>(smem + (in1 ? fb_plane<1>(0) + ((py - 1) * FbIn<1>::W + (px - 1)) * 16 : dump)) = fb_preact4<T>(x01, x2, c1s, c1b);
+          *reinterpret_cast<uint2*>(smem + (in2 ? fb_plane<2>(0) + ((py - 2) * FbIn<2>::W + (px - 2)) * 16 : dump)) = fb_preact4<T>(x01, x2, c2s, c2b);
+          *reinterpret_cast<uint2*>(smem + (in4 ? FB_TRPATCH + ((py - 4) * FB_TW + (px - 4)) * 8 : dump)) =
               make_uint2(Half<T>::pack(fmaxf(fmaf(f[0], cts.x, ctb.x), 0.f), fmaxf(fmaf(f[1], cts.y, ctb.y), 0.f)), Half<T>::pack(fmaxf(fmaf(f[2], cts.z, ctb.z), 0.f), 0.f));
         }
       }
@@ -387,13 +395,14 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
     {
       {   // column 0 of A_3 (layer 3 of the previous tile read it until B1)
         const int tid = tid_;
+        const int dump = FB_DUMP + (tid & 63) * 8;
         const float4 c3s = fb_c3(smem, FB_CPS, 216), c3b = fb_c3(smem, FB_CPB, 216);
 #pragma unroll
         for (int it = 0; it < 2; ++it)
           if (it == 0 || tid < FB_RBW * FB_RBH - FB_THREADS) {
             const int p = tid + it * FB_THREADS, py = p / FB_RBW, px = p - py * FB_RBW;
             const bool in3 = (unsigned)(py - 3) < (unsigned)FbIn<3>::H && (unsigned)(px - 3) < (unsigned)FbIn<3>::W;
-            *reinterpret_cast<uint2*>(smem + (in3 ? fb_plane<3>(0) + ((py - 3) * FbIn<3>::W + (px - 3)) * 16 : FB_DUMP)) =
+            *reinterpret_cast<uint2*>(smem + (in3 ? fb_plane<3>(0) + ((py - 3) * FbIn<3>::W + (px - 3)) * 16 : dump)) =
                 fb_preact4<T>(f32x2{fbase[it][0], fbase[it][1]}, f32x2{fbase[it][2], 0.f}, c3s, c3b);
           }
       }
@@ -422,6 +431,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
       // ALL reads of the phase, then all MFMAs, then the epilogues: LDS operations keep their program order (one address space to the
       // compiler), so a unit-by-unit loop paid a full read -> MFMA -> convert -> write latency chain per unit (version 1: ~800 cycles each).
       int vb[5], a1[5], a2[5], a3[5], crow[2];
+      const int dump = FB_DUMP + (tid & 63) * 8;
       const int plane_lane = FB_PATCH + (3 + lp) * 8;
       if (wave == 0 || wave == 3) {
 #pragma unroll
@@ -429,8 +439,8 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
           const int row = wave == 0 ? 4 - u : 9 + u;
           vb[u] = plane_lane + row * (FB_RBW * 8);
           a1[u] = e1 + row * (FbIn<1>::W * 16);
-          a2[u] = u <= 3 ? e2 + (row - 1) * (FbIn<2>::W * 16) : FB_DUMP;
-          a3[u] = u <= 2 ? e3 + (row - 2) * (FbIn<3>::W * 16) : FB_DUMP;
+          a2[u] = u <= 3 ? e2 + (row - 1) * (FbIn<2>::W * 16) : dump;
+          a3[u] = u <= 2 ? e3 + (row - 2) * (FbIn<3>::W * 16) : dump;
           if (u < 2) crow[u] = row - 3;
         }
       } else {
@@ -449,9 +459,9 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
             const bool in2 = ok && (unsigned)(ry - 1) < (unsigned)FbIn<2>::H && (unsigned)(rx - 1) < (unsigned)FbIn<2>::W;
             const bool in3 = ok && (unsigned)(ry - 2) < (unsigned)FbIn<3>::H && (unsigned)(rx - 2) < (unsigned)FbIn<3>::W;
             vb[u] = FB_PATCH + (ry * FB_RBW + rx) * 8;
-            a1[u] = ok ? fb_plane<1>(pl) + half + (ry * FbIn<1>::W + rx) * 16 : FB_DUMP;
-            a2[u] = in2 ? fb_plane<2>(pl) + half + ((ry - 1) * FbIn<2>::W + rx - 1) * 16 : FB_DUMP;
-            a3[u] = in3 ? fb_plane<3>(pl) + half + ((ry - 2) * FbIn<3>::W + rx - 2) * 16 : FB_DUMP;
+            a1[u] = ok ? fb_plane<1>(pl) + half + (ry * FbIn<1>::W + rx) * 16 : dump;
+            a2[u] = in2 ? fb_plane<2>(pl) + half + ((ry - 1) * FbIn<2>::W + rx - 1) * 16 : dump;
+            a3[u] = in3 ? fb_plane<3>(pl) + half + ((ry - 2) * FbIn<3>::W + rx - 2) * 16 : dump;
           }
         }
       }
@@ -528,6 +538,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
         const int row0 = 2 + 2 * wave;
         const int xb[1] = {fb_plane<1>(min(lq, 2)) + (row0 * FbIn<1>::W + 2 + lp) * 16};
         int g2a[2], g3a[2], xg[2][1];
+        const int dump = FB_DUMP + (tid & 63) * 8;
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
           const int q = 16 * (2 * (wave - 1) + gi) + lp;
@@ -535,8 +546,8 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
           const int qq = ok ? q : 0, ry = qq >> 2, cc = qq & 3, rx = cc < 2 ? cc : cc + 16;
           const bool in3 = ok && (unsigned)(ry - 1) < (unsigned)FbIn<3>::H && (unsigned)(rx - 1) < (unsigned)FbIn<3>::W;
           xg[gi][0] = fb_plane<1>(min(lq, 2)) + (ry * FbIn<1>::W + rx) * 16;
-          g2a[gi] = ok ? fb_plane<2>(pl) + half + (ry * FbIn<2>::W + rx) * 16 : FB_DUMP;
-          g3a[gi] = in3 ? fb_plane<3>(pl) + half + ((ry - 1) * FbIn<3>::W + rx - 1) * 16 : FB_DUMP;
+          g2a[gi] = ok ? fb_plane<2>(pl) + half + (ry * FbIn<2>::W + rx) * 16 : dump;
+          g3a[gi] = in3 ? fb_plane<3>(pl) + half + ((ry - 1) * FbIn<3>::W + rx - 1) * 16 : dump;
         }
         f32x4 acc[2], ga[2];
         fb_band<T, 1, 1, 2>(smem, xb, w1r, acc);
@@ -604,6 +615,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
       } else {                        // rows 3, 4 / 5, 6 and one group of halo columns (0, 17 of 10 rows: 20 pixels in 2 groups)
         const int row0 = 1 + 2 * wave;
         int xb[2], xg[2];
+        const int dump = FB_DUMP + (tid & 63) * 8;
         const int q = 16 * (wave - 1) + lp;
         const bool ok = q < 2 * FbIn<3>::H;
         const int qq = ok ? q : 0, ry = qq >> 1, rx = (qq & 1) ? 17 : 0;
@@ -612,7 +624,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void final_block_kernel(const FbArgs
           xb[k] = fb_plane<2>(min(4 * k + lq, 4)) + (row0 * FbIn<2>::W + 1 + lp) * 16;
           xg[k] = fb_plane<2>(min(4 * k + lq, 4)) + (ry * FbIn<2>::W + rx) * 16;
         }
-        const int g3a = ok ? fb_plane<3>(pl) + half + (ry * FbIn<3>::W + rx) * 16 : FB_DUMP;
+        const int g3a = ok ? fb_plane<3>(pl) + half + (ry * FbIn<3>::W + rx) * 16 : dump;
         f32x4 acc[2];
         fb_band<T, 2, 2, 2>(smem, xb, w2r, acc);
         const f32x4 ga = fb_group<T, 2, 2>(smem, xg, w2r);

@@ -100,7 +100,7 @@ class CdanEngine:
         self._ws = None
         self._ws_key = None
         self.use_side_streams = os.environ.get("MDIE_SIDE_STREAMS", "1") != "0"
-        self.chain_tail = os.environ.get("MDIE_CHAIN_TAIL", "0") == "1"   # A/B runs: decoder.final_dense as the four-launch chain (bit-identical)
+        self.block_tail = os.environ.get("MDIE_BLOCK_TAIL", "0") == "1"   # A/B runs: decoder.final_dense as ONE launch (bit-identical; slower than the chain: csrc/final_block.hip)
         mode = os.environ.get("MDIE_SHARE_CU_CONV4", "auto")
         self.share_cu = None if mode == "auto" else int(mode)          # None: the static default, or what an explicit tune() found; 0 .. 3: the form
         self._aux = C.c_void_p(0)
@@ -188,16 +188,16 @@ class CdanEngine:
             self._ws_key = key
         return self._ws
 
-    def _flags(self, general_tail=False, share_cu=0, chain_tail=False):
-        return ((0 if self.use_side_streams else L.FWD_SERIAL) | (L.FWD_GENERAL_TAIL if general_tail else 0) | (L.FWD_CHAIN_TAIL if (chain_tail or self.chain_tail) else 0)
+    def _flags(self, general_tail=False, share_cu=0, block_tail=False):
+        return ((0 if self.use_side_streams else L.FWD_SERIAL) | (L.FWD_GENERAL_TAIL if general_tail else 0) | (L.FWD_BLOCK_TAIL if (block_tail or self.block_tail) else 0)
                 | (L.FWD_SHARE_CU_CONV4 if share_cu == 1 else L.FWD_YIELD_CU_CONV4 if share_cu == 2 else
                    (L.FWD_YIELD_CU_CONV4 | L.FWD_LATE_DENSE1) if share_cu == 3 else 0))
 
-    def forward(self, x, out=None, want_taps=False, profile=False, general_tail=False, chain_tail=False):
+    def forward(self, x, out=None, want_taps=False, profile=False, general_tail=False, block_tail=False):
         """x: float32 NCHW [B,3,H,W] on this engine's GPU -> float32 NCHW [B,3,H,W].  Asynchronous on the current stream: enqueues the
         launches and returns; never times or synchronises anything (tune() is a separate, explicit call).
-        chain_tail / general_tail: decoder.final_dense as the four-launch chain / the general five-launch chain instead of the one-launch
-        block (bit-identical / within the order of one fp32 sum): A/B runs and tests."""
+        block_tail / general_tail: decoder.final_dense as ONE launch (csrc/final_block.hip) / as the general five-launch chain instead of the
+        four-launch chain with the transition folded in (bit-identical / within the order of one fp32 sum): A/B runs and tests."""
         if self.params is None:
             raise L.MdieError("CdanEngine.forward before load(state_dict)")
         _require_gpu(x, "CdanEngine.forward")
@@ -211,13 +211,13 @@ class CdanEngine:
             # the plain path goes through the registered operator (torch.ops.mdie.cdan_forward, ops.py)
             from . import ops  # noqa: F401  (registers the library)
             aux = self._aux.value if (self.use_side_streams and self._aux) else 0
-            return torch.ops.mdie.cdan_forward(x, self.params, ws, self.dtype, aux or 0, self._flags(general_tail, share, chain_tail))
+            return torch.ops.mdie.cdan_forward(x, self.params, ws, self.dtype, aux or 0, self._flags(general_tail, share, block_tail))
         y = out if out is not None else torch.empty_like(x)
         d = L.CdanFwdDesc()
         d.dtype, d.B, d.H, d.W = self.dtype, B, H, W
         d.params, d.x, d.y = self.params.data_ptr(), x.data_ptr(), y.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-        d.flags = self._flags(general_tail, share, chain_tail)
+        d.flags = self._flags(general_tail, share, block_tail)
         d.aux = self._aux if self.use_side_streams else None
         taps = (L.Tap * len(L.TAP_NAMES))() if want_taps else None
         if taps is not None:

@@ -24,7 +24,7 @@ FWD_GENERAL_TAIL = 4
 FWD_SHARE_CU_CONV4 = 16
 FWD_YIELD_CU_CONV4 = 32
 FWD_LATE_DENSE1 = 64
-FWD_CHAIN_TAIL = 128
+FWD_BLOCK_TAIL = 128
 LOSS_KINDS = {"mse": 0, "l1": 1, "charbonnier": 2, "ssim": 3, "gradient_l1": 4}
 
 TAP_NAMES = ("skip0", "skip1", "skip2", "dense0", "dense1", "dense2", "enc", "bott", "dec1", "dec2", "dec3", "dec4")

@@ -685,18 +685,18 @@ def test_final_block_one_launch_equals_the_chain(E, L, precision, shape):
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(2, 64, 64), (3, 128, 160), (32, 256, 256)])
 def test_network_with_the_one_launch_block_equals_the_chain(E, precision, shape):
-    """mdie_cdan_forward runs decoder.final_dense as ONE launch where the folded chain would run (16-bit types, whole 16x16 tiles, one weight
-    set, no taps); MDIE_FWD_CHAIN_TAIL puts the four-launch chain back.  Same arithmetic: the network's output must not change by a bit."""
+    """MDIE_FWD_BLOCK_TAIL: mdie_cdan_forward runs decoder.final_dense as ONE launch where the folded chain of four launches would run (16-bit
+    types, whole 16x16 tiles, one weight set, no taps).  Same arithmetic: the network's output must not change by a bit."""
     from oracle import params as P
     x, _ = P.lowlight_batch(45, *shape)
     x = x.cuda()
     eng = E.CdanEngine("cuda", precision).load(P.make_state_dict(42))
-    y_block = eng.forward(x, out=torch.empty_like(x)).clone()
-    y_chain = eng.forward(x, out=torch.empty_like(x), chain_tail=True).clone()
+    y_block = eng.forward(x, out=torch.empty_like(x), block_tail=True).clone()
+    y_chain = eng.forward(x, out=torch.empty_like(x)).clone()
     torch.cuda.synchronize()
     assert torch.equal(y_block, y_chain), f"{(y_block != y_chain).sum().item()} values differ, max {(y_block - y_chain).abs().max().item():.3e}"
-    _, ex_b = eng.forward(x, out=torch.empty_like(x), profile=True)
-    _, ex_c = eng.forward(x, out=torch.empty_like(x), profile=True, chain_tail=True)
+    _, ex_b = eng.forward(x, out=torch.empty_like(x), profile=True, block_tail=True)
+    _, ex_c = eng.forward(x, out=torch.empty_like(x), profile=True)
     assert len(ex_c["launches"]) - len(ex_b["launches"]) == 3, "four launches of the chain become one"
     assert abs(sum(b for _, b, _ in ex_b["launch_info"]) - sum(b for _, b, _ in ex_c["launch_info"])) <= 1e-6 * sum(b for _, b, _ in ex_c["launch_info"]), \
         "the block is booked at the chain's share of the SURVEY 8d byte model"
@@ -721,7 +721,7 @@ def test_forward_of_a_new_shape_does_not_synchronise_or_time_anything(E):
     torch.cuda.synchronize()
     assert eng._key(*shape) not in E._SHARE_CU and eng.form(*shape) == E.DEFAULT_FORM
     _, ex = eng.forward(x, out=y, profile=True)
-    assert len(ex["launches"]) == 36, len(ex["launches"])     # 39 of round 5, decoder.final_dense's four now one
+    assert len(ex["launches"]) == 39, len(ex["launches"])
 
 
 def test_transition_fusion_rejects_what_it_cannot_run(E, L):
