@@ -21,6 +21,13 @@
 
 namespace mdie {
 
+#ifdef EXP_UDSTAMPS   // diagnostic build only (tools/stamp_updense0.py): shader-clock stamps of wave 0 of every workgroup
+static unsigned long long* g_ud_dbg = nullptr;
+#define USTAMP(k) do { if (udbg && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); udbg[(size_t)blockIdx.x * 8 + (k)] = t_; } } while (0)
+#else
+#define USTAMP(k) do {} while (0)
+#endif
+
 constexpr int UD_THREADS = 256;
 constexpr int UD_TILE = 16, UD_PW = UD_TILE + 2;
 
@@ -34,6 +41,7 @@ struct UpDense0Args {
   const float* bias;              // [16]
   char* g0; int g0_stride;        // out: NHWC, 16 channels
   // TR: the block's transition folded into its producers (mdie_tr_fuse; the scheme is described in conv_thin.hip)
+  unsigned long long* dbg;        // (diagnostic builds)
   const char* tr_w; int tr_c0;    // the transition's packed 1x1 weights; its stored input channel of g0's channel 0 (base sits at 0..2)
   const float *tr_scale, *tr_shift;   // the transition's folded BatchNorm, by its stored input channel
   float* tr_out;                  // [pixel][4] fp32: the partial sums (base term + g0 term)
@@ -75,6 +83,12 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
   constexpr int PW = UD_PW;
   __shared__ __attribute__((aligned(16))) T patch[PW * PW * 4];
   __shared__ __attribute__((aligned(16))) T trpatch[TR ? UD_TILE * UD_TILE * 4 : 4];   // TR: relu(bn_tr(base)) of the tile's own pixels, [pixel][4]
+  // 16-bit types: the tile's 10 x 10 low-resolution pixels (channels 0..3, 8 bytes each) are loaded ONCE into LDS and the 4 bilinear taps of a
+  // patch pixel are LDS reads: 100 global loads per tile instead of 4 x 324.  The kernel ran at 3.0 TB/s of the bytes it must move with 9 scattered
+  // loads per thread; what such loads cost is their ISSUE on the vector memory path, not the wait (round 6: the one-launch block's base phase,
+  // profiles/r06f_final_block_v2_stamps.txt).  Same values, same arithmetic: outputs bit-identical.
+  constexpr int LW = UD_TILE / 2 + 2;
+  __shared__ __attribute__((aligned(8))) uint2 lostage[E == 2 ? LW * LW : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, lq = lane >> 4, lp = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,6 +112,10 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
     }
   }
 
+#ifdef EXP_UDSTAMPS
+  unsigned long long* const udbg = a0.dbg;
+#endif
+  USTAMP(0);
   // weight fragments and constants first: they land while the patch is computed
   uint4 wf[STEPS];
 #pragma unroll
@@ -121,6 +139,16 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
   constexpr int PIT = (PW * PW + UD_THREADS - 1) / UD_THREADS;
   float t[PIT][4][4], xin[PIT][3], hy[PIT][2], wx[PIT][2];
   bool inside[PIT];
+  const int ly0 = (y0 >> 1) - 1, lx0 = (x0 >> 1) - 1;      // low-resolution pixel of lostage[0][0] (may be -1: clamped when loaded, never addressed then)
+  int ltap[PIT][4];                                        // E == 2: byte offsets of the 4 taps in lostage
+  if constexpr (E == 2) {
+    if (tid < LW * LW) {
+      const int r = tid / LW, c = tid - r * LW;
+      const int ry = min(max(ly0 + r, 0), Hl - 1), rx = min(max(lx0 + c, 0), Wl - 1);
+      const char* lb = a.lo + (size_t)img * Hl * Wl * a.lo_stride * E;                   // wave-uniform
+      lostage[tid] = *reinterpret_cast<const uint2*>(lb + __umul24(__umul24(ry, Wl) + rx, (unsigned)a.lo_stride * E));
+    }
+  }
 #pragma unroll
   for (int it = 0; it < PIT; ++it) {
     const int p = tid + it * UD_THREADS;
@@ -139,15 +167,15 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
       ud_src(gx, Wl, xa, xb, wx[it][0], wx[it][1]);
       // addresses = wave-uniform image base + 32-bit lane offset from 24-bit multiplies (stamps of the first-layer kernel: a
       // 32-bit integer multiply or a 64-bit mad is 16 cycles of the SIMD, v_mul_u32_u24 is 4; the host checks the ranges)
-      const char* lb = a.lo + (size_t)img * Hl * Wl * a.lo_stride * E;
-      const unsigned ls = (unsigned)a.lo_stride * E, ra = __umul24(ya, Wl), rb = __umul24(yb, Wl);
-      const char* q[4] = {lb + __umul24(ra + xa, ls), lb + __umul24(ra + xb, ls), lb + __umul24(rb + xa, ls), lb + __umul24(rb + xb, ls)};
+      if constexpr (E == 2) {
+        const int ra = (ya - ly0) * LW, rb = (yb - ly0) * LW;
+        ltap[it][0] = (ra + xa - lx0) * 8; ltap[it][1] = (ra + xb - lx0) * 8; ltap[it][2] = (rb + xa - lx0) * 8; ltap[it][3] = (rb + xb - lx0) * 8;
+      } else {
+        const char* lb = a.lo + (size_t)img * Hl * Wl * a.lo_stride * E;
+        const unsigned ls = (unsigned)a.lo_stride * E, ra = __umul24(ya, Wl), rb = __umul24(yb, Wl);
+        const char* q[4] = {lb + __umul24(ra + xa, ls), lb + __umul24(ra + xb, ls), lb + __umul24(rb + xa, ls), lb + __umul24(rb + xb, ls)};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if constexpr (E == 2) {
-          const uint2 u = *reinterpret_cast<const uint2*>(q[k]);
-          t[it][k][0] = Half<T>::lo(u.x); t[it][k][1] = Half<T>::hi(u.x); t[it][k][2] = Half<T>::lo(u.y);
-        } else {
+        for (int k = 0; k < 4; ++k) {
           const float4 u = *reinterpret_cast<const float4*>(q[k]);
           t[it][k][0] = u.x; t[it][k][1] = u.y; t[it][k][2] = u.z;
         }
@@ -158,6 +186,20 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
       xin[it][1] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xbase + plane) + xo);
       xin[it][2] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xbase + 2 * plane) + xo);
     }
+  }
+  if constexpr (E == 2) {
+    USTAMP(1);
+    __syncthreads();                                       // the low-resolution pixels are staged
+    USTAMP(2);
+#pragma unroll
+    for (int it = 0; it < PIT; ++it)
+      if (inside[it]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(lostage) + ltap[it][k]);
+          t[it][k][0] = Half<T>::lo(u.x); t[it][k][1] = Half<T>::hi(u.x); t[it][k][2] = Half<T>::lo(u.y);
+        }
+      }
   }
 #pragma unroll
   for (int it = 0; it < PIT; ++it) {
@@ -209,7 +251,9 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
     const float4 s4 = *reinterpret_cast<const float4*>(a.tr_scale + a.tr_c0 + 4 * lq), b4 = *reinterpret_cast<const float4*>(a.tr_shift + a.tr_c0 + 4 * lq);
     trs[0] = f32x2{s4.x, s4.y}; trs[1] = f32x2{s4.z, s4.w}; trb[0] = f32x2{b4.x, b4.y}; trb[1] = f32x2{b4.z, b4.w};
   }
+  USTAMP(3);
   __syncthreads();
+  USTAMP(4);
 
   // ---- im2col gather (k = tap*3 + c) and one MFMA step per 16 pixels ----
   constexpr int KPL = E == 2 ? 3 : 4;
@@ -274,6 +318,10 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
     if (gy < a.H && gx < a.W)
       *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.tr_out + (size_t)img * plane * 4) + (__umul24(gy, a.W) + gx) * 16u) = make_float4(tacc[0], tacc[1], tacc[2], 0.f);
   }
+  USTAMP(5);
+#ifdef EXP_UDSTAMPS
+  if (udbg && tid == 0) { unsigned long long r_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_) :: "memory"); udbg[(size_t)blockIdx.x * 8 + 6] = r_; }
+#endif
 }
 
 }  // namespace mdie
@@ -307,6 +355,9 @@ extern "C" int mdie_up_add_dense0_fwd(const mdie_up_dense0_desc* d, void* stream
   a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift; a.bias = d->bias;
   a.g0 = reinterpret_cast<char*>(d->g0); a.g0_stride = d->g0_stride;
   a.delta = d->blob_delta;
+#ifdef EXP_UDSTAMPS
+  a.dbg = g_ud_dbg;
+#endif
   if (d->tr) {
     MDIE_REQUIRE(d->dtype != MDIE_F32 && d->base_channels == vec, "mdie_up_add_dense0_fwd: tr needs a 16-bit type with the base stored as one 16-byte group");
     MDIE_REQUIRE(d->tr->weight && d->tr->pre_scale && d->tr->pre_shift && d->tr->partial_out && d->tr->c0 >= vec && d->tr->c0 % 8 == 0 && !d->tr->out_nchw3,
@@ -333,3 +384,7 @@ extern "C" int mdie_up_add_dense0_fwd(const mdie_up_dense0_desc* d, void* stream
   MDIE_LAUNCH_CHECK("mdie_up_add_dense0_fwd");
   return MDIE_OK;
 }
+
+#ifdef EXP_UDSTAMPS
+extern "C" void mdie_exp_set_ud_dbg(void* p) { mdie::g_ud_dbg = (unsigned long long*)p; }
+#endif
