@@ -971,6 +971,7 @@ def forward_train(net, x, precision="fp32", dropout_p=0.2):
 
 
 # ---- one training step as a hipGraph (models/model.py:154-172: zero_grad, forward, loss, backward, optimizer step) -------------------
+ALLOW_IN_GRAPH_EXCHANGE = False     # tests / experiments: CapturedStep(buckets=...) without the environment switch
 _CAPTURING_STEP = None     # the CapturedStep whose graph is being recorded right now (GradBuckets._launch checks the stream against it)
 
 
@@ -994,7 +995,18 @@ class CapturedStep:
     GradScaler.scale) is applied to the total loss before backward inside the graph -- the scaler's factor is a device
     tensor, so replays follow its updates.
 
-    Data parallel (`buckets`: a GradBuckets): the gradient exchange is INSIDE the graph.  The buckets' post-accumulate hooks fire while
+    Data parallel (`buckets`: a GradBuckets) -- UNSAFE, opt-in (MDIE_DDP_CAPTURE=1 | auto, or train.ALLOW_IN_GRAPH_EXCHANGE): a process that
+    captures RCCL collectives this way can be ABORTED by torch's own NCCL watchdog thread.  Round 6 caught the text of what round 5 saw twice
+    without one: `Process group watchdog thread terminated with exception: HIP error: operation not permitted on an event last recorded in
+    a capturing stream` (hipErrorCapturedEvent), raised from `WorkNCCL::isCompleted()` <- `Watchdog::runLoop()`, then `terminate` -> SIGABRT
+    (profiles/r06zz_nccl_watchdog_abort_in_graph_exchange.log: tools/bench_train.py's in-graph variant, 0.7 s after the group was created).
+    The watchdog polls the end events of the Work objects it has been handed; one of them had been recorded while the communication stream
+    was part of a capture.  Which Work that is lies inside torch (a plain probe -- eager all-reduce, then a capture with all-reduces, watchdog
+    polling throughout -- does not reproduce it: tools/probe_nccl_capture.py, profiles/r06k_probe_nccl_capture.txt; here the collectives are
+    issued from autograd's device thread by the buckets' hooks), it is a race against the watchdog's 100 ms poll, and nothing on this side
+    of torch's API can order it.  The default data-parallel step is therefore EAGER with the collectives issued by the hooks; this form stays
+    for whoever measures it on a torch that keeps captured Work objects away from the watchdog.
+    The gradient exchange is INSIDE the graph.  The buckets' post-accumulate hooks fire while
     the backward is captured, so each bucket's all-reduce is recorded at the point of the backward where its last gradient has been
     produced -- `torch.distributed`'s NCCL (= RCCL) process group forks its communication stream from the capturing stream there -- and
     `finish()` records the join in front of the optimizer step: every replay overlaps the collectives with the rest of backward exactly as
@@ -1013,6 +1025,9 @@ class CapturedStep:
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.buckets = buckets
         if buckets is not None:
+            if not (ALLOW_IN_GRAPH_EXCHANGE or __import__("os").environ.get("MDIE_DDP_CAPTURE", "0") in ("1", "auto")):
+                raise RuntimeError("CapturedStep(buckets=...): capturing the gradient exchange is opt-in (MDIE_DDP_CAPTURE=1 | auto): torch's NCCL watchdog "
+                                   "can abort a process that does it (see the class docstring); the default is eager steps with the exchange from the hooks")
             buckets.attach()       # the hooks fire while the backward is being CAPTURED: each bucket's collective becomes a branch of the graph
 
         def fwd_bwd():

@@ -4,17 +4,20 @@
 Not collected by pytest (no test_ prefix).  The test runs this file as a child process and passes only when the child prints
 DDP-ONE-RANK-OK (every assertion sits in front of that line), then DDP-TEARDOWN-OK, and exits with code 0.
 
-Why a child, and what the teardown must look like.  Round 5 saw `destroy_process_group()` abort the interpreter once (SIGABRT: main
-thread inside torch/distributed/distributed_c10d.py destroy_process_group, a second thread with no Python frame, no text from c10d, RCCL
-or HIP: gpurun_out/r05a/poison.log; not reproduced in four more runs).  What was alive in that process: it had captured RCCL all-reduces
-into hipGraphs (CapturedStep(buckets=...), the section below) on the communicator being destroyed.  RCCL attaches a user object to such a
-graph (hipGraphRetainUserObject) whose destructor -- run by the HIP runtime on a thread of its own when the graph and its executables
-are finally released -- returns the captured plans to the communicator: the communicator must outlive every such graph, and "outlive"
-means the release has HAPPENED, not that the last Python reference was dropped.  The test then relied on `del cap` (no collection of
-reference cycles) and synchronised only BEFORE the final section; the product path (Model.train under torchrun) kept its graphs until
-interpreter exit and never destroyed the group.  The ordering rule, now one function used by every owner of a process group
-(mdie_amd.host.shutdown_distributed): drop the CapturedSteps, close the GradBuckets, gc.collect(), torch.cuda.synchronize(), and only
-then destroy_process_group().  A teardown that does not come back clean FAILS the test (round 5 downgraded it to a warning)."""
+Why a child, and what was found.  Round 5 saw this process die twice -- once with SIGABRT while the main thread was inside
+`destroy_process_group()` and a second thread had no Python frame (gpurun_out/r05a/poison.log), once with a C++ exception whose text was
+cut off.  Round 6 caught the text (profiles/r06zz_nccl_watchdog_abort_in_graph_exchange.log, tools/bench_train.py's in-graph variant):
+    Process group watchdog thread terminated with exception: HIP error: operation not permitted on an event last recorded in a capturing
+    stream (hipErrorCapturedEvent) -- raised from WorkNCCL::isCompleted() <- ProcessGroupNCCL::Watchdog::runLoop(), then terminate -> SIGABRT.
+The thread without a Python frame is torch's NCCL watchdog: it polls the end events of the Work objects it has been handed, and one of them
+had been recorded while the communication stream was part of a hipGraph capture -- which only happens in a process that captures RCCL
+collectives (`CapturedStep(..., buckets=bk)`, the in-graph exchange).  It is a race against the watchdog's poll (one run in five), it is not
+reproduced by a plain probe (tools/probe_nccl_capture.py), and nothing on this side of torch's API can order it.  So: (1) the product's
+data-parallel step is EAGER with the collectives issued by the hooks (MDIE_DDP_CAPTURE=0, the default); capturing the exchange is an explicit,
+documented-unsafe opt-in (train.CapturedStep); (2) this test exercises the in-graph form only under MDIE_TEST_IN_GRAPH_EXCHANGE=1; (3) every
+owner of a process group tears down in ONE order -- drop the CapturedSteps, close the GradBuckets, gc.collect(), torch.cuda.synchronize(), then
+destroy_process_group() (mdie_amd.host.shutdown_distributed) -- and a teardown that does not come back clean FAILS the test (round 5
+downgraded it to a warning)."""
 import os
 import sys
 
@@ -101,10 +104,14 @@ def main():
         buckets.close()
         del cap
 
+        # OFF by default (MDIE_TEST_IN_GRAPH_EXCHANGE=1 turns it on): capturing collectives is an opt-in, unsafe form -- torch's NCCL watchdog
+        # aborted tools/bench_train.py's in-graph variant with hipErrorCapturedEvent in round 6 (train.CapturedStep's docstring) -- and a test must
+        # not be a race against a 100 ms poll.
         # the exchange INSIDE the captured step (what host.Model.train runs under world > 1 at launch-bound sizes): the hooks fire while the
         # backward is captured, each bucket's all-reduce is a branch of the graph, finish() is the join in front of the captured Adam step.
         # Two replays on two batches: losses and parameters bit-identical to the captured step without any exchange (world size 1)
         def captured(with_buckets):
+            T.ALLOW_IN_GRAPH_EXCHANGE = True
             torch.manual_seed(5)
             net = CDAN(precision="bf16")
             net.load_state_dict(sd, strict=True)
@@ -120,9 +127,10 @@ def main():
                 bk.close()
             del cap
             return res
-        ref_c, got_c = captured(False), captured(True)
-        assert got_c[2], "in-graph exchange: a gradient was copied or .grad is not bucket memory"
-        assert all(torch.equal(u, v) for u, v in zip(got_c[0], ref_c[0])) and all(torch.equal(u, v) for u, v in zip(got_c[1], ref_c[1]))
+        if os.environ.get("MDIE_TEST_IN_GRAPH_EXCHANGE") == "1":
+            ref_c, got_c = captured(False), captured(True)
+            assert got_c[2], "in-graph exchange: a gradient was copied or .grad is not bucket memory"
+            assert all(torch.equal(u, v) for u, v in zip(got_c[0], ref_c[0])) and all(torch.equal(u, v) for u, v in zip(got_c[1], ref_c[1]))
 
         # one parameter, two gradients in one backward (the network applied twice) with the sink active: the second sighting must not
         # overwrite the slice the first, un-summed gradient lives in (GradBuckets.claim) -- gradients equal to the run without buckets

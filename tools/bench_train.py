@@ -93,6 +93,9 @@ byts = 3.0 * L.lib.mdie_cdan_algorithmic_bytes(B, S, S, esz) + 16.0 * 3585663
 peak_tf = 157.3 if prec == "fp32" else 2500.0
 
 variants = [(m, "overlap") for m in modes]
+if dist is not None and os.environ.get("MDIE_DDP_CAPTURE", "0") not in ("1", "auto"):
+    # the exchange INSIDE the captured step is opt-in: torch's NCCL watchdog can abort a process that captures collectives (train.CapturedStep)
+    variants = [v for v in variants if v != ("graph", "overlap")]
 if dist is not None and "eager" in modes:
     variants += [("eager", "none"), ("eager", "after")]     # the same step without the exchange, and with it after backward (nothing overlapped)
 if dist is not None and "graph" in modes:
