@@ -30,12 +30,16 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
     step()
 torch.cuda.synchronize()
-names = ("aten::zero_", "aten::fill_", "aten::zeros", "aten::zeros_like", "aten::ones", "aten::full", "aten::copy_", "aten::clone", "aten::add_", "aten::mul_", "aten::div_")
+names = ("aten::zero_", "aten::fill_", "aten::copy_", "aten::add_", "aten::mul_", "aten::div_", "aten::clone")
 by = collections.Counter()
 for e in prof.events():
     if e.name in names:
+        chain, q = [], e.cpu_parent
+        while q is not None and len(chain) < 6:
+            chain.append(q.name)
+            q = q.cpu_parent
         st = [s for s in (e.stack or []) if "mdie" in s or "multi-degradation" in s or "host.py" in s or "train.py" in s or "tools/" in s]
         shape = tuple(e.input_shapes[0]) if e.input_shapes else ()
-        by[(e.name, st[0] if st else (e.stack[0] if e.stack else "?"), shape)] += 1
+        by[(e.name, " <- ".join(chain) or (st[0] if st else "?"), shape)] += 1
 for (n, where, shape), c in sorted(by.items(), key=lambda kv: -kv[1]):
-    print(f"{c:4d}  {n:18s} {str(shape):24s} {where}")
+    print(f"{c:4d}  {n:14s} {str(shape):22s} {where[:200]}")
