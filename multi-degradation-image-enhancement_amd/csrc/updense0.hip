@@ -141,14 +141,45 @@ __global__ __launch_bounds__(UD_THREADS, 4) void up_dense0_kernel(const UpDense0
   bool inside[PIT];
   const int ly0 = (y0 >> 1) - 1, lx0 = (x0 >> 1) - 1;      // low-resolution pixel of lostage[0][0] (may be -1: clamped when loaded, never addressed then)
   int ltap[PIT][4];                                        // E == 2: byte offsets of the 4 taps in lostage
+  // INTERIOR tiles (the 18x18 patch and its 10x10 low-resolution pixels inside the picture, no tap clamped: 77 % of the tiles of a 256x256 picture):
+  // the half-pixel source of an x2 upsample is the pixel's parity -- tap weights 0.25 / 0.75, first tap at (p >> 1) of the staged pixels -- so the
+  // float arithmetic of ud_src, the clamps and the in-picture tests go (the kernel is bound by vector issue: profiles/r06j_up_dense0_stamps.txt,
+  // 4.3 k of a workgroup's 12.7 k cycles in this index phase).  ud_src's values exactly: bit-identical.
+  const bool interior = E == 2 && y0 >= 2 && y0 + UD_TILE + 2 <= a.H && x0 >= 2 && x0 + UD_TILE + 2 <= a.W;     // (workgroup-uniform)
   if constexpr (E == 2) {
     if (tid < LW * LW) {
       const int r = tid / LW, c = tid - r * LW;
-      const int ry = min(max(ly0 + r, 0), Hl - 1), rx = min(max(lx0 + c, 0), Wl - 1);
+      const int ry = interior ? ly0 + r : min(max(ly0 + r, 0), Hl - 1), rx = interior ? lx0 + c : min(max(lx0 + c, 0), Wl - 1);
       const char* lb = a.lo + (size_t)img * Hl * Wl * a.lo_stride * E;                   // wave-uniform
       lostage[tid] = *reinterpret_cast<const uint2*>(lb + __umul24(__umul24(ry, Wl) + rx, (unsigned)a.lo_stride * E));
     }
   }
+  if (interior) {
+    if constexpr (E == 2) {
+      const float* const xtile = a.x + (size_t)img * 3 * plane + (size_t)(y0 - 1) * a.W + (x0 - 1);      // wave-uniform: patch pixel (0, 0)
+#pragma unroll
+      for (int it = 0; it < PIT; ++it) {
+        const int p = tid + it * UD_THREADS;
+        const int py = p / PW, px = p - py * PW;
+        inside[it] = p < PW * PW;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) t[it][k][c] = 0.f;
+        xin[it][0] = xin[it][1] = xin[it][2] = 0.f;
+        hy[it][1] = (py & 1) ? 0.75f : 0.25f; hy[it][0] = 1.0f - hy[it][1];      // patch row py = picture row y0 - 1 + py: odd py is an even row
+        wx[it][1] = (px & 1) ? 0.75f : 0.25f; wx[it][0] = 1.0f - wx[it][1];
+        ltap[it][0] = ((py >> 1) * LW + (px >> 1)) * 8;
+        ltap[it][1] = ltap[it][0] + 8; ltap[it][2] = ltap[it][0] + LW * 8; ltap[it][3] = ltap[it][0] + LW * 8 + 8;
+        if (inside[it]) {
+          const unsigned xo = (__umul24(py, a.W) + px) * 4u;
+          xin[it][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xtile) + xo);
+          xin[it][1] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xtile + plane) + xo);
+          xin[it][2] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xtile + 2 * plane) + xo);
+        }
+      }
+    }
+  } else
 #pragma unroll
   for (int it = 0; it < PIT; ++it) {
     const int p = tid + it * UD_THREADS;
