@@ -10,6 +10,12 @@
 // to HBM and read back (up to 3 x with an 18x18 halo) by the next launch.  Here the block reads t4 (8 bytes per low-resolution
 // pixel) and x and writes y: ~45 MB per step.
 //
+// MEASURED (round 6, profiles/r06*_final_block_*, LEDGER round 6): bit-identical to the chain on every shape, and SLOWER -- 292-319 us against
+// 235 us.  The traffic is gone; what binds instead is vector-instruction issue and per-wave latency chains: every layer pre-activates every input
+// element (175 per output pixel before any halo), two waves per SIMD is all that 250 registers and 78 KB of LDS leave, and a wave runs at
+// 8-10 cycles per instruction (SQ counters: 40 % issuing, 39 % in s_waitcnt / barriers, 21 % dependency stalls, the matrix pipe 22 % busy; LDS is
+// not the limit).  The engine therefore runs the chain by default; MDIE_FWD_BLOCK_TAIL selects this kernel (A/B runs, tests, a starting point).
+//
 // LDS holds ACTIVATED operands, per consumer.  Layer l applies its OWN BatchNorm to every channel of its input
 // (models/cdan.py:41-46), so relu(bn_l(g_j)) differs per (l, j).  The producer of g_j has the map in registers (4 channels of one
 // pixel per lane = the MFMA accumulator layout): its epilogue rounds g_j to the storage type once (what the chain stores) and
