@@ -506,7 +506,7 @@ def test_upsample_into_first_dense_layer_fused(E, L, precision):
     assert (g0[..., :8] == -7.0).all() and (g0[..., 24:] == -7.0).all()
 
 
-def _final_dense_problem(E, L, precision, shape):
+def _final_dense_problem(E, L, precision, shape, signed_scales=False):
     """decoder.final_dense (models/cdan.py:22-53,119,153-157) on seeded parameters, behind three forms of the C ABI:
     run(fold=False): mdie_up_add_dense0_fwd, three 3x3 layers, the 1x1 launch; run(fold=True[, half=True]): the transition folded into the
     four producers (mdie_tr_fuse); run_block(): ONE launch (mdie_final_dense_fwd).  Returns (run, run_block, ref) with ref() = torch's CPU
@@ -527,6 +527,10 @@ def _final_dense_problem(E, L, precision, shape):
     pbs = [torch.randn(3 + 16 * l, generator=g) * 0.3 for l in range(4)]
     wt, bt = torch.randn(3, 67, 1, 1, generator=g) * 0.2, torch.randn(3, generator=g) * 0.2
     pst, pbt = torch.rand(67, generator=g) + 0.5, torch.randn(67, generator=g) * 0.3
+    if signed_scales:      # a trained BatchNorm's gamma may be negative or (pruned) zero: every third scale flipped, every seventh zero
+        for v in pss + [pst]:
+            v[1::3] *= -1.0
+            v[2::7] = 0.0
 
     def stored(v, n):          # real channel c >= 3 sits at stored channel c + 5 (the base is one 8-channel group)
         out = torch.zeros(n)
@@ -680,6 +684,18 @@ def test_final_block_one_launch_equals_the_chain(E, L, precision, shape):
         assert torch.equal(y_b, y_f), f"one launch vs folded chain: {(y_b != y_f).sum().item()} of {y_b.numel()} values differ, max {(y_b - y_f).abs().max().item():.3e}"
     assert torch.equal(run_block(), y_b), "run-to-run"
     assert rel_to_max(y_b, ref_of(base_u)) <= {"bf16": BF16_TOL, "fp16": F16_TOL}[precision]     # (torch CPU arithmetic: the operator bound)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_final_block_with_negative_and_zero_batchnorm_scales(E, L, precision):
+    """The one-launch block against the chain when a third of the folded BatchNorm scales are negative and some are zero (a trained gamma may be
+    either): the block keeps the chain's pre-activation arithmetic, so nothing about it depends on a scale's sign -- bit-identical again."""
+    run, run_block, ref_of = _final_dense_problem(E, L, precision, (3, 48, 64), signed_scales=True)
+    base_u, _, y_u = run(False)
+    _, _, y_f = run(True, half=True)
+    y_b = run_block()
+    assert torch.equal(y_b, y_f) and (y_b - y_u).abs().max().item() <= 3e-6
+    assert rel_to_max(y_b, ref_of(base_u)) <= {"bf16": BF16_TOL, "fp16": F16_TOL}[precision]
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
