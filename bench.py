@@ -426,7 +426,7 @@ def main():
         # through nn.Module.forward (state_dict fingerprint walk + output allocation per call) instead of the C ABI call above
         extra = {}
         with torch.no_grad():
-            t_mod = timed_loop(lambda: net(x), dev, 20)
+            t_mod = timed_loop(lambda: net(x), dev, 60, warm=10)   # (long enough for the launch queue to fill: 20 calls read 8 % slow)
             extra["module_forward_bf16" if args.precision == "bf16" else f"module_forward_{args.precision}"] = {
                 "images_per_sec": round(B / t_mod, 1), "ms_per_step": round(t_mod * 1e3, 4),
                 "what": "net(x) through models.cdan.CDAN.forward (eager launches), same batch"}
