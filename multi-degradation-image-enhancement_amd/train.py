@@ -228,6 +228,14 @@ def _zeros(n, dev):
     return _ZEROS[key]
 
 
+# How the training step's wide (conv_wide) layers treat their CUs: 0 = one persistent workgroup per CU until the launch ends (the default: fastest
+# alone), 2 = two shorter runs per CU -- every CU returns to the dispatcher half way -- 1 = conv_kernel (mdie_conv_desc.share_cu; the forms are
+# bit-identical).  On ONE GPU nothing runs beside these layers and 0 wins; under data parallelism RCCL's all-reduce kernels need CUs while backward is
+# still running, and a persistent workgroup that holds its CU until its launch ends is exactly what starved the DenseBlock branches in inference
+# (DESIGN section 4 / 7).  MDIE_TRAIN_SHARE_CU=2 is the switch for the first multi-GPU run to A/B against exposed all-reduce time; unmeasured here.
+WIDE_SHARE_CU = int(__import__("os").environ.get("MDIE_TRAIN_SHARE_CU", "0"))
+
+
 def _conv_raw(dt, segs, packed, bias_st, ks, cout_st, out, pre=None, act=L.ACT_NONE, out_nchw3=None, planar=False, bnred=None):
     """out = act(conv_k(relu(cat(segs) * pre_scale + pre_shift)?) + bias); out: NHWC view with >= cout_st channels, or
     (planar) a [cout_st / 16, B*H*W, 16] tensor: one plane per 16 output channels (mdie_conv_desc.out_group_stride)."""
@@ -250,6 +258,7 @@ def _conv_raw(dt, segs, packed, bias_st, ks, cout_st, out, pre=None, act=L.ACT_N
     else:
         d.out, d.out_stride = out.data_ptr(), out.stride(3)
     d.out_nchw3 = out_nchw3.data_ptr() if out_nchw3 is not None else None
+    d.share_cu = WIDE_SHARE_CU
     if bnred is not None:     # (x segments, scale, shift, partial): the BatchNorm-ReLU backward sums of x ride on this input-gradient convolution
         xsegs, bsc, bsh, partial = bnred
         r = L.BnReduceFuse()

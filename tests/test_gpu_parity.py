@@ -2503,6 +2503,36 @@ def test_side_stream_weight_gradients_equal_main_stream(E, precision, shape, mon
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", [2, 1])
+def test_training_step_is_bit_identical_in_the_cu_sharing_forms_of_its_wide_layers(E, monkeypatch, form):
+    """MDIE_TRAIN_SHARE_CU (train.WIDE_SHARE_CU): the training step's conv_wide layers in two shorter runs per CU (2) or on conv_kernel (1) instead of
+    one persistent workgroup per CU -- the switch a multi-GPU run A/Bs against exposed all-reduce time.  A schedule, not arithmetic: loss, every
+    gradient and the updated BatchNorm statistics of one step at a shape conv_wide takes (8 x 256 x 256) must not change by a bit."""
+    import mdie_amd.train as T
+    from models.cdan import CDAN
+    from oracle import params as P
+    sd = P.make_state_dict(42)
+    x, t = (v.cuda() for v in P.lowlight_batch(61, 8, 256, 256))
+
+    def run(share):
+        monkeypatch.setattr(T, "WIDE_SHARE_CU", share)
+        torch.manual_seed(7)
+        net = CDAN(precision="bf16")
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().train()
+        loss = torch.sqrt((net(x) - t) ** 2 + 1e-6).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), [p.grad.clone() for p in net.parameters()], [b.clone() for b in net.buffers()]
+
+    a, b = run(0), run(form)
+    assert torch.equal(a[0], b[0])
+    bad = [i for i, (u, v) in enumerate(zip(a[1], b[1])) if not torch.equal(u, v)]
+    assert not bad, f"{len(bad)} gradients differ between the forms"
+    assert all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
+
+
+@pytest.mark.gpu
 def test_ddp_one_rank_nccl_gradients_live_in_the_buckets(E, monkeypatch):
     """The data-parallel step on RCCL (a ONE-rank "nccl" group: the one-GPU box has no second device, the code path -- grad hooks ->
     bucket complete -> asynchronous all-reduce on the communication stream -> finish -- is the one eight ranks run; the step being
